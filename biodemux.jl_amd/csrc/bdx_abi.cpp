@@ -1,0 +1,457 @@
+// bdx_abi.cpp — C-ABI of libbiodemux_hip.so (see include/biodemux_hip.h for the contract and
+// the reference lines each entry point replaces).  Host-side only: validation, table upload,
+// launch planning, staging buffers.  All arithmetic of the hot path runs in the gfx950
+// kernels of bdx_device.hip / bdx_filter.hip; there is NO CPU fallback — without a usable
+// HIP device every entry point fails with BDX_E_DEVICE.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bdx_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct bdx_ctx {
+    bdx_config_t cfg{};
+    BdxDevCfg dev{};
+    BdxGenericPlan plan{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // device tables
+    DevBuf bc_bytes[2], bc_off[2], bc_nn[2];
+    DevBuf counts_own;
+    unsigned long long *counts = nullptr;
+    // staging for the host entry point
+    DevBuf d_seq, d_off, d_out_i32, d_out_f64;
+    // candidate masks (filtered paths)
+    DevBuf d_cand[2];
+    std::string err;
+    std::string path;
+    int64_t launches = 0;
+    int64_t last_blocks = 0;
+};
+
+namespace {
+
+int fail(bdx_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(ctx, BDX_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__));     \
+    } while (0)
+
+BdxDevRange cvt_range(const bdx_range_t &r) {
+    BdxDevRange d;
+    d.start_offset = r.start_offset;
+    d.end_offset = r.end_offset;
+    d.start_from_end = r.start_from_end != 0;
+    d.end_from_end = r.end_from_end != 0;
+    return d;
+}
+
+const size_t LDS_MAX = 160 * 1024;
+
+// Launch planning for the exact-evaluation kernel: per-lane DP (+origin) columns, barcode
+// tables, count histogram and the read staging area must fit the CU's 160 KiB of LDS.
+int plan_generic(bdx_ctx *ctx) {
+    const BdxDevCfg &d = ctx->dev;
+    BdxGenericPlan &p = ctx->plan;
+    p.dp_rows = d.max_m + 1;
+    const size_t per_thread = (size_t)p.dp_rows * 4 * (d.any_traceback ? 2 : 1);
+    const int B0 = d.pass[0].n_barcodes, B1 = d.is_dual ? d.pass[1].n_barcodes : 0;
+    size_t bc_total = 0;
+    for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) bc_total += ctx->cfg.pass[k].bc_off[ctx->cfg.pass[k].n_barcodes];
+    p.bc_stage_bytes = bc_total <= 32 * 1024 ? (int)((bc_total + 15) & ~(size_t)15) : 0;
+    if (p.bc_stage_bytes == 0 && bc_total > 0 && bc_total <= 32 * 1024) p.bc_stage_bytes = 16;
+    p.hist_entries = d.n_counts <= 4096 ? d.n_counts : 0;
+    const size_t fixed = (size_t)(B0 + 1 + B1 + 1 + B0 + B1) * 4 + 16 + (size_t)p.bc_stage_bytes + 16 +
+                         (size_t)p.hist_entries * 4 + 16;
+    const int tries[3] = {256, 128, 64};
+    for (int t : tries) {
+        const size_t need = fixed + per_thread * (size_t)t;
+        if (need + 4096 > LDS_MAX && !(t == 64 && need <= LDS_MAX)) continue;
+        p.threads = t;
+        // Read staging: aim for two resident workgroups per CU (<= 80 KiB each) when that
+        // still leaves room for ~192 B per read; otherwise take what is left of the CU.
+        size_t budget = need < 80 * 1024 ? 80 * 1024 - need : 0;
+        if (budget < (size_t)t * 192) budget = LDS_MAX - need;
+        size_t stage = budget > 64 * 1024 ? 64 * 1024 : budget;
+        stage &= ~(size_t)15;
+        if (stage < 1024 || p.bc_stage_bytes == 0) stage = 0;
+        p.stage_bytes = (int)stage;
+        p.lds_bytes = need + stage;
+        return BDX_OK;
+    }
+    return fail(ctx, BDX_E_INVALID,
+                "barcodes too long for the on-chip DP columns: max length %d needs %zu B of LDS per lane "
+                "(limit: 64 lanes within 160 KiB)",
+                d.max_m, per_thread);
+}
+
+int validate(const bdx_config_t *c) {
+    if (!c) return fail(nullptr, BDX_E_INVALID, "config is NULL");
+    if (c->abi_version != BDX_ABI_VERSION)
+        return fail(nullptr, BDX_E_INVALID, "ABI version mismatch: header %u, library %u", c->abi_version,
+                    (unsigned)BDX_ABI_VERSION);
+    if (c->struct_size != sizeof(bdx_config_t))
+        return fail(nullptr, BDX_E_INVALID, "bdx_config_t size mismatch: caller %u, library %zu", c->struct_size,
+                    sizeof(bdx_config_t));
+    if (c->algorithm < BDX_ALG_SEMIGLOBAL || c->algorithm > BDX_ALG_EXACT)
+        return fail(nullptr, BDX_E_INVALID, "unknown matching_algorithm %d", c->algorithm);
+    if (!std::isfinite(c->max_error_rate) || std::fabs(c->max_error_rate) > BDX_MAX_RATE)
+        return fail(nullptr, BDX_E_INVALID, "max_error_rate must be finite and |rate| <= %g", BDX_MAX_RATE);
+    if (!std::isfinite(c->min_delta)) return fail(nullptr, BDX_E_INVALID, "min_delta must be finite");
+    const int costs[4] = {c->match, c->mismatch, c->indel, c->has_nindel ? c->nindel : 1};
+    for (int v : costs)
+        if (v > BDX_MAX_COST || v < -BDX_MAX_COST)
+            return fail(nullptr, BDX_E_INVALID, "scoring costs must lie in [-%d, %d]", BDX_MAX_COST, BDX_MAX_COST);
+    if (c->algorithm == BDX_ALG_SEMIGLOBAL) {
+        // the reference divides by indel / min(indel, nindel) (classification.jl:170-176);
+        // a zero divisor raises DivideError there for every read.
+        const int div = c->has_nindel ? (c->indel < c->nindel ? c->indel : c->nindel) : c->indel;
+        if (div == 0) return fail(nullptr, BDX_E_INVALID, "indel (and nindel) must be non-zero (DivideError in the reference)");
+    }
+    const int npass = c->is_dual ? 2 : 1;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c->pass[k];
+        // core.jl:308-313
+        if (p.trim_side != 0 && p.trim_side != 3 && p.trim_side != 5)
+            return fail(nullptr, BDX_E_INVALID, "trim_side%s must be 3 or 5, got %d", k ? "2" : "", p.trim_side);
+        if (p.n_barcodes < 1) return fail(nullptr, BDX_E_INVALID, "pass %d has no barcodes", k + 1);
+        if (!p.bc_bytes || !p.bc_off || !p.bc_len_no_N)
+            return fail(nullptr, BDX_E_INVALID, "pass %d barcode tables are NULL", k + 1);
+        if (p.bc_off[0] != 0) return fail(nullptr, BDX_E_INVALID, "bc_off[0] must be 0");
+        for (int i = 0; i < p.n_barcodes; ++i) {
+            if (p.bc_off[i + 1] < p.bc_off[i]) return fail(nullptr, BDX_E_INVALID, "bc_off must be non-decreasing");
+            const uint32_t m = p.bc_off[i + 1] - p.bc_off[i];
+            if (m == 0)
+                return fail(nullptr, BDX_E_INVALID, "barcode %d of pass %d is empty (outside the supported domain)", i + 1, k + 1);
+            if (m > BDX_MAX_M)
+                return fail(nullptr, BDX_E_INVALID, "barcode %d of pass %d is longer than %d", i + 1, k + 1, BDX_MAX_M);
+            if (p.bc_len_no_N[i] < 0 || p.bc_len_no_N[i] > (int32_t)m)
+                return fail(nullptr, BDX_E_INVALID, "bc_len_no_N[%d] out of range", i);
+        }
+        if (p.explicit_window < 0 || p.explicit_window > BDX_WINDOW_ALIGN_ONE)
+            return fail(nullptr, BDX_E_INVALID, "explicit_window must be 0, 1 or 2");
+        if (p.explicit_window) {
+            const int64_t lim = (int64_t)1 << 30;
+            const int64_t w[4] = {p.win_first, p.win_last, p.win_max_start_pos, p.win_min_end_pos};
+            for (int64_t v : w)
+                if (v > lim || v < -lim) return fail(nullptr, BDX_E_INVALID, "explicit window values must be within +-2^30");
+        }
+    }
+    return BDX_OK;
+}
+
+int upload_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxDevCfg &d = ctx->dev;
+    d.algorithm = c.algorithm;
+    d.is_dual = c.is_dual != 0;
+    d.max_error_rate = c.max_error_rate;
+    d.min_delta = c.min_delta;
+    d.match = c.match;
+    d.mismatch = c.mismatch;
+    d.indel = c.indel;
+    d.has_nindel = c.has_nindel != 0;
+    d.nindel = c.has_nindel ? c.nindel : 0;
+    d.need_traceback = c.need_traceback != 0;
+    d.max_m = 1;
+    d.any_traceback = d.need_traceback;
+    const int npass = d.is_dual ? 2 : 1;
+    for (int k = 0; k < 2; ++k) {
+        BdxDevPass &P = d.pass[k];
+        memset(&P, 0, sizeof P);
+        if (k >= npass) continue;
+        const bdx_pass_t &p = c.pass[k];
+        P.ref_search = cvt_range(p.ref_search_range);
+        P.bc_start = cvt_range(p.barcode_start_range);
+        P.bc_end = cvt_range(p.barcode_end_range);
+        P.trim_side = p.trim_side;
+        P.n_barcodes = p.n_barcodes;
+        P.cand_words = (p.n_barcodes + 31) / 32;
+        P.explicit_window = p.explicit_window;
+        P.win_first = p.win_first;
+        P.win_last = p.win_last;
+        P.win_max_start = p.win_max_start_pos;
+        P.win_min_end = p.win_min_end_pos;
+        if (p.trim_side != 0) d.any_traceback = 1;
+        const size_t nbytes = p.bc_off[p.n_barcodes];
+        for (int i = 0; i < p.n_barcodes; ++i) {
+            const int m = (int)(p.bc_off[i + 1] - p.bc_off[i]);
+            if (m > d.max_m) d.max_m = m;
+        }
+        HIP_TRY(ctx, ctx->bc_bytes[k].ensure(nbytes + 16));
+        HIP_TRY(ctx, ctx->bc_off[k].ensure((size_t)(p.n_barcodes + 1) * 4));
+        HIP_TRY(ctx, ctx->bc_nn[k].ensure((size_t)p.n_barcodes * 4));
+        HIP_TRY(ctx, hipMemcpy(ctx->bc_bytes[k].p, p.bc_bytes, nbytes, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->bc_off[k].p, p.bc_off, (size_t)(p.n_barcodes + 1) * 4, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->bc_nn[k].p, p.bc_len_no_N, (size_t)p.n_barcodes * 4, hipMemcpyHostToDevice));
+        P.bc_bytes = (const uint8_t *)ctx->bc_bytes[k].p;
+        P.bc_off = (const uint32_t *)ctx->bc_off[k].p;
+        P.bc_len_no_N = (const int32_t *)ctx->bc_nn[k].p;
+    }
+    d.counts_stride2 = d.is_dual ? (d.pass[1].n_barcodes > 1 ? d.pass[1].n_barcodes : 1) : 1;
+    const long long nc = 4LL + (long long)d.pass[0].n_barcodes * d.counts_stride2;
+    if (nc > (1LL << 28)) return fail(ctx, BDX_E_INVALID, "sample_counts table too large (%lld entries)", nc);
+    d.n_counts = (int)nc;
+    // allowed_error = floor(rate * normalisation) must stay inside the int32 DP domain
+    if (std::fabs(c.max_error_rate) * (double)d.max_m >= (double)(1 << 27))
+        return fail(ctx, BDX_E_INVALID, "max_error_rate * barcode length exceeds the supported range");
+    HIP_TRY(ctx, ctx->counts_own.ensure((size_t)d.n_counts * 8));
+    HIP_TRY(ctx, hipMemset(ctx->counts_own.p, 0, (size_t)d.n_counts * 8));
+    ctx->counts = (unsigned long long *)ctx->counts_own.p;
+    return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bdx_abi_version(void) { return BDX_ABI_VERSION; }
+
+const char *bdx_last_error(const bdx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
+    if (!out) return fail(nullptr, BDX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = validate(config);
+    if (rc != BDX_OK) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, BDX_E_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (config->device < 0 || config->device >= ndev)
+        return fail(nullptr, BDX_E_INVALID, "device ordinal %d out of range (0..%d)", config->device, ndev - 1);
+    bdx_ctx *ctx = new (std::nothrow) bdx_ctx();
+    if (!ctx) return fail(nullptr, BDX_E_DEVICE, "out of host memory");
+    ctx->cfg = *config;
+    ctx->device = config->device;
+    auto bail = [&](int code) {
+        g_create_error = ctx->err;
+        bdx_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        ctx->err = "hipSetDevice failed";
+        return bail(BDX_E_DEVICE);
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx->err = "hipStreamCreate failed";
+        return bail(BDX_E_DEVICE);
+    }
+    ctx->stream = ctx->own_stream;
+    rc = upload_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
+    rc = plan_generic(ctx);  // needs the caller's host tables: run before they are dropped
+    if (rc != BDX_OK) return bail(rc);
+    ctx->path = "generic";
+    // the copied config must not keep pointing at caller memory
+    for (int k = 0; k < 2; ++k) {
+        ctx->cfg.pass[k].bc_bytes = nullptr;
+        ctx->cfg.pass[k].bc_off = nullptr;
+        ctx->cfg.pass[k].bc_len_no_N = nullptr;
+    }
+    if (bdx_generic_set_lds_limit(LDS_MAX) != hipSuccess) {
+        ctx->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+        return bail(BDX_E_DEVICE);
+    }
+    *out = ctx;
+    return BDX_OK;
+}
+
+void bdx_destroy(bdx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->own_stream);
+        (void)hipStreamDestroy(ctx->own_stream);
+    }
+    for (int k = 0; k < 2; ++k) {
+        ctx->bc_bytes[k].release();
+        ctx->bc_off[k].release();
+        ctx->bc_nn[k].release();
+        ctx->d_cand[k].release();
+    }
+    ctx->counts_own.release();
+    ctx->d_seq.release();
+    ctx->d_off.release();
+    ctx->d_out_i32.release();
+    ctx->d_out_f64.release();
+    delete ctx;
+}
+
+int32_t bdx_set_stream(bdx_ctx *ctx, void *hip_stream) {
+    if (!ctx) return BDX_E_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return BDX_OK;
+}
+
+int32_t bdx_sync(bdx_ctx *ctx) {
+    if (!ctx) return BDX_E_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDX_OK;
+}
+
+int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int64_t *d_seq_off, int64_t n_reads,
+                            const bdx_outputs_t *d_out) {
+    if (!ctx) return BDX_E_INVALID;
+    if (n_reads < 0) return fail(ctx, BDX_E_INVALID, "n_reads is negative");
+    if (n_reads == 0) return BDX_OK;
+    if (!d_seq_bytes || !d_seq_off || !d_out) return fail(ctx, BDX_E_INVALID, "NULL device pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BdxDevOut o;
+    o.bc1 = d_out->bc1;
+    o.bc2 = d_out->bc2;
+    o.keep_start = d_out->keep_start;
+    o.keep_end = d_out->keep_end;
+    o.pass_start = d_out->pass_start;
+    o.pass_end = d_out->pass_end;
+    o.pass_raw = d_out->pass_raw;
+    o.pass_score = d_out->pass_score;
+    o.pass_bc = d_out->pass_bc;
+    o.pass_delta = d_out->pass_delta;
+    HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                    ctx->counts, nullptr, nullptr, ctx->stream));
+    ctx->launches += 1;
+    ctx->last_blocks = (n_reads + ctx->plan.threads - 1) / ctx->plan.threads;
+    return BDX_OK;
+}
+
+int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t *seq_off, int64_t n_reads,
+                          const bdx_outputs_t *out) {
+    if (!ctx) return BDX_E_INVALID;
+    if (n_reads < 0) return fail(ctx, BDX_E_INVALID, "n_reads is negative");
+    if (n_reads == 0) return BDX_OK;
+    if (!seq_bytes || !seq_off || !out) return fail(ctx, BDX_E_INVALID, "NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t base = seq_off[0];
+    const int64_t total = seq_off[n_reads] - base;
+    if (total < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
+    // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
+    HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));
+    HIP_TRY(ctx, ctx->d_off.ensure((size_t)(n_reads + 1) * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_seq.p, seq_bytes + base, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    // int32 outputs: bc1 bc2 keep_start keep_end (n each), pass_start pass_end pass_raw pass_bc (2n each)
+    const size_t n = (size_t)n_reads;
+    HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
+    HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
+    int32_t *bi = (int32_t *)ctx->d_out_i32.p;
+    bdx_outputs_t d{};
+    d.bc1 = bi;
+    d.bc2 = out->bc2 ? bi + n : nullptr;
+    d.keep_start = out->keep_start ? bi + 2 * n : nullptr;
+    d.keep_end = out->keep_end ? bi + 3 * n : nullptr;
+    d.pass_start = out->pass_start ? bi + 4 * n : nullptr;
+    d.pass_end = out->pass_end ? bi + 6 * n : nullptr;
+    d.pass_raw = out->pass_raw ? bi + 8 * n : nullptr;
+    d.pass_bc = out->pass_bc ? bi + 10 * n : nullptr;
+    d.pass_score = out->pass_score ? (double *)ctx->d_out_f64.p : nullptr;
+    d.pass_delta = out->pass_delta ? (double *)ctx->d_out_f64.p + 2 * n : nullptr;
+    // kernel sees the byte base shifted by -base so that off[i] addresses read i
+    const uint8_t *d_seq_rebased = (const uint8_t *)ctx->d_seq.p - base;
+    int rc = bdx_classify_device(ctx, d_seq_rebased, (const int64_t *)ctx->d_off.p, n_reads, &d);
+    if (rc != BDX_OK) return rc;
+    auto back = [&](void *h, const void *dv, size_t bytes) -> hipError_t {
+        if (!h || !dv) return hipSuccess;
+        return hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIP_TRY(ctx, back(out->bc1, d.bc1, n * 4));
+    HIP_TRY(ctx, back(out->bc2, d.bc2, n * 4));
+    HIP_TRY(ctx, back(out->keep_start, d.keep_start, n * 4));
+    HIP_TRY(ctx, back(out->keep_end, d.keep_end, n * 4));
+    HIP_TRY(ctx, back(out->pass_start, d.pass_start, n * 8));
+    HIP_TRY(ctx, back(out->pass_end, d.pass_end, n * 8));
+    HIP_TRY(ctx, back(out->pass_raw, d.pass_raw, n * 8));
+    HIP_TRY(ctx, back(out->pass_bc, d.pass_bc, n * 8));
+    HIP_TRY(ctx, back(out->pass_score, d.pass_score, n * 16));
+    HIP_TRY(ctx, back(out->pass_delta, d.pass_delta, n * 16));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDX_OK;
+}
+
+int64_t bdx_counts_len(const bdx_ctx *ctx) { return ctx ? ctx->dev.n_counts : 0; }
+
+int32_t bdx_get_counts(bdx_ctx *ctx, int64_t *out, int64_t n) {
+    if (!ctx || !out) return BDX_E_INVALID;
+    if (n < ctx->dev.n_counts) return fail(ctx, BDX_E_INVALID, "counts buffer too small: need %d", ctx->dev.n_counts);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->counts, (size_t)ctx->dev.n_counts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDX_OK;
+}
+
+int32_t bdx_reset_counts(bdx_ctx *ctx) {
+    if (!ctx) return BDX_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts, 0, (size_t)ctx->dev.n_counts * 8, ctx->stream));
+    return BDX_OK;
+}
+
+void *bdx_counts_device_ptr(bdx_ctx *ctx) { return ctx ? (void *)ctx->counts : nullptr; }
+
+int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts) {
+    if (!ctx) return BDX_E_INVALID;
+    ctx->counts = d_counts ? (unsigned long long *)d_counts : (unsigned long long *)ctx->counts_own.p;
+    return BDX_OK;
+}
+
+const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str() : ""; }
+
+int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
+    if (!ctx || !out) return BDX_E_INVALID;
+    out->threads_per_block = ctx->plan.threads;
+    out->lds_bytes_per_block = (int32_t)ctx->plan.lds_bytes;
+    out->blocks = ctx->last_blocks;
+    out->reads_per_block = ctx->plan.threads;
+    out->filter_used = BDX_FILTER_OFF;
+    out->max_m = ctx->dev.max_m;
+    out->launches = ctx->launches;
+    return BDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// bdx_internal.h — structures shared between the C-ABI translation unit (bdx_abi.cpp) and the
+// gfx950 kernels (bdx_device.hip).  Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/biodemux_hip.h"
+
+// Integer domain of the device DP.  The reference computes in Int64 with
+// INF_INT = typemax(Int) ÷ 4 (classification.jl:7); every DP value is bounded by
+// (max_m + 2) * max|cost| + allowed_error, so with the limits enforced in bdx_create
+// (|cost| <= BDX_MAX_COST, max_m <= BDX_MAX_M, |allowed_error| < 2^27) int32 arithmetic
+// is exact and BDX_INF32 + value never overflows.
+#define BDX_INF32 0x3FFFFFFF
+#define BDX_MAX_COST 32767
+#define BDX_MAX_M 8192
+#define BDX_MAX_RATE 1.0e4
+
+struct BdxDevRange {
+    long long start_offset;
+    long long end_offset;
+    int start_from_end;
+    int end_from_end;
+};
+
+struct BdxDevPass {
+    BdxDevRange ref_search, bc_start, bc_end;
+    int trim_side;
+    int n_barcodes;
+    int explicit_window;
+    int cand_words;  // ceil(n_barcodes / 32)
+    long long win_first, win_last, win_max_start, win_min_end;
+    const uint8_t *bc_bytes;    // device
+    const uint32_t *bc_off;     // device, n_barcodes + 1
+    const int32_t *bc_len_no_N; // device
+};
+
+struct BdxDevCfg {
+    int algorithm;
+    int is_dual;
+    double max_error_rate;
+    double min_delta;
+    int match, mismatch, indel;
+    int has_nindel, nindel;
+    int need_traceback;
+    int max_m;
+    int any_traceback;  // origin array needed (trim or summary in any pass)
+    int counts_stride2; // max(1, B2 when dual)
+    int n_counts;
+    BdxDevPass pass[2];
+};
+
+struct BdxDevOut {
+    int32_t *bc1, *bc2, *keep_start, *keep_end;
+    int32_t *pass_start, *pass_end, *pass_raw, *pass_bc;
+    double *pass_score, *pass_delta;
+};
+
+// Launch geometry chosen on the host for the generic (unfiltered / verify) kernel.
+struct BdxGenericPlan {
+    int threads;         // 64 / 128 / 256
+    int dp_rows;         // max_m + 1
+    int stage_bytes;     // LDS bytes reserved for staged read bytes (0 = read from HBM/L2 directly)
+    int bc_stage_bytes;  // LDS bytes for the staged barcode bytes of both passes (0 = not staged)
+    int hist_entries;    // LDS histogram entries (0 = global atomics)
+    size_t lds_bytes;
+};
+
+// Implemented in bdx_device.hip.
+hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,
+                              const long long *d_off, long long n_reads, const BdxDevOut &out,
+                              unsigned long long *d_counts, const uint32_t *d_cand0,
+                              const uint32_t *d_cand1, hipStream_t stream);
+hipError_t bdx_generic_set_lds_limit(size_t bytes);

@@ -1,0 +1,213 @@
+/*
+ * biodemux_hip.h — C-ABI of libbiodemux_hip.so, the MI355X (gfx950) drop-in for the
+ * per-read classification hot path of I-Mihara/BioDemuX.jl v1.6.0.
+ *
+ * The reference has NO FFI seam (it is 100 % Julia).  The seam this library creates replaces
+ * the body of worker_task's per-read loop (src/core.jl:243-267): instead of one
+ * determine_filename(seq, config, ws) (src/classification.jl:871) per read, the Julia host
+ * packs a chunk into one byte vector + offsets and makes ONE ccall per chunk.  Each entry
+ * point below names the reference code it replaces.  INTEGRATION.md shows the Julia binding.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the ABI; every function returns 0 on success or
+ *     a negative BDX_E_* code, with a message retrievable by bdx_last_error().
+ *   - all sequence positions are 1-based inclusive, as in Julia.
+ *   - the caller owns every buffer it passes, for the duration of the call only (device
+ *     entry points: until bdx_sync() returns).  The library owns its tables, stream and
+ *     staging buffers.  Nothing returned needs freeing except the context.
+ *   - one context per OS thread / per GPU; a single context is not re-entrant
+ *     (the reference runs nthreads() independent workers, core.jl:454-466).
+ */
+#ifndef BIODEMUX_HIP_H
+#define BIODEMUX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDX_ABI_VERSION 1
+
+/* error codes */
+#define BDX_OK 0
+#define BDX_E_INVALID (-1)   /* bad argument / config outside the supported domain */
+#define BDX_E_DEVICE (-2)    /* HIP runtime error (no GPU, OOM, launch failure) */
+#define BDX_E_STATE (-3)     /* call sequence error */
+
+/* DemuxConfig.matching_algorithm (classification.jl:57): :semiglobal / :hamming / :exact */
+#define BDX_ALG_SEMIGLOBAL 0
+#define BDX_ALG_HAMMING 1
+#define BDX_ALG_EXACT 2
+
+/* bdx_pass_t.explicit_window (0 = normal operation) */
+#define BDX_WINDOW_FIND_BEST 1
+#define BDX_WINDOW_ALIGN_ONE 2
+
+/* bdx_config_t.filter: candidate pre-filter in front of the exact per-barcode evaluation.
+ * Every filter is lossless (it can only drop barcodes whose alignment would return Inf),
+ * so results are identical for every value; OFF forces the unfiltered path. */
+#define BDX_FILTER_AUTO 0
+#define BDX_FILTER_OFF 1
+#define BDX_FILTER_QGRAM 2     /* pigeonhole exact-piece seeds */
+#define BDX_FILTER_BITPAR 3    /* Myers bit-parallel lower bound (m <= 32) */
+
+/* DynamicRange, classification.jl:9-14 (already parsed by the host; resolve() of :96-100
+ * runs per read on the device). */
+typedef struct {
+    int64_t start_offset;
+    int64_t end_offset;
+    int32_t start_from_end;
+    int32_t end_from_end;
+} bdx_range_t;
+
+/* The per-pass slice of DemuxConfig selected in match_barcode_pass (classification.jl:778-792). */
+typedef struct {
+    bdx_range_t ref_search_range;
+    bdx_range_t barcode_start_range;
+    bdx_range_t barcode_end_range;
+    int32_t trim_side;            /* 0 = nothing, 3, 5 (core.jl:308-313 validation is repeated) */
+    int32_t n_barcodes;
+    const uint8_t *bc_bytes;      /* config.bc_seqs concatenated (already preprocessed, fileio.jl:44-67) */
+    const uint32_t *bc_off;       /* n_barcodes + 1 offsets into bc_bytes */
+    const int32_t *bc_len_no_N;   /* config.bc_lengths_no_N (fileio.jl:69) */
+    /* Unit-level override used to expose the reference's exported functions through the same
+     * kernel.  explicit_window == BDX_WINDOW_FIND_BEST: the four values below replace
+     * (first:last of final_search_range, max_start_pos, min_end_pos) of classification.jl
+     * :799-809 verbatim for every read and the :805 sanity check is skipped — the pass then
+     * equals one call of find_best_matching_bc (:722).  explicit_window ==
+     * BDX_WINDOW_ALIGN_ONE: additionally the reducer is bypassed and the pass outputs are the
+     * direct return of ONE alignment call on barcode 1 with max_error = max_error_rate
+     * (semiglobal_alignment :447 / semiglobal_alignment_N :463 / hamming_align :557 /
+     * exact_align :485). */
+    int32_t explicit_window;
+    int32_t _pad;
+    int64_t win_first, win_last, win_max_start_pos, win_min_end_pos;
+} bdx_pass_t;
+
+typedef struct {
+    uint32_t abi_version;         /* = BDX_ABI_VERSION */
+    uint32_t struct_size;         /* = sizeof(bdx_config_t) */
+    int32_t algorithm;            /* BDX_ALG_* */
+    int32_t is_dual;              /* config.is_dual */
+    double max_error_rate;        /* Float64, compared exactly as in classification.jl:658,696 */
+    double min_delta;             /* Float64; == 0.0 selects the no_delta reducer (:723) */
+    int32_t match, mismatch, indel;
+    int32_t has_nindel;           /* nindel !== nothing -> NScoring (:644-648) */
+    int32_t nindel;
+    int32_t need_traceback;       /* config.summary (stats !== nothing, :812) */
+    int32_t filter;               /* BDX_FILTER_* */
+    int32_t device;               /* HIP device ordinal */
+    bdx_pass_t pass[2];
+} bdx_config_t;
+
+/* Per-read outputs.  Any pointer may be NULL (that output is skipped).  For the host entry
+ * point these are host pointers, for the device entry point device pointers.
+ *   bc1        int32[n]  >0 = config.ids index (1-based, as Julia), 0 = "unknown",
+ *                        -1 = "ambiguous_classification"  (classification.jl:879-883, :890-894, :897-899)
+ *   bc2        int32[n]  config.ids2 index when dual and matched, else 0
+ *   keep_start, keep_end int32[n]  determine_filename's 2nd/3rd return (:907-937):
+ *                        (-1,-1) unknown/ambiguous, (1,0) empty keep range, else 1-based inclusive
+ * Per-pass outputs, pass 1 at [2i] and pass 2 at [2i+1]: the return tuple of
+ * find_best_matching_bc (classification.jl:722) for that pass —
+ *   pass_bc    int32[2n] min_score_bc (1-based; 0 = no barcode accepted, pass not run, or the
+ *                        range sanity check :805 failed)
+ *   pass_score double[2n] min_score (Float64 raw / normalisation; +Inf when pass_bc == 0)
+ *   pass_delta double[2n] delta (+Inf from the no_delta reducer :666; sub_min - min :711 otherwise)
+ *   pass_start, pass_end int32[2n]  best_start, best_end (-1 for ScoreOnly / none)
+ *   pass_raw   int32[2n] integer numerator of min_score (cost or mismatches), -1 if none
+ * match_barcode_pass's status follows as: pass_bc == 0 -> :unknown; pass_delta < min_delta ->
+ * :ambiguous (:822); else :match. */
+typedef struct {
+    int32_t *bc1;
+    int32_t *bc2;
+    int32_t *keep_start;
+    int32_t *keep_end;
+    int32_t *pass_start;
+    int32_t *pass_end;
+    int32_t *pass_raw;
+    double *pass_score;
+    int32_t *pass_bc;
+    double *pass_delta;
+} bdx_outputs_t;
+
+typedef struct bdx_ctx bdx_ctx;
+
+/* Library / ABI version (BDX_ABI_VERSION). */
+int32_t bdx_abi_version(void);
+
+/* Replaces: build_config's validation (core.jl:308-313) + per-worker workspace creation
+ * SemiGlobalWorkspace(max_m, need_origin) (core.jl:229-233).  Copies the config, uploads the
+ * barcode tables, creates a stream.  On failure *out is NULL and bdx_last_error(NULL) holds
+ * the message. */
+int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out);
+
+/* Releases everything bdx_create made. */
+void bdx_destroy(bdx_ctx *ctx);
+
+/* Message of the last failing call on ctx (or of the last failing bdx_create when ctx is
+ * NULL).  The Julia shim turns a non-zero return into error(msg), matching the reference's
+ * throw-from-worker behaviour (core.jl:593-597). */
+const char *bdx_last_error(const bdx_ctx *ctx);
+
+/* Replaces: worker_task's per-read loop (core.jl:243-267), i.e. n_reads calls of
+ * determine_filename / determine_filename_and_stats (classification.jl:871, :940).
+ * seq_bytes = the chunk's read sequences concatenated (code units, not upper-cased — the
+ * reference compares raw bytes, classification.jl:185,597); seq_off[i]..seq_off[i+1] bounds
+ * read i (n_reads+1 entries, seq_off[0] may be non-zero).  Blocks until the outputs are
+ * filled.  Also accumulates the DemuxStats scalar counters (see bdx_get_counts). */
+int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t *seq_off,
+                          int64_t n_reads, const bdx_outputs_t *out);
+
+/* Same, with every pointer (seq_bytes, seq_off, outputs) already resident in HBM on
+ * ctx's device.  Asynchronous on the context's stream; call bdx_sync() before reading.
+ * This is the entry the multi-GPU driver and bench.py use. */
+int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int64_t *d_seq_off,
+                            int64_t n_reads, const bdx_outputs_t *d_out);
+
+/* Waits for the context's stream. */
+int32_t bdx_sync(bdx_ctx *ctx);
+
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) for all work of this context.
+ * NULL restores the context's own stream. */
+int32_t bdx_set_stream(bdx_ctx *ctx, void *hip_stream);
+
+/* DemuxStats scalar part (classification.jl:736-744, updated at :942,:950,:953,:963,:966,
+ * :976-978): counts[0..3] = total, matched, unmatched, ambiguous reads; counts[4 + (bc1-1)*S +
+ * (bc2 ? bc2-1 : 0)] = sample_counts[(bc1,bc2)], S = max(1, n_barcodes of pass 2 when dual).
+ * bdx_counts_len returns 4 + B1*S. */
+int64_t bdx_counts_len(const bdx_ctx *ctx);
+
+/* Copies the accumulated counters to the host (synchronises the stream). */
+int32_t bdx_get_counts(bdx_ctx *ctx, int64_t *out, int64_t n);
+
+/* Zeroes the counters. */
+int32_t bdx_reset_counts(bdx_ctx *ctx);
+
+/* Device address of the int64 counter vector — the buffer a multi-GPU host all-reduces
+ * (sum) over RCCL, the analogue of merge_stats (reporting.jl:1-9).  bdx_set_counts_buffer
+ * lets the host supply its own device buffer (e.g. a torch tensor) of bdx_counts_len()
+ * int64 so the collective can run on it directly; NULL restores the internal one. */
+void *bdx_counts_device_ptr(bdx_ctx *ctx);
+int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts);
+
+/* Introspection for bench/tests: name of the kernel path a classify call will take
+ * ("generic", "qgram+verify", "bitpar+verify", ...), and numbers of the last launch. */
+const char *bdx_kernel_path(const bdx_ctx *ctx);
+
+typedef struct {
+    int32_t threads_per_block;
+    int32_t lds_bytes_per_block;
+    int64_t blocks;
+    int32_t reads_per_block;
+    int32_t filter_used;          /* BDX_FILTER_* actually in effect */
+    int32_t max_m;
+    int64_t launches;             /* kernel launches so far on this context */
+} bdx_launch_info_t;
+int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,817 @@
+/*
+ * bdx_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Line-faithful plain-C restatement of BioDemuX.jl v1.6.0 src/classification.jl.
+ * Every function cites the Julia lines it follows.  Loop structure, the fact/lact
+ * cut-off bookkeeping, tie-breaks and the Float64 decision logic are kept exactly
+ * as written there (Int == int64_t, Float64 == double; build WITHOUT -ffast-math).
+ *
+ * Parity pinning: see bdx_oracle.h.
+ */
+#include "bdx_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define INF_INT ORC_INF_INT
+
+static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+
+/* resolve(dr, len) -> max(1, s):min(len, e)            classification.jl:96-100
+ * Julia's UnitRange(start, stop) stores stop = start-1 when stop < start, and the
+ * callers use last(range) (classification.jl:800-801), so that is reproduced. */
+void orc_resolve(const orc_range_t *dr, int64_t len, int64_t *first, int64_t *last) {
+    int64_t s = dr->start_from_end ? len + dr->start_offset : dr->start_offset;
+    int64_t e = dr->end_from_end ? len + dr->end_offset : dr->end_offset;
+    int64_t a = imax(1, s);
+    int64_t b = imin(len, e);
+    if (b < a) b = a - 1;
+    *first = a;
+    *last = b;
+}
+
+/* ---- output policies, classification.jl:130-168 ---- */
+typedef struct {
+    int64_t score, start, end;
+} res_t;
+
+static inline res_t init_result(void) { /* :130-136 (ScoreOnly keeps only .score) */
+    res_t r = {INF_INT, -1, -1};
+    return r;
+}
+
+static inline res_t update_result_scoreonly(res_t cur, int64_t new_score) { /* :138-140 */
+    cur.score = imin(cur.score, new_score);
+    return cur;
+}
+
+static inline res_t update_result_traceback(int32_t trim_side, res_t cur, int64_t new_score,
+                                            int64_t j, int64_t start_pos) { /* :142-153 */
+    if (new_score < cur.score) {
+        res_t r = {new_score, start_pos, j};
+        return r;
+    } else if (new_score == cur.score) {
+        if (trim_side == 3 && start_pos > cur.start) {
+            res_t r = {new_score, start_pos, j};
+            return r;
+        }
+    }
+    return cur;
+}
+
+static inline orc_align_t finalize_result(int32_t output_mode, res_t result,
+                                          int64_t normalization) { /* :155-168 */
+    orc_align_t a;
+    if (output_mode == ORC_OUT_SCOREONLY) {
+        a.start = -1;
+        a.end = -1;
+    } else {
+        a.start = result.start;
+        a.end = result.end;
+    }
+    if (result.score >= INF_INT) {
+        a.score = INFINITY;
+        a.raw = INF_INT;
+    } else {
+        a.score = (double)result.score / (double)normalization;
+        a.raw = result.score;
+    }
+    return a;
+}
+
+/* max_indel_steps_for, classification.jl:170-176 (Julia div truncates toward zero, like C) */
+static inline int64_t max_indel_steps_for(int32_t has_nindel, int64_t indel, int64_t nindel,
+                                          int64_t allowed_error) {
+    if (!has_nindel) return allowed_error / indel;
+    return allowed_error / imin(indel, nindel);
+}
+
+/* step_scores_main, classification.jl:178-206.  DP is 1-based (DP[0] unused). */
+static inline void step_scores_main(int32_t has_nindel, int64_t match, int64_t mismatch,
+                                    int64_t indel, int64_t nindel, const uint8_t *q,
+                                    const uint8_t *r, int64_t i, int64_t j,
+                                    int64_t previous_score, const int64_t *DP, int64_t *ins,
+                                    int64_t *del, int64_t *sub) {
+    if (!has_nindel) {
+        *ins = DP[i] + indel;
+        *del = previous_score + indel;
+        *sub = DP[i - 1] + (q[i] == r[j] ? match : mismatch);
+    } else {
+        int is_N_q = q[i] == (uint8_t)'N';
+        int64_t cost = is_N_q ? nindel : indel;
+        *ins = DP[i] + cost;
+        *del = previous_score + cost;
+        int is_match = (q[i] == r[j]) || is_N_q;
+        *sub = DP[i - 1] + (is_match ? match : mismatch);
+    }
+}
+
+/* step_scores (boundary rows i == fact or i == m), classification.jl:208-236 */
+static inline void step_scores(int32_t has_nindel, int64_t match, int64_t mismatch,
+                               int64_t indel, int64_t nindel, const uint8_t *q,
+                               const uint8_t *r, int64_t i, int64_t j, int64_t previous_score,
+                               const int64_t *DP, int64_t m, int64_t *ins, int64_t *del,
+                               int64_t *sub) {
+    if (!has_nindel) {
+        *ins = (i == m ? INF_INT : DP[i] + indel);
+        *del = previous_score + indel;
+        *sub = (i == 1 ? 0 : DP[i - 1]) + (q[i] == r[j] ? match : mismatch);
+    } else {
+        int is_N_q = q[i] == (uint8_t)'N';
+        int64_t cost = is_N_q ? nindel : indel;
+        *ins = DP[i] + (i == m ? INF_INT : cost);
+        *del = previous_score + cost;
+        int is_match = (q[i] == r[j]) || is_N_q;
+        *sub = (i == 1 ? 0 : DP[i - 1]) + (is_match ? match : mismatch);
+    }
+}
+
+/* Origin selection shared by the three cell sites, classification.jl:310-321, :348-359,
+ * :384-395: start from deletion, replace by substitution if strictly less, then by
+ * insertion if strictly less. */
+static inline int64_t pick_origin(int64_t ins, int64_t del, int64_t sub, int64_t ins_o,
+                                  int64_t del_o, int64_t sub_o) {
+    int64_t best_score = del;
+    int64_t best_origin = del_o;
+    if (sub < best_score) {
+        best_score = sub;
+        best_origin = sub_o;
+    }
+    if (ins < best_score) {
+        best_score = ins;
+        best_origin = ins_o;
+    }
+    return best_origin;
+}
+
+static inline int64_t min3(int64_t a, int64_t b, int64_t c) { return imin(imin(a, b), c); }
+
+/* semiglobal_alignment_core, classification.jl:238-445.
+ * q and r are passed 0-based from the caller; shifted to 1-based here.
+ * DP/origin must hold at least m+1 entries (index 0 unused). */
+orc_align_t orc_semiglobal_core(int64_t *DP, int64_t *origin, const uint8_t *q0, int64_t m,
+                                const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                                int64_t mismatch, int64_t indel, int32_t has_nindel,
+                                int64_t nindel, int32_t output_mode, int32_t trim_side,
+                                int64_t range_first, int64_t range_last, int64_t max_start_pos,
+                                int64_t min_end_pos, int64_t normalization_length) {
+    const uint8_t *q = q0 - 1;
+    const uint8_t *r = r0 - 1;
+    const int is_traceback = output_mode == ORC_OUT_TRACEBACK; /* :275 */
+
+    if (m == 0 || n == 0) { /* :250-252 */
+        return finalize_result(output_mode, init_result(), normalization_length);
+    }
+
+    int64_t allowed_error = (int64_t)floor(max_error * (double)normalization_length); /* :254 */
+    res_t result = init_result();                                                    /* :255 */
+
+    int64_t max_indel_steps = max_indel_steps_for(has_nindel, indel, nindel, allowed_error); /* :257 */
+
+    int64_t min_valid_start = min_end_pos - (m + max_indel_steps) + 1; /* :259 */
+
+    if (min_valid_start > max_start_pos) { /* :261-263 */
+        return finalize_result(output_mode, result, normalization_length);
+    }
+
+    /* Shrink ref_search_range start, :266-268 (Julia re-normalises an empty range) */
+    if (min_valid_start > range_first) {
+        range_first = imax(range_first, min_valid_start);
+        if (range_last < range_first) range_last = range_first - 1;
+    }
+
+    int64_t band_offset = imax(m - n - max_indel_steps, -max_start_pos - max_indel_steps); /* :270 */
+
+    for (int64_t i = 1; i <= m; i++) { /* :278-283 */
+        DP[i] = indel * i;
+        if (is_traceback) origin[i] = 1 - i;
+    }
+
+    int64_t lact = imin(allowed_error + 1, m); /* :286 */
+    for (int64_t j = range_first; j <= range_last; j++) { /* :287 */
+        int64_t previous_score_origin = j;
+        int64_t fact, previous_score;
+        int64_t current_origin = 0;
+        if (j + band_offset >= 1) { /* :289-295 */
+            fact = j + band_offset;
+            previous_score = allowed_error;
+        } else {
+            fact = 1;
+            previous_score = 0;
+        }
+
+        if (fact > lact) { /* :297-299 */
+            return finalize_result(output_mode, result, normalization_length);
+        }
+
+        if (fact <= lact) { /* :301 */
+            int64_t ins, del, sub;
+            /* 1. first iteration (i = fact), :303 */
+            step_scores(has_nindel, match, mismatch, indel, nindel, q, r, fact, j, previous_score,
+                        DP, m, &ins, &del, &sub);
+            if (is_traceback) { /* :306-324 */
+                int64_t del_origin = previous_score_origin;
+                int64_t sub_origin = (fact == 1 ? j : origin[fact - 1]);
+                int64_t ins_origin = origin[fact];
+                current_origin = pick_origin(ins, del, sub, ins_origin, del_origin, sub_origin);
+            }
+            if (fact != 1) { /* :326-331 */
+                DP[fact - 1] = previous_score;
+                if (is_traceback) origin[fact - 1] = previous_score_origin;
+            }
+            previous_score = min3(ins, del, sub); /* :332 */
+            if (is_traceback) previous_score_origin = current_origin;
+
+            /* 2. main loop, :338-373 */
+            int64_t limit = (lact == m) ? m - 1 : lact;
+            for (int64_t i = fact + 1; i <= limit; i++) {
+                step_scores_main(has_nindel, match, mismatch, indel, nindel, q, r, i, j,
+                                 previous_score, DP, &ins, &del, &sub);
+                if (is_traceback) {
+                    int64_t del_origin = previous_score_origin;
+                    int64_t sub_origin = origin[i - 1];
+                    int64_t ins_origin = origin[i];
+                    current_origin = pick_origin(ins, del, sub, ins_origin, del_origin, sub_origin);
+                }
+                DP[i - 1] = previous_score;
+                if (is_traceback) origin[i - 1] = previous_score_origin;
+                previous_score = min3(ins, del, sub);
+                if (is_traceback) previous_score_origin = current_origin;
+            }
+
+            /* 3. last iteration (i = m) if needed, :376-409 */
+            if (lact == m && lact > fact) {
+                step_scores(has_nindel, match, mismatch, indel, nindel, q, r, m, j, previous_score,
+                            DP, m, &ins, &del, &sub);
+                if (is_traceback) {
+                    int64_t del_origin = previous_score_origin;
+                    int64_t ins_origin = origin[m];
+                    int64_t sub_origin = origin[m - 1];
+                    current_origin = pick_origin(ins, del, sub, ins_origin, del_origin, sub_origin);
+                }
+                DP[m - 1] = previous_score;
+                if (is_traceback) origin[m - 1] = previous_score_origin;
+                previous_score = min3(ins, del, sub);
+                if (is_traceback) previous_score_origin = current_origin;
+            }
+        }
+
+        DP[lact] = previous_score; /* :412-415 */
+        if (is_traceback) origin[lact] = previous_score_origin;
+
+        if (lact == m && previous_score <= allowed_error) { /* :417 */
+            lact -= 1;
+            if (j >= min_end_pos) {
+                if (previous_score == 0) { /* :420-430 */
+                    int do_early_exit = !is_traceback || (is_traceback && trim_side == 5);
+                    if (do_early_exit) {
+                        res_t z = {0, -1, -1};
+                        if (is_traceback) {
+                            z.start = previous_score_origin;
+                            z.end = j;
+                        }
+                        return finalize_result(output_mode, z, normalization_length);
+                    }
+                }
+                if (is_traceback) { /* :432-436 */
+                    result = update_result_traceback(trim_side, result, previous_score, j,
+                                                     previous_score_origin);
+                } else {
+                    result = update_result_scoreonly(result, previous_score);
+                }
+            }
+        }
+        while (lact > 0 && DP[lact] > allowed_error) lact -= 1; /* :439-441 */
+        lact += 1;                                              /* :442 */
+    }
+    return finalize_result(output_mode, result, normalization_length); /* :444 */
+}
+
+/* semiglobal_alignment (:447-461) and semiglobal_alignment_N (:463-477) */
+orc_align_t orc_semiglobal_alignment(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n,
+                                     double max_error, int64_t match, int64_t mismatch,
+                                     int64_t indel, int32_t has_nindel, int64_t nindel,
+                                     int64_t range_first, int64_t range_last,
+                                     int64_t max_start_pos, int64_t min_end_pos, int64_t non_N_m,
+                                     int32_t trim_side, int32_t need_traceback) {
+    int64_t *DP = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 2));
+    int64_t *origin = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 2));
+    int32_t output_mode = (trim_side == 0 && !need_traceback) ? ORC_OUT_SCOREONLY : ORC_OUT_TRACEBACK;
+    int64_t norm = has_nindel ? non_N_m : m; /* :460 vs :476 */
+    orc_align_t a = orc_semiglobal_core(DP, origin, q, m, r, n, max_error, match, mismatch, indel,
+                                        has_nindel, nindel, output_mode, trim_side, range_first,
+                                        range_last, max_start_pos, min_end_pos, norm);
+    free(DP);
+    free(origin);
+    return a;
+}
+
+/* Base.findnext(query::String, ref::String, start): leftmost occurrence whose first code
+ * unit index is >= start; 0 when none.  1-based.  (m >= 1) */
+static int64_t find_next(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n, int64_t start) {
+    if (start < 1) start = 1;
+    for (int64_t s = start; s + m - 1 <= n; s++) {
+        if (memcmp(r + (s - 1), q, (size_t)m) == 0) return s;
+    }
+    return 0;
+}
+
+/* Base.findprev(query::String, ref::String, k): rightmost occurrence that ENDS at or before
+ * code unit k (this is what the reference relies on, classification.jl:498-505); 0 when none. */
+static int64_t find_prev(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n, int64_t k) {
+    int64_t s = imin(k - m + 1, n - m + 1);
+    for (; s >= 1; s--) {
+        if (memcmp(r + (s - 1), q, (size_t)m) == 0) return s;
+    }
+    return 0;
+}
+
+static inline orc_align_t align_none(void) {
+    orc_align_t a = {INFINITY, INF_INT, -1, -1};
+    return a;
+}
+
+/* exact_align, classification.jl:485-548 */
+orc_align_t orc_exact_align(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n,
+                            int64_t range_first, int64_t range_last, int64_t max_start_pos,
+                            int64_t min_end_pos, int32_t trim_side) {
+    int64_t start_range_first = imax(range_first, 1);                                /* :490 */
+    int64_t start_range_last = imin(imin(range_last, max_start_pos), n - m + 1);     /* :491 */
+
+    if (start_range_last < start_range_first) return align_none(); /* :493-495 */
+
+    if (trim_side == 3) { /* :499-515 */
+        int64_t s = find_prev(q, m, r, n, start_range_last + m - 1);
+        if (s != 0) {
+            if (s >= start_range_first) {
+                if ((s + m - 1) >= min_end_pos) {
+                    orc_align_t a = {0.0, 0, s, s + m - 1};
+                    return a;
+                }
+            }
+        }
+        return align_none();
+    } else { /* :517-547 */
+        int64_t s = find_next(q, m, r, n, start_range_first);
+        if (s != 0) {
+            if (s <= start_range_last) {
+                if ((s + m - 1) >= min_end_pos) {
+                    orc_align_t a = {0.0, 0, s, s + m - 1};
+                    return a;
+                } else {
+                    int64_t next_search = s + 1;
+                    while (next_search <= start_range_last) {
+                        s = find_next(q, m, r, n, next_search);
+                        if (s == 0) break;
+                        if (s > start_range_last) break;
+                        if ((s + m - 1) >= min_end_pos) {
+                            orc_align_t a = {0.0, 0, s, s + m - 1};
+                            return a;
+                        }
+                        next_search = s + 1;
+                    }
+                }
+            }
+        }
+        return align_none();
+    }
+}
+
+/* hamming_align, classification.jl:557-625 */
+orc_align_t orc_hamming_align(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n,
+                              double max_error_rate, int64_t range_first, int64_t range_last,
+                              int64_t max_start_pos, int64_t min_end_pos, int32_t trim_side) {
+    const uint8_t *q_bytes = q0 - 1;
+    const uint8_t *r_bytes = r0 - 1;
+    double best_score = INFINITY; /* :562-564 */
+    int64_t best_raw = INF_INT;
+    int64_t best_start = -1;
+    int64_t best_end = -1;
+
+    int64_t allowed_errors = (int64_t)floor(max_error_rate * (double)m); /* :567 */
+
+    int64_t start_range_first = imax(range_first, 1);                            /* :570 */
+    int64_t start_range_last = imin(imin(range_last, max_start_pos), n - m + 1); /* :571 */
+
+    if (start_range_last < start_range_first) return align_none(); /* :573-576 */
+
+    for (int64_t j = start_range_first; j <= start_range_last; j++) { /* :581 */
+        int64_t end_pos = j + m - 1;
+        if (end_pos < min_end_pos) continue; /* :584-586 */
+
+        int64_t current_mismatches = 0;
+        int match_failed = 0;
+
+        for (int64_t k = 0; k <= m - 1; k++) { /* :592-604 */
+            uint8_t q_char = q_bytes[k + 1];
+            uint8_t r_char = r_bytes[j + k];
+            if (q_char != r_char && q_char != 0x4E) {
+                current_mismatches += 1;
+                if (current_mismatches > allowed_errors) {
+                    match_failed = 1;
+                    break;
+                }
+            }
+        }
+
+        if (!match_failed) { /* :606-621 */
+            double score = (double)current_mismatches / (double)m;
+            if (score < best_score) {
+                best_score = score;
+                best_raw = current_mismatches;
+                best_start = j;
+                best_end = end_pos;
+            } else if (score == best_score) {
+                if (trim_side == 3) {
+                    if (j > best_start) {
+                        best_start = j;
+                        best_end = end_pos;
+                    }
+                }
+            }
+        }
+    }
+    orc_align_t a = {best_score, best_raw, best_start, best_end};
+    return a;
+}
+
+/* One barcode's alignment as dispatched inside both reducers, classification.jl:639-656 /
+ * :677-694.  Returns (score, s, e) with s = e = -1 for the ScoreOnly semi-global case. */
+static orc_align_t align_one(const orc_config_t *cfg, const orc_pass_t *p, int64_t i /*1-based*/,
+                             const uint8_t *seq, int64_t n, int64_t *DP, int64_t *origin,
+                             double max_error_rate, int64_t range_first, int64_t range_last,
+                             int64_t max_start_pos, int64_t min_end_pos, int32_t trim_side,
+                             int32_t need_traceback) {
+    const uint8_t *bc = p->bc_bytes + p->bc_off[i - 1];
+    int64_t m = p->bc_off[i] - p->bc_off[i - 1];
+    if (cfg->algorithm == ORC_ALG_HAMMING) {
+        return orc_hamming_align(bc, m, seq, n, max_error_rate, range_first, range_last,
+                                 max_start_pos, min_end_pos, trim_side);
+    } else if (cfg->algorithm == ORC_ALG_EXACT) {
+        return orc_exact_align(bc, m, seq, n, range_first, range_last, max_start_pos, min_end_pos,
+                               trim_side);
+    } else {
+        int32_t output_mode =
+            (trim_side == 0 && !need_traceback) ? ORC_OUT_SCOREONLY : ORC_OUT_TRACEBACK; /* :454 */
+        int64_t norm = cfg->has_nindel ? p->bc_len_no_N[i - 1] : m;
+        orc_align_t a = orc_semiglobal_core(DP, origin, bc, m, seq, n, max_error_rate, cfg->match,
+                                            cfg->mismatch, cfg->indel, cfg->has_nindel, cfg->nindel,
+                                            output_mode, trim_side, range_first, range_last,
+                                            max_start_pos, min_end_pos, norm);
+        if (output_mode == ORC_OUT_SCOREONLY) { /* :651-653 / :688-690 */
+            a.start = -1;
+            a.end = -1;
+        }
+        return a;
+    }
+}
+
+/* find_best_matching_bc_no_delta, classification.jl:632-667 */
+static orc_best_t find_best_no_delta(const orc_config_t *cfg, const orc_pass_t *p,
+                                     const uint8_t *seq, int64_t n, int64_t *DP, int64_t *origin,
+                                     double max_error_rate, int64_t range_first,
+                                     int64_t range_last, int64_t max_start_pos,
+                                     int64_t min_end_pos, int32_t trim_side,
+                                     int32_t need_traceback) {
+    double min_score = INFINITY;
+    int64_t min_score_bc = 0;
+    int64_t best_start = -1;
+    int64_t best_end = -1;
+
+    for (int64_t i = 1; i <= p->n_barcodes; i++) {
+        orc_align_t a = align_one(cfg, p, i, seq, n, DP, origin, max_error_rate, range_first,
+                                  range_last, max_start_pos, min_end_pos, trim_side, need_traceback);
+        double score = a.score;
+        if (score <= max_error_rate && score < min_score) { /* :658-664 */
+            min_score = score;
+            min_score_bc = i;
+            max_error_rate = fmin(max_error_rate, min_score);
+            best_start = a.start;
+            best_end = a.end;
+        }
+    }
+    orc_best_t b = {min_score_bc, min_score, INFINITY, best_start, best_end}; /* :666 */
+    return b;
+}
+
+/* find_best_matching_bc_with_delta, classification.jl:669-713 */
+static orc_best_t find_best_with_delta(const orc_config_t *cfg, const orc_pass_t *p,
+                                       const uint8_t *seq, int64_t n, int64_t *DP,
+                                       int64_t *origin, double max_error_rate,
+                                       int64_t range_first, int64_t range_last,
+                                       int64_t max_start_pos, int64_t min_end_pos,
+                                       int32_t trim_side, int32_t need_traceback) {
+    double min_score = INFINITY;
+    double sub_min_score = INFINITY;
+    int64_t min_score_bc = 0;
+    int64_t best_start = -1;
+    int64_t best_end = -1;
+
+    for (int64_t i = 1; i <= p->n_barcodes; i++) {
+        orc_align_t a = align_one(cfg, p, i, seq, n, DP, origin, max_error_rate, range_first,
+                                  range_last, max_start_pos, min_end_pos, trim_side, need_traceback);
+        double score = a.score;
+        if (score <= max_error_rate) { /* :696-709 */
+            if (score < min_score) {
+                sub_min_score = min_score;
+                min_score = score;
+                min_score_bc = i;
+                max_error_rate = fmin(max_error_rate, sub_min_score);
+                best_start = a.start;
+                best_end = a.end;
+            } else if (score < sub_min_score) {
+                sub_min_score = score;
+                max_error_rate = fmin(max_error_rate, sub_min_score);
+            }
+        }
+    }
+    double delta = sub_min_score - min_score; /* :711 */
+    orc_best_t b = {min_score_bc, min_score, delta, best_start, best_end};
+    return b;
+}
+
+/* find_best_matching_bc, classification.jl:722-728 */
+orc_best_t orc_find_best_matching_bc(const orc_config_t *cfg, int pass, const uint8_t *seq,
+                                     int64_t n, int64_t *DP, int64_t *origin, int64_t range_first,
+                                     int64_t range_last, int64_t max_start_pos,
+                                     int64_t min_end_pos, int32_t trim_side,
+                                     int32_t need_traceback) {
+    const orc_pass_t *p = &cfg->pass[pass];
+    if (cfg->min_delta == 0.0) {
+        return find_best_no_delta(cfg, p, seq, n, DP, origin, cfg->max_error_rate, range_first,
+                                  range_last, max_start_pos, min_end_pos, trim_side, need_traceback);
+    } else {
+        return find_best_with_delta(cfg, p, seq, n, DP, origin, cfg->max_error_rate, range_first,
+                                    range_last, max_start_pos, min_end_pos, trim_side,
+                                    need_traceback);
+    }
+}
+
+/* match_barcode_pass, classification.jl:776-868 (stats histograms :827-865 are out of scope).
+ * status: 1 match, 0 unknown, -1 ambiguous. */
+static void match_barcode_pass(const orc_config_t *cfg, int is_pass2, const uint8_t *seq,
+                               int64_t n, int64_t *DP, int64_t *origin, int32_t *status,
+                               int64_t *bc_idx, int64_t *s_out, int64_t *e_out,
+                               double *score_out, orc_best_t *fb) {
+    const orc_pass_t *p = &cfg->pass[is_pass2 ? 1 : 0];
+    int32_t trim_side = p->trim_side;
+
+    int64_t rs_f, rs_l, bs_f, bs_l, be_f, be_l; /* :795-797 */
+    orc_resolve(&p->ref_search_range, n, &rs_f, &rs_l);
+    orc_resolve(&p->barcode_start_range, n, &bs_f, &bs_l);
+    orc_resolve(&p->barcode_end_range, n, &be_f, &be_l);
+
+    int64_t start_j = imax(imax(rs_f, bs_f), 1); /* :799 */
+    int64_t end_j = imin(imin(rs_l, be_l), n);   /* :800 */
+    int64_t max_start_pos = bs_l;                /* :801 */
+    int64_t min_end_pos = be_f;                  /* :802 */
+
+    *bc_idx = 0;
+    *s_out = -1;
+    *e_out = -1;
+    *score_out = INFINITY;
+    fb->bc = 0;
+    fb->score = INFINITY;
+    fb->delta = INFINITY;
+    fb->start = -1;
+    fb->end = -1;
+
+    if (start_j > end_j || start_j > max_start_pos || end_j < min_end_pos) { /* :805-807 */
+        *status = 0;
+        return;
+    }
+
+    int32_t need_tb = (trim_side != 0) || cfg->summary; /* :812 */
+
+    orc_best_t b = orc_find_best_matching_bc(cfg, is_pass2 ? 1 : 0, seq, n, DP, origin, start_j,
+                                             end_j, max_start_pos, min_end_pos, trim_side, need_tb);
+    *fb = b;
+
+    if (b.bc == 0) { /* :820-824 */
+        *status = 0;
+        return;
+    } else if (b.delta < cfg->min_delta) {
+        *status = -1;
+        return;
+    }
+    *status = 1; /* :867 */
+    *bc_idx = b.bc;
+    *s_out = b.start;
+    *e_out = b.end;
+    *score_out = b.score;
+}
+
+/* determine_filename, classification.jl:871-938 (the filename string itself is formed by the
+ * host from bc1/bc2; here the verdict is returned as indices). */
+void orc_determine_filename(const orc_config_t *cfg, const uint8_t *seq, int64_t n, int64_t *DP,
+                            int64_t *origin, orc_verdict_t *out) {
+    int32_t status1, status2 = 2;
+    int64_t bc1_idx, start1, end1;
+    int64_t idx2 = 0, start2 = -1, end2 = -1;
+    double score1, score2 = INFINITY;
+
+    out->bc1 = 0;
+    out->bc2 = 0;
+    out->keep_start = -1;
+    out->keep_end = -1;
+    out->pass_status[1] = 2;
+    out->pass_bc[1] = 0;
+    out->pass_start[1] = -1;
+    out->pass_end[1] = -1;
+    out->pass_score[1] = INFINITY;
+    out->pass_delta[1] = INFINITY;
+    orc_best_t fb;
+
+    match_barcode_pass(cfg, 0, seq, n, DP, origin, &status1, &bc1_idx, &start1, &end1, &score1, &fb); /* :875 */
+    out->pass_status[0] = status1;
+    out->pass_bc[0] = (int32_t)fb.bc;
+    out->pass_start[0] = (int32_t)fb.start;
+    out->pass_end[0] = (int32_t)fb.end;
+    out->pass_score[0] = fb.score;
+    out->pass_delta[0] = fb.delta;
+
+    if (status1 == 0) { /* :879-883 */
+        out->bc1 = 0;
+        return;
+    } else if (status1 == -1) {
+        out->bc1 = -1;
+        return;
+    }
+
+    int64_t bc2_idx = 0;
+    if (cfg->is_dual) { /* :887-900 */
+        match_barcode_pass(cfg, 1, seq, n, DP, origin, &status2, &idx2, &start2, &end2, &score2, &fb);
+        out->pass_status[1] = status2;
+        out->pass_bc[1] = (int32_t)fb.bc;
+        out->pass_start[1] = (int32_t)fb.start;
+        out->pass_end[1] = (int32_t)fb.end;
+        out->pass_score[1] = fb.score;
+        out->pass_delta[1] = fb.delta;
+        if (status2 == 0) {
+            out->bc1 = 0;
+            return;
+        } else if (status2 == -1) {
+            out->bc1 = -1;
+            return;
+        }
+        bc2_idx = idx2;
+    }
+    out->bc1 = (int32_t)bc1_idx;
+    out->bc2 = (int32_t)bc2_idx;
+
+    int64_t keep_start = 1; /* :907-908 */
+    int64_t keep_end = n;
+
+    int32_t ts1 = cfg->pass[0].trim_side;
+    int32_t ts2 = cfg->pass[1].trim_side;
+    if (ts1 != 0) { /* :910-919 */
+        if (ts1 == 3) {
+            keep_end = imax(1, start1) - 1;
+        } else if (ts1 == 5) {
+            keep_start = end1 + 1;
+        }
+    }
+    if (cfg->is_dual && ts2 != 0) { /* :921-929 */
+        if (ts2 == 3) {
+            keep_end = imin(keep_end, imax(1, start2) - 1);
+        } else if (ts2 == 5) {
+            keep_start = imax(keep_start, end2 + 1);
+        }
+    }
+    if (keep_start > keep_end) { /* :932-935 */
+        out->keep_start = 1;
+        out->keep_end = 0;
+        return;
+    }
+    out->keep_start = (int32_t)keep_start;
+    out->keep_end = (int32_t)keep_end;
+}
+
+/* ---- batch driver: worker_task, core.jl:226-279 ---- */
+typedef struct {
+    const orc_config_t *cfg;
+    const uint8_t *seq_bytes;
+    const int64_t *seq_off;
+    int64_t lo, hi;
+    int32_t *bc1, *bc2, *keep_start, *keep_end, *pass_start, *pass_end, *pass_bc;
+    double *pass_score, *pass_delta;
+    int64_t *counts; /* thread-local, merged by the caller (merge_stats, reporting.jl:1-9) */
+    int64_t n_counts;
+    int64_t max_m;
+} job_t;
+
+static void *worker(void *arg) {
+    job_t *jb = (job_t *)arg;
+    const orc_config_t *cfg = jb->cfg;
+    /* SemiGlobalWorkspace(max_m, ...), core.jl:229-233 */
+    int64_t *DP = (int64_t *)malloc(sizeof(int64_t) * (size_t)(jb->max_m + 2));
+    int64_t *origin = (int64_t *)malloc(sizeof(int64_t) * (size_t)(jb->max_m + 2));
+    int64_t B2 = cfg->is_dual ? cfg->pass[1].n_barcodes : 0;
+    int64_t stride2 = B2 > 1 ? B2 : 1;
+    for (int64_t i = jb->lo; i < jb->hi; i++) { /* core.jl:243-267 */
+        const uint8_t *seq = jb->seq_bytes + jb->seq_off[i];
+        int64_t n = jb->seq_off[i + 1] - jb->seq_off[i];
+        orc_verdict_t v;
+        orc_determine_filename(cfg, seq, n, DP, origin, &v);
+        jb->bc1[i] = v.bc1;
+        if (jb->bc2) jb->bc2[i] = v.bc2;
+        if (jb->keep_start) jb->keep_start[i] = v.keep_start;
+        if (jb->keep_end) jb->keep_end[i] = v.keep_end;
+        if (jb->pass_start) {
+            jb->pass_start[2 * i] = v.pass_start[0];
+            jb->pass_start[2 * i + 1] = v.pass_start[1];
+        }
+        if (jb->pass_end) {
+            jb->pass_end[2 * i] = v.pass_end[0];
+            jb->pass_end[2 * i + 1] = v.pass_end[1];
+        }
+        if (jb->pass_score) {
+            jb->pass_score[2 * i] = v.pass_score[0];
+            jb->pass_score[2 * i + 1] = v.pass_score[1];
+        }
+        if (jb->pass_bc) {
+            jb->pass_bc[2 * i] = v.pass_bc[0];
+            jb->pass_bc[2 * i + 1] = v.pass_bc[1];
+        }
+        if (jb->pass_delta) {
+            jb->pass_delta[2 * i] = v.pass_delta[0];
+            jb->pass_delta[2 * i + 1] = v.pass_delta[1];
+        }
+        if (jb->counts) { /* classification.jl:942, :950, :953, :963, :966, :976-978 */
+            jb->counts[0] += 1;
+            if (v.bc1 > 0) {
+                jb->counts[1] += 1;
+                int64_t k = 4 + (int64_t)(v.bc1 - 1) * stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
+                jb->counts[k] += 1;
+            } else if (v.bc1 == 0) {
+                jb->counts[2] += 1;
+            } else {
+                jb->counts[3] += 1;
+            }
+        }
+    }
+    free(DP);
+    free(origin);
+    return NULL;
+}
+
+int orc_classify_batch(const orc_config_t *cfg, const uint8_t *seq_bytes, const int64_t *seq_off,
+                       int64_t n_reads, int32_t *bc1, int32_t *bc2, int32_t *keep_start,
+                       int32_t *keep_end, int32_t *pass_start, int32_t *pass_end,
+                       double *pass_score, int32_t *pass_bc, double *pass_delta, int64_t *counts,
+                       int32_t nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    int64_t max_m = 0; /* core.jl:229-232 */
+    for (int p = 0; p < (cfg->is_dual ? 2 : 1); p++) {
+        for (int64_t i = 0; i < cfg->pass[p].n_barcodes; i++) {
+            int64_t m = cfg->pass[p].bc_off[i + 1] - cfg->pass[p].bc_off[i];
+            if (m > max_m) max_m = m;
+        }
+    }
+    int64_t B1 = cfg->pass[0].n_barcodes;
+    int64_t B2 = cfg->is_dual ? cfg->pass[1].n_barcodes : 0;
+    int64_t n_counts = 4 + B1 * (B2 > 1 ? B2 : 1);
+
+    job_t *jobs = (job_t *)calloc((size_t)nthreads, sizeof(job_t));
+    pthread_t *tids = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    int64_t per = (n_reads + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        job_t *jb = &jobs[t];
+        jb->cfg = cfg;
+        jb->seq_bytes = seq_bytes;
+        jb->seq_off = seq_off;
+        jb->lo = imin(n_reads, per * t);
+        jb->hi = imin(n_reads, per * (t + 1));
+        jb->bc1 = bc1;
+        jb->bc2 = bc2;
+        jb->keep_start = keep_start;
+        jb->keep_end = keep_end;
+        jb->pass_start = pass_start;
+        jb->pass_end = pass_end;
+        jb->pass_score = pass_score;
+        jb->pass_bc = pass_bc;
+        jb->pass_delta = pass_delta;
+        jb->max_m = max_m;
+        jb->n_counts = n_counts;
+        jb->counts = counts ? (int64_t *)calloc((size_t)n_counts, sizeof(int64_t)) : NULL;
+    }
+    if (nthreads == 1) {
+        worker(&jobs[0]);
+    } else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&tids[t], NULL, worker, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(tids[t], NULL);
+    }
+    if (counts) { /* merge_stats, reporting.jl:1-9 (adds into the caller's vector) */
+        for (int t = 0; t < nthreads; t++) {
+            for (int64_t k = 0; k < n_counts; k++) counts[k] += jobs[t].counts[k];
+            free(jobs[t].counts);
+        }
+    }
+    free(jobs);
+    free(tids);
+    return 0;
+}
