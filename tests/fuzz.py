@@ -1,0 +1,83 @@
+"""Randomised differential cases shared by the CPU and GPU test files: seeded configs over the
+whole option space of the hot path (algorithm, costs, N-scoring, rates, min_delta, the three
+range kinds, trimming, dual mode, summary/traceback, ragged reads incl. empty ones)."""
+from __future__ import annotations
+
+import numpy as np
+
+import helpers as H
+from biodemux_jl_amd import synth
+
+_RANGES = ["1:end", "1:end", "1:end", "1:30", "5:60", "end-40:end", "end-20:end-3", "1:8", "10:9", "3:end-5"]
+_START_RANGES = ["1:end", "1:end", "1:end", "1:10", "1:1", "5:40", "end-30:end"]
+_END_RANGES = ["1:end", "1:end", "1:end", "20:end", "end-10:end", "1:40", "30:end"]
+
+
+def _rand_barcodes(rng, n, lo, hi, with_n):
+    out = []
+    for _ in range(n):
+        m = int(rng.integers(lo, hi + 1))
+        s = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=m))
+        if with_n and rng.random() < 0.5:
+            s = list(s)
+            for _k in range(int(rng.integers(1, 3))):
+                s[int(rng.integers(0, m))] = "N"
+            s = "".join(s)
+        out.append(s)
+    return out
+
+
+def random_case(seed: int, n_reads: int = 600):
+    """Returns (DemuxConfig, seq_bytes, seq_off)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    alg = ["semiglobal", "semiglobal", "semiglobal", "hamming", "exact"][int(rng.integers(0, 5))]
+    with_n = rng.random() < 0.3
+    B = int(rng.integers(1, 40))
+    lo = int(rng.integers(4, 20))
+    hi = lo if rng.random() < 0.6 else lo + int(rng.integers(1, 16))
+    bcs = _rand_barcodes(rng, B, lo, hi, with_n)
+    dual = rng.random() < 0.3
+    bcs2 = _rand_barcodes(rng, int(rng.integers(1, 12)), lo, hi, with_n) if dual else []
+    kw = dict(
+        bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
+        max_error_rate=float([0.0, 0.05, 0.1, 0.2, 0.25, 0.3, 0.5][int(rng.integers(0, 7))]),
+        min_delta=float([0.0, 0.0, 0.05, 0.15, 0.3][int(rng.integers(0, 5))]),
+        match=0, mismatch=int(rng.integers(1, 4)), indel=int(rng.integers(1, 4)),
+        nindel=(int(rng.integers(1, 3)) if (with_n or rng.random() < 0.15) else None),
+        ref_search_range=H.bdx.parse_dynamic_range(_RANGES[int(rng.integers(0, len(_RANGES)))]),
+        barcode_start_range=H.bdx.parse_dynamic_range(_START_RANGES[int(rng.integers(0, len(_START_RANGES)))]),
+        barcode_end_range=H.bdx.parse_dynamic_range(_END_RANGES[int(rng.integers(0, len(_END_RANGES)))]),
+        trim_side=[None, None, 3, 5][int(rng.integers(0, 4))],
+        summary=bool(rng.random() < 0.2),
+        matching_algorithm=alg,
+    )
+    if dual:
+        kw.update(
+            is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[sum(c != "N" for c in b) for b in bcs2],
+            ids2=[f"b{i}" for i in range(len(bcs2))],
+            ref_search_range2=H.bdx.parse_dynamic_range(_RANGES[int(rng.integers(0, len(_RANGES)))]),
+            barcode_start_range2=H.bdx.parse_dynamic_range(_START_RANGES[int(rng.integers(0, len(_START_RANGES)))]),
+            barcode_end_range2=H.bdx.parse_dynamic_range(_END_RANGES[int(rng.integers(0, len(_END_RANGES)))]),
+            trim_side2=[None, 3, 5][int(rng.integers(0, 3))])
+    cfg = H.bdx.DemuxConfig(**kw)
+    max_len = int(rng.integers(max(hi, 8), 160))
+    plain = [b.replace("N", "A") for b in bcs]
+    second = ([b.replace("N", "C") for b in bcs2], max_len // 2, None) if dual else None
+    seq, off, _ = synth.make_ragged_reads(plain, n_reads, 0, max_len, seed=seed, plant_frac=0.8, sub=0.04,
+                                          ins=0.015, dele=0.015, n_rate=0.005,
+                                          plant_hi=(max_len // 3 if dual else None), second=second)
+    return cfg, seq, off
+
+
+def assert_same(got: dict, exp: dict, what: str = ""):
+    for k in ("bc1", "bc2", "keep_start", "keep_end", "pass_bc", "pass_start", "pass_end"):
+        if k in got and k in exp:
+            bad = np.flatnonzero((got[k] != exp[k]).reshape(len(got[k]), -1).any(axis=1))
+            assert bad.size == 0, f"{what}: {k} differs at reads {bad[:8].tolist()} (got {got[k][bad[:4]].tolist()} exp {exp[k][bad[:4]].tolist()})"
+    for k in ("pass_score", "pass_delta"):
+        if k in got and k in exp:
+            # bit-exact doubles; NaN == NaN (Inf - Inf in the with_delta reducer)
+            a, b = got[k].view(np.uint64), exp[k].view(np.uint64)
+            nan = np.isnan(got[k]) & np.isnan(exp[k])
+            bad = np.flatnonzero(((a != b) & ~nan).any(axis=1))
+            assert bad.size == 0, f"{what}: {k} differs at reads {bad[:8].tolist()} (got {got[k][bad[:4]].tolist()} exp {exp[k][bad[:4]].tolist()})"

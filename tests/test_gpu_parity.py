@@ -1,0 +1,218 @@
+"""GPU parity tests proper: everything goes through the C-ABI of libbiodemux_hip.so and is
+compared bit-for-bit with the oracle (integer outputs exactly; Float64 scores/deltas by bit
+pattern).  Run with `pytest -m gpu` on an MI355X."""
+import functools
+import os
+
+import numpy as np
+import pytest
+
+import fuzz
+import helpers as H
+from biodemux_jl_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KAT = H.kat_vectors()
+run = H.bdx.execute_demultiplexing  # product default: HIP classifier, no injection
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert os.path.exists(H.bdx.LIB_PATH), "HIP extension missing: run __graft_entry__.build()"
+
+
+# ---- the reference's unit tests, through the kernel ----
+@pytest.mark.parametrize("vec", KAT, ids=[f"{v['fn']}@{v['src']}" for v in KAT])
+def test_kat_hip(vec):
+    got, expect = H.run_kat(vec, "hip")
+    assert got == expect, vec["src"]
+
+
+# ---- the reference's integration tests + golden files, through the kernel ----
+def test_demo1_R1_golden(tmp_path):
+    assert H.scenario_demo1_R1(run, str(tmp_path)) == 24
+
+
+def test_demo1_R2_golden(tmp_path):
+    assert H.scenario_demo1_R2(run, str(tmp_path)) == 24
+
+
+def test_demo2_golden(tmp_path):
+    assert H.scenario_demo2(run, str(tmp_path)) == 76
+
+
+@pytest.mark.parametrize("algorithm", ["exact", "hamming"])
+def test_demo1_R1_other_modes(tmp_path, algorithm):
+    assert H.scenario_demo1_modes(run, str(tmp_path), algorithm) == 24
+
+
+@pytest.mark.parametrize("scenario", H.SCENARIOS_SMALL, ids=[s.__name__ for s in H.SCENARIOS_SMALL])
+def test_reference_integration_scenarios(tmp_path, scenario):
+    scenario(run, str(tmp_path))
+
+
+# ---- randomised differential tests vs the oracle ----
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_vs_oracle(seed):
+    cfg, seq, off = fuzz.random_case(seed, n_reads=700)
+    oc = H.orc.OracleClassifier(cfg, nthreads=8)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"seed {seed} filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+
+
+def _c2_config(bcs, **kw):
+    base = dict(bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"bc{i + 1}" for i in range(len(bcs))],
+                max_error_rate=0.1)
+    base.update(kw)
+    return H.bdx.DemuxConfig(**base)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                               # C2: ScoreOnly, no_delta, allowed_error 2
+    dict(max_error_rate=0.2),                             # reference default rate: allowed_error 4
+    dict(max_error_rate=0.2, min_delta=0.1),              # with_delta reducer
+    dict(max_error_rate=0.2, trim_side=3),                # traceback, rightmost ties
+    dict(max_error_rate=0.2, trim_side=5, summary=True),
+    dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15),  # demo2's costs
+    dict(matching_algorithm="hamming", max_error_rate=0.15),
+    dict(matching_algorithm="exact"),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "C2")
+def test_c2_shape_vs_oracle(kw):
+    """BASELINE config 2's shape (150 bp x 96 barcodes of 24) at a size the oracle finishes in seconds."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 60000, 150)
+    cfg = _c2_config(bcs, **kw)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"{kw} filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+
+
+def test_c4_dual_trim_vs_oracle():
+    """BASELINE config 4: dual 24 x 16 barcodes, bc1 planted early, bc2 late, trim 5 / 3."""
+    b1 = synth.make_barcodes(24, 24, seed=1)
+    b2 = synth.make_barcodes(16, 24, seed=2)
+    seq, off, _ = synth.make_reads(b1, 40000, 150, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True,
+                            bc_seqs2=b2, bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)],
+                            max_error_rate=0.2, trim_side=5, trim_side2=3)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        fuzz.assert_same(hc.classify(seq, off), exp, "C4")
+        assert np.array_equal(hc.counts, oc.counts)
+    assert (exp["bc1"] > 0).mean() > 0.5  # the case is not vacuous
+
+
+def test_c5_long_reads_window_vs_oracle():
+    """BASELINE config 5: 10 kbp reads, 24 variable-length barcodes, ref_search_range 1:200."""
+    lens = np.random.Generator(np.random.PCG64(5)).integers(16, 33, size=24)
+    bcs = synth.make_barcodes(24, 24, seed=5, lengths=lens)
+    seq, off, _ = synth.make_reads(bcs, 3000, 10000, plant_lo=0, plant_hi=150)
+    cfg = _c2_config(bcs, max_error_rate=0.2, ref_search_range=H.bdx.parse_dynamic_range("1:200"))
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        fuzz.assert_same(hc.classify(seq, off), exp, "C5")
+    assert (exp["bc1"] > 0).mean() > 0.5
+
+
+# ---- edge cases ----
+def test_empty_and_tiny_reads():
+    cfg = _c2_config(["ACGTACGT", "TTTTCCCC"], max_error_rate=0.25, trim_side=3)
+    reads = ["", "A", "ACGTACGT", "ACGTACG", "NNNNNNNN", "acgtacgt", "TTTTCCCC" * 3, "", "ACGTACGTTTTTCCCC"]
+    seq, off = H.bdx.pack_reads(reads)
+    exp = H.orc.OracleClassifier(cfg).classify(seq, off)
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        fuzz.assert_same(hc.classify(seq, off), exp, "edge")
+        assert hc.classify(np.zeros(0, np.uint8), np.zeros(1, np.int64))["bc1"].shape == (0,)
+
+
+def test_offsets_need_not_start_at_zero():
+    bcs = synth.make_barcodes(8, 12, seed=3, min_hamming=4)
+    seq, off, _ = synth.make_ragged_reads(bcs, 5000, 20, 90, seed=3)
+    cfg = _c2_config(bcs, max_error_rate=0.2)
+    exp = H.orc.OracleClassifier(cfg, nthreads=8).classify(seq, off)
+    k = 1234
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        got = hc.classify(seq, off[k:])  # same byte buffer, offsets of a sub-range
+    fuzz.assert_same(got, {key: v[k:] for key, v in exp.items()}, "sub-range")
+
+
+def test_error_paths():
+    with pytest.raises(H.bdx.BdxError, match="trim_side must be 3 or 5"):
+        H.bdx.HipClassifier(_c2_config(["ACGT"], trim_side=4))
+    with pytest.raises(H.bdx.BdxError, match="empty"):
+        H.bdx.HipClassifier(_c2_config(["ACGT", ""]))
+    with pytest.raises(H.bdx.BdxError, match="indel"):
+        H.bdx.HipClassifier(_c2_config(["ACGT"], indel=0))
+
+
+def test_counts_accumulate_and_reset():
+    bcs = synth.make_barcodes(16, 16, seed=9, min_hamming=5)
+    seq, off, _ = synth.make_reads(bcs, 20000, 80, seed=9)
+    cfg = _c2_config(bcs, max_error_rate=0.2)
+    with H.bdx.HipClassifier(cfg) as hc:
+        hc.classify(seq, off)
+        c1 = hc.counts
+        hc.classify(seq, off)
+        assert np.array_equal(hc.counts, 2 * c1)
+        hc.reset_counts()
+        assert hc.counts.sum() == 0
+    assert c1[0] == 20000 and c1[1] + c1[2] + c1[3] == c1[0] and c1[4:].sum() == c1[1]
+
+
+# ---- full BASELINE size: size-independent properties + a sampled oracle check ----
+def test_c2_full_size_properties():
+    """10 M reads x 96 barcodes (BASELINE config 2) on device-resident buffers:
+    (1) counters are consistent with the per-read verdicts (a checksum of checksums),
+    (2) classifying a permutation of the reads gives the permuted verdicts,
+    (3) a re-run is bit-identical (idempotence), (4) a strided 1-in-200 sample equals the oracle."""
+    import torch
+
+    n = 10_000_000
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, truth = synth.make_reads(bcs, n, 150)
+    cfg = _c2_config(bcs)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_bc1 = torch.empty(n, dtype=torch.int32, device=dev)
+    d_bc1b = torch.empty(n, dtype=torch.int32, device=dev)
+    with H.bdx.HipClassifier(cfg) as hc:
+        hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1.data_ptr())
+        hc.sync()
+        counts = hc.counts
+        bc1 = d_bc1.cpu().numpy()
+        assert counts[0] == n
+        assert counts[1] == int((bc1 > 0).sum()) and counts[2] == int((bc1 == 0).sum())
+        assert np.array_equal(counts[4:], np.bincount(bc1[bc1 > 0] - 1, minlength=96))
+        # idempotence
+        hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1b.data_ptr())
+        hc.sync()
+        assert torch.equal(d_bc1, d_bc1b)
+        # permutation (reversal of read order): same bytes rows, reversed
+        d_rev = d_seq.view(n, 150).flip(0).contiguous().view(-1)
+        hc.classify_device(d_rev.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1b.data_ptr())
+        hc.sync()
+        assert torch.equal(d_bc1.flip(0), d_bc1b)
+    # planted barcodes are recovered (sanity of the workload itself)
+    planted = truth > 0
+    assert (bc1[planted] == truth[planted]).mean() > 0.9
+    # sampled oracle check
+    idx = np.arange(0, n, 200)
+    sseq = seq.reshape(n, 150)[idx].reshape(-1)
+    soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
+    assert np.array_equal(bc1[idx], exp["bc1"])
