@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -43,6 +44,11 @@ struct bdx_ctx {
     bdx_config_t cfg{};
     BdxDevCfg dev{};
     BdxGenericPlan plan{};
+    BdxBitparPlan bplan{};
+    DevBuf bp_tables;
+    DevBuf d_maxlen;
+    int user_len_hint = 0;  // 0 = measure every device batch
+    int filter_used = BDX_FILTER_OFF;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -128,6 +134,136 @@ int plan_generic(bdx_ctx *ctx) {
                 "barcodes too long for the on-chip DP columns: max length %d needs %zu B of LDS per lane "
                 "(limit: 64 lanes within 160 KiB)",
                 d.max_m, per_thread);
+}
+
+
+// ---- bit-parallel pre-filter: eligibility and tables (see bdx_bitpar.hip for the argument) ----
+int build_bitpar_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxBitparPlan &bp = ctx->bplan;
+    bp = BdxBitparPlan{};
+    if (c.filter == BDX_FILTER_OFF) return BDX_OK;
+    const int npass = c.is_dual ? 2 : 1;
+    // cost domain: every edit operation must cost >= 1 and a match >= 0
+    int cmin = 1;
+    if (c.algorithm == BDX_ALG_SEMIGLOBAL) {
+        cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
+        if (c.has_nindel && c.nindel < cmin) cmin = c.nindel;
+        if (c.match < 0 || cmin < 1) return BDX_OK;
+    }
+    const bool n_wild = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) || c.algorithm == BDX_ALG_HAMMING;
+    // alphabet = distinct barcode bytes (<= 7), everything else shares the "other" code
+    int code_of[256];
+    for (int i = 0; i < 256; ++i) code_of[i] = -1;
+    int K = 0;
+    size_t cand_words = 0;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        cand_words += (size_t)(p.n_barcodes + 31) / 32;
+        for (int b = 0; b < p.n_barcodes; ++b) {
+            const uint32_t m = p.bc_off[b + 1] - p.bc_off[b];
+            if (m > 32) return BDX_OK;  // one 32-bit word per barcode
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
+                if (code_of[ch] < 0) {
+                    if (K == 7) return BDX_OK;
+                    code_of[ch] = K++;
+                }
+            }
+        }
+    }
+    if (cand_words > 64) return BDX_OK;
+    bp.ncodes = K + 1;
+    std::vector<uint8_t> lut(256);
+    for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)(code_of[i] < 0 ? K : code_of[i]);
+    size_t bytes = 256;
+    size_t o_peq[2] = {0, 0}, o_pv[2] = {0, 0}, o_kb[2] = {0, 0};
+    for (int k = 0; k < npass; ++k) {
+        const int B = c.pass[k].n_barcodes;
+        bp.bpad[k] = 32;  // power of two >= B: peq row address = code << log2(4*bpad)
+        while (bp.bpad[k] < B) bp.bpad[k] <<= 1;
+        if ((size_t)bp.ncodes * bp.bpad[k] * 4 > 48 * 1024) return BDX_OK;
+        o_peq[k] = bytes;
+        bytes += (size_t)bp.ncodes * bp.bpad[k] * 4;
+        o_pv[k] = bytes;
+        bytes += (size_t)B * 4;
+        o_kb[k] = bytes;
+        bytes += (size_t)B * 4;
+    }
+    std::vector<uint8_t> blob(bytes, 0);
+    memcpy(blob.data(), lut.data(), 256);
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        uint32_t *peq = (uint32_t *)(blob.data() + o_peq[k]);
+        uint32_t *pv = (uint32_t *)(blob.data() + o_pv[k]);
+        int32_t *kb = (int32_t *)(blob.data() + o_kb[k]);
+        for (int b = 0; b < p.n_barcodes; ++b) {
+            const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+            const int shift = 32 - m;
+            const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
+            const uint32_t pad = ~rows;  // virtual rows below the barcode: match everything, D stays 0
+            pv[b] = rows;
+            for (int code = 0; code < bp.ncodes; ++code) {
+                uint32_t mask = pad;
+                for (int i = 0; i < m; ++i) {
+                    const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
+                    const bool wild = n_wild && ch == 'N';
+                    if (wild || (code < K && code_of[ch] == code)) mask |= 1u << (shift + i);
+                }
+                peq[(size_t)code * bp.bpad[k] + b] = mask;
+            }
+            // allowed_error at the initial threshold, exactly as the device computes it
+            long long ae;
+            if (c.algorithm == BDX_ALG_EXACT)
+                ae = 0;
+            else if (c.algorithm == BDX_ALG_HAMMING)
+                ae = (long long)std::floor(c.max_error_rate * (double)m);
+            else
+                ae = (long long)std::floor(c.max_error_rate * (double)(c.has_nindel ? p.bc_len_no_N[b] : m));
+            kb[b] = ae < 0 ? -1 : (int32_t)(ae / cmin);
+        }
+    }
+    HIP_TRY(ctx, ctx->bp_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->bp_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)ctx->bp_tables.p;
+    bp.d_lut = base;
+    for (int k = 0; k < npass; ++k) {
+        bp.d_peq[k] = (const uint32_t *)(base + o_peq[k]);
+        bp.d_pvinit[k] = (const uint32_t *)(base + o_pv[k]);
+        bp.d_kb[k] = (const int32_t *)(base + o_kb[k]);
+    }
+    bp.enabled = 1;
+    return BDX_OK;
+}
+
+// Geometry of the fused kernel for a given typical read length: the largest R whose LDS
+// footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
+bool size_bitpar(bdx_ctx *ctx, int read_len) {
+    BdxBitparPlan &bp = ctx->bplan;
+    if (!bp.enabled) return false;
+    if (read_len < 1) read_len = 1;
+    if (bp.read_len_hint == read_len && bp.reads_per_block > 0) return true;
+    int forced = 0;
+    if (const char *e = getenv("BDX_BITPAR_R")) forced = atoi(e);
+    const int tries[5] = {256, 128, 64, 32, 16};
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t limit = pass == 0 ? 80 * 1024 : LDS_MAX;
+        for (int R : tries) {
+            if (forced && R != forced) continue;
+            bp.reads_per_block = R;
+            size_t st = (size_t)R * (size_t)read_len + 64;
+            st = (st + 15) & ~(size_t)15;
+            if (st > (size_t)1 << 20) continue;
+            bp.stage_bytes = (int)st;
+            if (bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan) <= limit) {
+                bp.read_len_hint = read_len;
+                return true;
+            }
+        }
+    }
+    bp.reads_per_block = 0;
+    bp.read_len_hint = 0;
+    return false;
 }
 
 int validate(const bdx_config_t *c) {
@@ -288,7 +424,16 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = plan_generic(ctx);  // needs the caller's host tables: run before they are dropped
     if (rc != BDX_OK) return bail(rc);
-    ctx->path = "generic";
+    rc = build_bitpar_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
+    ctx->path = ctx->bplan.enabled ? "bitpar+verify" : "generic";
+    ctx->filter_used = ctx->bplan.enabled ? BDX_FILTER_BITPAR : BDX_FILTER_OFF;
+    if (ctx->bplan.enabled) {
+        if (ctx->d_maxlen.ensure(256) != hipSuccess) {
+            ctx->err = "hipMalloc failed";
+            return bail(BDX_E_DEVICE);
+        }
+    }
     // the copied config must not keep pointing at caller memory
     for (int k = 0; k < 2; ++k) {
         ctx->cfg.pass[k].bc_bytes = nullptr;
@@ -317,6 +462,8 @@ void bdx_destroy(bdx_ctx *ctx) {
         ctx->d_cand[k].release();
     }
     ctx->counts_own.release();
+    ctx->bp_tables.release();
+    ctx->d_maxlen.release();
     ctx->d_seq.release();
     ctx->d_off.release();
     ctx->d_out_i32.release();
@@ -327,6 +474,12 @@ void bdx_destroy(bdx_ctx *ctx) {
 int32_t bdx_set_stream(bdx_ctx *ctx, void *hip_stream) {
     if (!ctx) return BDX_E_INVALID;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return BDX_OK;
+}
+
+int32_t bdx_set_read_length_hint(bdx_ctx *ctx, int32_t typical_read_length) {
+    if (!ctx) return BDX_E_INVALID;
+    ctx->user_len_hint = typical_read_length > 0 ? typical_read_length : 0;
     return BDX_OK;
 }
 
@@ -354,10 +507,32 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     o.pass_score = d_out->pass_score;
     o.pass_bc = d_out->pass_bc;
     o.pass_delta = d_out->pass_delta;
-    HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                    ctx->counts, nullptr, nullptr, ctx->stream));
+    bool filtered = false;
+    if (ctx->bplan.enabled) {
+        int len = ctx->user_len_hint;
+        if (len <= 0) {  // measure the batch: one tiny kernel + a 4-byte copy
+            int host_len = 0;
+            HIP_TRY(ctx, bdx_launch_maxlen((const long long *)d_seq_off, n_reads, (int *)ctx->d_maxlen.p, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&host_len, ctx->d_maxlen.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            len = host_len;
+        }
+        filtered = size_bitpar(ctx, len);
+    }
+    if (filtered) {
+        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, d_seq_bytes, (const long long *)d_seq_off,
+                                       n_reads, o, ctx->counts, ctx->stream));
+        ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
+        ctx->path = "bitpar+verify";
+        ctx->filter_used = BDX_FILTER_BITPAR;
+    } else {
+        HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                        ctx->counts, nullptr, nullptr, ctx->stream));
+        ctx->last_blocks = (n_reads + ctx->plan.threads - 1) / ctx->plan.threads;
+        ctx->path = "generic";
+        ctx->filter_used = BDX_FILTER_OFF;
+    }
     ctx->launches += 1;
-    ctx->last_blocks = (n_reads + ctx->plan.threads - 1) / ctx->plan.threads;
     return BDX_OK;
 }
 
@@ -444,11 +619,12 @@ const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str()
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;
-    out->threads_per_block = ctx->plan.threads;
-    out->lds_bytes_per_block = (int32_t)ctx->plan.lds_bytes;
+    const bool f = ctx->filter_used == BDX_FILTER_BITPAR && ctx->bplan.reads_per_block > 0;
+    out->threads_per_block = f ? 256 : ctx->plan.threads;
+    out->lds_bytes_per_block = f ? (int32_t)bdx_bitpar_lds_bytes(ctx->dev, ctx->bplan, ctx->plan) : (int32_t)ctx->plan.lds_bytes;
     out->blocks = ctx->last_blocks;
-    out->reads_per_block = ctx->plan.threads;
-    out->filter_used = BDX_FILTER_OFF;
+    out->reads_per_block = f ? ctx->bplan.reads_per_block : ctx->plan.threads;
+    out->filter_used = ctx->filter_used;
     out->max_m = ctx->dev.max_m;
     out->launches = ctx->launches;
     return BDX_OK;

@@ -21,409 +21,9 @@
 // (lane mod 32): conflict-free by construction even when lanes sit on different rows.
 // All DP arithmetic is int32 (see bdx_internal.h for the bound that makes that exact); the
 // accept/tighten/ambiguity decisions are IEEE doubles exactly as written in the reference.
-#include "bdx_internal.h"
-
-#define LDS __attribute__((address_space(3)))
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#include "bdx_core.h"
 
 namespace {
-
-struct Costs {
-    int match, mismatch, indel, nindel;
-};
-
-struct AlignOut {
-    int raw;    // BDX_INF32 when nothing was recorded
-    int start;  // 1-based, -1 when not tracked
-    int end;
-};
-
-// Byte accessors: reads and barcodes either staged in LDS or left in global memory.
-template <bool STAGED>
-struct Bytes;
-template <>
-struct Bytes<true> {
-    const LDS uint8_t *p;
-    __device__ __forceinline__ int operator[](int i) const { return p[i]; }
-    __device__ __forceinline__ Bytes<true> at(long long o) const { return Bytes<true>{p + o}; }
-};
-template <>
-struct Bytes<false> {
-    const uint8_t *p;
-    __device__ __forceinline__ int operator[](int i) const { return p[i]; }
-    __device__ __forceinline__ Bytes<false> at(long long o) const { return Bytes<false>{p + o}; }
-};
-
-// resolve(), classification.jl:96-100, with Julia's UnitRange normalisation (empty a:b has
-// last == a-1; the callers use last(range), :800-801).
-__device__ __forceinline__ void resolve_range(const BdxDevRange &dr, long long len, long long &first,
-                                              long long &last) {
-    long long s = dr.start_from_end ? len + dr.start_offset : dr.start_offset;
-    long long e = dr.end_from_end ? len + dr.end_offset : dr.end_offset;
-    long long a = s > 1 ? s : 1;
-    long long b = e < len ? e : len;
-    if (b < a) b = a - 1;
-    first = a;
-    last = b;
-}
-
-// semiglobal_alignment_core, classification.jl:238-445, one (read, barcode) pair per lane.
-// DP / OG point at this lane's column: row i lives at DP[i * S].  q, r are 0-based here.
-// The three cell sites of the reference (:303 first row via step_scores, :340 main loop via
-// step_scores_main, :377 last row via step_scores) are one loop: step_scores differs from
-// step_scores_main only for i == 1 (row-0 value 0) and i == m (no horizontal move), and the
-// first iteration is the only one that can have i == 1.  DP[i-1] of the previous column is
-// carried in `diag` (it is the value read as DP[i] one iteration earlier), likewise origin.
-template <bool TB, bool NS, bool STAGED>
-__device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int S, const Bytes<STAGED> q,
-                                            const int m, const Bytes<STAGED> r, const int n, const int ae,
-                                            const Costs c, const int trim_side, int first, const int last,
-                                            const int max_start, const int min_end) {
-    AlignOut res{BDX_INF32, -1, -1};
-    if (m == 0 || n == 0) return res;  // :250-252
-
-    const int steps = ae / (NS ? (c.indel < c.nindel ? c.indel : c.nindel) : c.indel);  // :257, :170-176
-    const int min_valid_start = min_end - (m + steps) + 1;                            // :259
-    if (min_valid_start > max_start) return res;                                      // :261-263
-    if (min_valid_start > first) first = min_valid_start;                             // :266-268
-    const int b1 = m - n - steps, b2 = -max_start - steps;
-    const int band = b1 > b2 ? b1 : b2;  // :270
-
-    for (int i = 1; i <= m; ++i) {  // :278-283
-        DP[i * S] = c.indel * i;
-        if (TB) OG[i * S] = 1 - i;
-    }
-
-    int lact = (ae + 1 < m) ? ae + 1 : m;  // :286
-    for (int j = first; j <= last; ++j) {  // :287
-        int prev_o = j;                    // :288
-        int fact, prev;
-        if (j + band >= 1) {  // :289-295
-            fact = j + band;
-            prev = ae;
-        } else {
-            fact = 1;
-            prev = 0;
-        }
-        if (fact > lact) return res;  // :297-299
-
-        const int rj = r[j - 1];
-        int diag = (fact == 1) ? 0 : DP[(fact - 1) * S];
-        int diag_o = 0;
-        if (TB) diag_o = (fact == 1) ? j : OG[(fact - 1) * S];
-        for (int i = fact; i <= lact; ++i) {
-            const int qi = q[i - 1];
-            const bool isN = NS && (qi == 'N');
-            const int cost = isN ? c.nindel : c.indel;       // :196-197
-            const int dpi = DP[i * S];
-            const int ins = (i == m) ? BDX_INF32 : dpi + cost;  // :213 / :229, :183
-            const int del = prev + cost;                      // :184
-            const int sub = diag + ((qi == rj || isN) ? c.match : c.mismatch);  // :185, :202-203, :215
-            int cur_o = 0;
-            if (TB) {  // :310-321: deletion, then substitution if strictly less, then insertion
-                const int ins_o = OG[i * S];
-                int best = del;
-                cur_o = prev_o;
-                if (sub < best) {
-                    best = sub;
-                    cur_o = diag_o;
-                }
-                if (ins < best) cur_o = ins_o;
-                diag_o = ins_o;
-            }
-            if (i != 1) {  // :326-331, :364-367
-                DP[(i - 1) * S] = prev;
-                if (TB) OG[(i - 1) * S] = prev_o;
-            }
-            int t = del < sub ? del : sub;
-            prev = ins < t ? ins : t;  // :332
-            if (TB) prev_o = cur_o;
-            diag = dpi;
-        }
-        DP[lact * S] = prev;  // :412-415
-        if (TB) OG[lact * S] = prev_o;
-
-        if (lact == m && prev <= ae) {  // :417
-            lact -= 1;
-            if (j >= min_end) {
-                if (prev == 0 && (!TB || trim_side == 5)) {  // :420-430
-                    AlignOut z{0, TB ? prev_o : -1, TB ? j : -1};
-                    return z;
-                }
-                if (TB) {  // update_result, :142-153
-                    if (prev < res.raw || (prev == res.raw && trim_side == 3 && prev_o > res.start)) {
-                        res.raw = prev;
-                        res.start = prev_o;
-                        res.end = j;
-                    }
-                } else {  // :138-140
-                    res.raw = prev < res.raw ? prev : res.raw;
-                }
-            }
-        }
-        while (lact > 0 && DP[lact * S] > ae) --lact;  // :439-441
-        ++lact;                                         // :442
-    }
-    return res;  // :444
-}
-
-// hamming_align, classification.jl:557-625.  Scores of one call share the divisor m, so the
-// reference's Float64 `score < best_score` / `==` are decided on the integer numerators.
-template <bool STAGED>
-__device__ __forceinline__ AlignOut hamming_dev(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
-                                                const int n, const int allowed, const int first,
-                                                const int last, const int max_start, const int min_end,
-                                                const int trim_side) {
-    AlignOut best{BDX_INF32, -1, -1};
-    const int sf = first > 1 ? first : 1;  // :570
-    int sl = last < max_start ? last : max_start;
-    if (n - m + 1 < sl) sl = n - m + 1;  // :571
-    if (sl < sf) return best;            // :573-576
-    if (m == 0) return best;             // 0/0 = NaN never beats Inf (:607-613)
-    for (int j = sf; j <= sl; ++j) {     // :581
-        const int end_pos = j + m - 1;
-        if (end_pos < min_end) continue;  // :584-586
-        int mism = 0;
-        bool failed = false;
-        for (int k = 0; k < m; ++k) {  // :592-604
-            const int qc = q[k];
-            const int rc = r[j - 1 + k];
-            if (qc != rc && qc != 0x4E) {
-                if (++mism > allowed) {
-                    failed = true;
-                    break;
-                }
-            }
-        }
-        if (!failed) {  // :606-621
-            if (mism < best.raw) {
-                best.raw = mism;
-                best.start = j;
-                best.end = end_pos;
-            } else if (mism == best.raw && trim_side == 3 && j > best.start) {
-                best.start = j;
-                best.end = end_pos;
-            }
-        }
-    }
-    return best;
-}
-
-template <bool STAGED>
-__device__ __forceinline__ bool bytes_equal(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
-                                            const int s /*1-based*/) {
-    for (int k = 0; k < m; ++k)
-        if (q[k] != r[s - 1 + k]) return false;
-    return true;
-}
-
-// exact_align, classification.jl:485-548.  findnext(query, ref, i) = leftmost occurrence
-// starting at or after i; findprev(query, ref, k) = rightmost occurrence ENDING at or before k.
-template <bool STAGED>
-__device__ __forceinline__ AlignOut exact_dev(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
-                                              const int n, const int first, const int last,
-                                              const int max_start, const int min_end, const int trim_side) {
-    AlignOut none{BDX_INF32, -1, -1};
-    const int sf = first > 1 ? first : 1;  // :490
-    int sl = last < max_start ? last : max_start;
-    if (n - m + 1 < sl) sl = n - m + 1;  // :491
-    if (sl < sf) return none;            // :493-495
-    if (trim_side == 3) {                // :499-515: only the first findprev hit is examined
-        for (int s = sl; s >= 1; --s) {
-            if (bytes_equal<STAGED>(q, m, r, s)) {
-                if (s >= sf && s + m - 1 >= min_end) return AlignOut{0, s, s + m - 1};
-                return none;
-            }
-        }
-        return none;
-    }
-    // :517-547: leftmost hit; hits that end before min_end_pos are skipped and the scan goes on
-    for (int s = sf; s <= n - m + 1; ++s) {
-        if (bytes_equal<STAGED>(q, m, r, s)) {
-            if (s > sl) return none;
-            if (s + m - 1 >= min_end) return AlignOut{0, s, s + m - 1};
-        }
-    }
-    return none;
-}
-
-// Return tuple of find_best_matching_bc (classification.jl:722) plus match_barcode_pass's status.
-struct PassOut {
-    int status;  // 1 match, 0 unknown, -1 ambiguous, 2 pass not run
-    int bc;      // min_score_bc (kept even when ambiguous)
-    int start, end, raw;
-    double score;
-    double delta;
-};
-
-// match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
-// reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
-template <bool STAGED>
-__device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPass &P, const Bytes<STAGED> bcb,
-                                            const LDS uint32_t *bc_off, const LDS int *bc_nn,
-                                            const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
-                                            const int S, const uint32_t *cand) {
-    PassOut po{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-    long long first, last, max_start_ll, min_end_ll;
-    if (P.explicit_window) {
-        first = P.win_first;
-        last = P.win_last;
-        max_start_ll = P.win_max_start;
-        min_end_ll = P.win_min_end;
-    } else {
-        long long rs_f, rs_l, bs_f, bs_l, be_f, be_l;  // :795-797
-        resolve_range(P.ref_search, n, rs_f, rs_l);
-        resolve_range(P.bc_start, n, bs_f, bs_l);
-        resolve_range(P.bc_end, n, be_f, be_l);
-        first = rs_f > bs_f ? rs_f : bs_f;  // :799
-        if (first < 1) first = 1;
-        last = rs_l < be_l ? rs_l : be_l;  // :800
-        if (n < last) last = n;
-        max_start_ll = bs_l;  // :801
-        min_end_ll = be_f;    // :802
-        if (first > last || first > max_start_ll || last < min_end_ll) return po;  // :805-807
-    }
-    // After the sanity check every bound is within [-(2^30), 2^30]; clamp so int32 arithmetic
-    // in the cores cannot overflow for hand-made explicit windows.
-    const long long LIM = 1LL << 30;
-    auto clampi = [&](long long v) -> int { return (int)(v > LIM ? LIM : (v < -LIM ? -LIM : v)); };
-    const int jf = clampi(first), jl = clampi(last), max_start = clampi(max_start_ll), min_end = clampi(min_end_ll);
-
-    const int trim_side = P.trim_side;
-    const bool need_tb = (trim_side != 0) || cfg.need_traceback;  // :812
-    const Costs c{cfg.match, cfg.mismatch, cfg.indel, cfg.nindel};
-    const bool with_delta = !(cfg.min_delta == 0.0);  // :723
-
-    double rate = cfg.max_error_rate;
-    double min_score = __builtin_inf(), sub_min = __builtin_inf();
-    int best = 0, bs = -1, be = -1, braw = -1;
-
-    const bool align_one = P.explicit_window == BDX_WINDOW_ALIGN_ONE;
-    const int B = align_one ? 1 : P.n_barcodes;
-    for (int b = 0; b < B; ++b) {  // :638 / :676 — file order, threshold tightens as we go
-        if (cand && !((cand[b >> 5] >> (b & 31)) & 1u)) continue;
-        const int o = (int)bc_off[b];
-        const int m = (int)bc_off[b + 1] - o;
-        const Bytes<STAGED> q = bcb.at(o);
-        AlignOut a;
-        double score;
-        if (cfg.algorithm == BDX_ALG_HAMMING) {
-            const int allowed = (int)__builtin_floor(rate * (double)m);  // :567
-            a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side);
-            score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :607
-        } else if (cfg.algorithm == BDX_ALG_EXACT) {
-            a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side);
-            score = a.raw >= BDX_INF32 ? __builtin_inf() : 0.0;
-        } else {
-            const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476
-            const int ae = (int)__builtin_floor(rate * (double)norm);     // :254
-            if (cfg.has_nindel) {
-                a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
-                            : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
-            } else {
-                a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
-                            : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
-            }
-            score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)norm;  // :155-168
-        }
-        if (align_one) {  // unit-level API: the direct return of one alignment call
-            if (a.raw < BDX_INF32) {
-                po.status = 1;
-                po.bc = 1;
-                po.start = a.start;
-                po.end = a.end;
-                po.raw = a.raw;
-                po.score = score;
-            }
-            return po;
-        }
-        if (!with_delta) {  // :658-664
-            if (score <= rate && score < min_score) {
-                min_score = score;
-                best = b + 1;
-                rate = rate < min_score ? rate : min_score;
-                bs = a.start;
-                be = a.end;
-                braw = a.raw;
-            }
-        } else if (score <= rate) {  // :696-708
-            if (score < min_score) {
-                sub_min = min_score;
-                min_score = score;
-                best = b + 1;
-                rate = rate < sub_min ? rate : sub_min;
-                bs = a.start;
-                be = a.end;
-                braw = a.raw;
-            } else if (score < sub_min) {
-                sub_min = score;
-                rate = rate < sub_min ? rate : sub_min;
-            }
-        }
-    }
-    const double delta = with_delta ? (sub_min - min_score) : __builtin_inf();  // :711 / :666
-    po.bc = best;
-    po.start = bs;
-    po.end = be;
-    po.raw = braw;
-    po.score = min_score;
-    po.delta = delta;
-    if (best == 0) return po;  // :820-821
-    po.status = (delta < cfg.min_delta) ? -1 : 1;  // :822-823, :867
-    return po;
-}
-
-struct Verdict {
-    int bc1, bc2, keep_start, keep_end;
-};
-
-template <bool STAGED>
-__device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<STAGED> bcb0,
-                                             const Bytes<STAGED> bcb1, const LDS uint32_t *off0,
-                                             const LDS uint32_t *off1, const LDS int *nn0, const LDS int *nn1,
-                                             const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
-                                             const int S, const uint32_t *cand0, const uint32_t *cand1,
-                                             Verdict &v, PassOut &p1, PassOut &p2) {
-    // determine_filename, classification.jl:871-938
-    v = Verdict{0, 0, -1, -1};
-    p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-    p1 = run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0);  // :875
-    if (p1.status != 1) {  // :879-883
-        v.bc1 = p1.status;
-        return;
-    }
-    if (cfg.is_dual) {  // :887-895
-        p2 = run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1);
-        if (p2.status != 1) {
-            v.bc1 = p2.status;
-            return;
-        }
-        v.bc2 = p2.bc;
-    }
-    v.bc1 = p1.bc;
-    int keep_start = 1, keep_end = n;  // :907-908
-    const int ts1 = cfg.pass[0].trim_side, ts2 = cfg.pass[1].trim_side;
-    if (ts1 == 3)  // :910-919
-        keep_end = (p1.start > 1 ? p1.start : 1) - 1;
-    else if (ts1 == 5)
-        keep_start = p1.end + 1;
-    if (cfg.is_dual) {  // :921-929
-        if (ts2 == 3) {
-            const int e2 = (p2.start > 1 ? p2.start : 1) - 1;
-            keep_end = keep_end < e2 ? keep_end : e2;
-        } else if (ts2 == 5) {
-            const int s2 = p2.end + 1;
-            keep_start = keep_start > s2 ? keep_start : s2;
-        }
-    }
-    if (keep_start > keep_end) {  // :932-935
-        v.keep_start = 1;
-        v.keep_end = 0;
-    } else {
-        v.keep_start = keep_start;
-        v.keep_end = keep_end;
-    }
-}
 
 struct GenericArgs {
     BdxDevCfg cfg;
@@ -590,6 +190,33 @@ __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
 }
 
 }  // namespace
+
+namespace {
+__global__ void bdx_maxlen_kernel(const long long *off, long long n, int *out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = 0;
+    for (; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long d = off[i + 1] - off[i];
+        const int x = d > 0x3FFFFFFF ? 0x3FFFFFFF : (int)d;
+        v = x > v ? x : v;
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        const int o = __shfl_xor(v, s, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+}
+}  // namespace
+
+hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    if (n_reads <= 0) return hipSuccess;
+    long long blocks = (n_reads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bdx_maxlen_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_off, n_reads, d_out);
+    return hipGetLastError();
+}
 
 hipError_t bdx_generic_set_lds_limit(size_t bytes) {
     hipError_t e;

@@ -67,6 +67,29 @@ struct BdxGenericPlan {
     size_t lds_bytes;
 };
 
+// Bit-parallel (Myers) pre-filter: tables built on the host in bdx_abi.cpp, used by
+// bdx_bitpar.hip.  enabled == 0 -> the config is outside the filter's domain.
+struct BdxBitparPlan {
+    int enabled;
+    int reads_per_block;   // R: 256 / 128 / 64 / 32 / 16
+    int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
+    int read_len_hint;     // the read length the geometry was planned for
+    int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
+    int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
+    const uint8_t *d_lut;          // device, 256 bytes
+    const uint32_t *d_peq[2];      // device, [ncodes][bpad]
+    const uint32_t *d_pvinit[2];   // device, [B]: top-aligned mask of the barcode's rows
+    const int32_t *d_kb[2];        // device, [B]: max unit edit operations of a recordable alignment
+};
+
+// Implemented in bdx_bitpar.hip.
+size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp);
+hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
+                             const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
+                             unsigned long long *d_counts, hipStream_t stream);
+// max read length of a device-resident batch (one tiny kernel; result written to *d_out)
+hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
+
 // Implemented in bdx_device.hip.
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,
                               const long long *d_off, long long n_reads, const BdxDevOut &out,

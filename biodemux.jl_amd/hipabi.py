@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "bdx_abi_version", "bdx_create", "bdx_destroy", "bdx_last_error", "bdx_classify_host",
     "bdx_classify_device", "bdx_sync", "bdx_set_stream", "bdx_counts_len", "bdx_get_counts",
     "bdx_reset_counts", "bdx_counts_device_ptr", "bdx_set_counts_buffer", "bdx_kernel_path",
-    "bdx_launch_info",
+    "bdx_launch_info", "bdx_set_read_length_hint",
 ]
 
 
@@ -150,6 +150,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_counts_device_ptr.argtypes = [vp]
     L.bdx_set_counts_buffer.restype = C.c_int32
     L.bdx_set_counts_buffer.argtypes = [vp, vp]
+    L.bdx_set_read_length_hint.restype = C.c_int32
+    L.bdx_set_read_length_hint.argtypes = [vp, C.c_int32]
     L.bdx_kernel_path.restype = C.c_char_p
     L.bdx_kernel_path.argtypes = [vp]
     L.bdx_launch_info.restype = C.c_int32
@@ -296,6 +298,9 @@ class HipClassifier:
 
     def sync(self):
         self._check(self.lib.bdx_sync(self.h))
+
+    def set_read_length_hint(self, n: int):
+        self._check(self.lib.bdx_set_read_length_hint(self.h, int(n)))
 
     def set_stream(self, hip_stream: int):
         self._check(self.lib.bdx_set_stream(self.h, hip_stream))

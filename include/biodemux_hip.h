@@ -166,6 +166,12 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
 int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int64_t *d_seq_off,
                             int64_t n_reads, const bdx_outputs_t *d_out);
 
+/* Optional: the typical (maximum) read length of the batches to come.  The fused kernels size
+ * their LDS staging for it; without a hint every device batch is measured first (one tiny
+ * kernel + a 4-byte copy, which synchronises the stream).  Reads longer than planned are
+ * still classified exactly, by a slower path.  0 clears the hint. */
+int32_t bdx_set_read_length_hint(bdx_ctx *ctx, int32_t typical_read_length);
+
 /* Waits for the context's stream. */
 int32_t bdx_sync(bdx_ctx *ctx);
 

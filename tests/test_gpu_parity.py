@@ -204,6 +204,7 @@ def test_c2_full_size_properties():
         assert torch.equal(d_bc1, d_bc1b)
         # permutation (reversal of read order): same bytes rows, reversed
         d_rev = d_seq.view(n, 150).flip(0).contiguous().view(-1)
+        torch.cuda.synchronize()  # torch's stream produced d_rev; the classifier runs on its own stream
         hc.classify_device(d_rev.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1b.data_ptr())
         hc.sync()
         assert torch.equal(d_bc1.flip(0), d_bc1b)
