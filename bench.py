@@ -66,6 +66,8 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
     dev_index = local_rank if world > 1 else 0
+    if os.environ.get("BDX_FORCE_DEVICE"):  # rehearsal of N > 1 on a 1-GPU box (with BDX_DIST_BACKEND=gloo)
+        dev_index = int(os.environ["BDX_FORCE_DEVICE"])
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -124,6 +126,8 @@ def main():
     # max over ranks
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
+        if torch.distributed.get_backend() == "gloo":
+            el = el.cpu()
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed_max = float(el.item())
     kern_ms = [a.elapsed_time(b) for a, b in events]          # device time of the classify launch(es)

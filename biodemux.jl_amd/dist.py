@@ -32,7 +32,7 @@ def init_process_group(backend: str = None):
     if world <= 1:
         return rank, local_rank, world
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("BDX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if backend == "nccl":
@@ -69,5 +69,10 @@ def allreduce_counts(counts):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl" and not t.is_cuda:
             t = t.cuda()
+        if dist.get_backend() == "gloo" and t.is_cuda:  # CPU rehearsal of the multi-rank path
+            dev = t.device
+            t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy() if is_np else t
