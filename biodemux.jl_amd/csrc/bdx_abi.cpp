@@ -232,6 +232,13 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         bp.d_pvinit[k] = (const uint32_t *)(base + o_pv[k]);
         bp.d_kb[k] = (const int32_t *)(base + o_kb[k]);
     }
+    // known-score class (config level): SimpleScoring with unit costs, ScoreOnly output.
+    for (int k = 0; k < npass; ++k) {
+        const bool score_only = c.pass[k].trim_side == 0 && !c.need_traceback;
+        bp.known_ok[k] = c.algorithm == BDX_ALG_SEMIGLOBAL && !c.has_nindel && c.match == 0 && c.mismatch == 1 &&
+                         c.indel == 1 && score_only && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE &&
+                         !getenv("BDX_NO_KNOWN");
+    }
     bp.enabled = 1;
     return BDX_OK;
 }

@@ -48,6 +48,7 @@ struct BitparArgs {
     int ncodes;
     int bpad[2];
     int bshift[2];
+    int known_ok[2];  // config-level eligibility of the known-score class per pass
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
 };
 
@@ -87,6 +88,9 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *cand = (LDS uint32_t *)take((size_t)R * (cw0 + cw1) * 4);
     LDS int *roff = (LDS int *)take((size_t)(R + 1) * 4);   // byte offset of each read in the stage
     LDS int *win = (LDS int *)take((size_t)R * 4 * 4);      // [pass][first|last][R]
+    LDS uint32_t *slots = (LDS uint32_t *)take((size_t)2 * R * 4 * 4);  // [pass][R][4] (barcode << 8 | d)
+    LDS int *scnt = (LDS int *)take((size_t)2 * R * 4);                 // [pass][R] entries pushed
+    LDS unsigned char *full = take((size_t)2 * R);                      // [pass][R] read is in the known-score class
     LDS unsigned char *rstage = take((size_t)a.stage_bytes);
     LDS unsigned char *codes = take((size_t)a.stage_bytes);
 
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < 256; i += BS) lut[i] = a.lut[i];
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
     for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
+    for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
     __syncthreads();
     const int bytes0 = (int)off0[B0];
     const int bytes1 = cfg.is_dual ? (int)off1[B1] : 0;
@@ -146,6 +151,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             int l = ok ? (w.last < n ? w.last : n) : 0;
             win[(p * 2 + 0) * R + t] = f;
             win[(p * 2 + 1) * R + t] = l;
+            // known-score class, per read: every column 1..n is swept and neither the start nor
+            // the end range binds (band_offset = m-n-steps, min_valid_start <= 1, j >= min_end always)
+            full[p * R + t] = (unsigned char)(a.known_ok[p] && ok && n > 0 && w.first == 1 && w.last == n &&
+                                              w.max_start >= n && w.min_end <= 1);
         }
     }
     __syncthreads();
@@ -206,9 +215,15 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                     Mv = Ph & Xv;
                     best = score < best ? score : best;
                 }
-                if (best <= kb[b])
+                if (best <= kb[b]) {
                     __hip_atomic_fetch_or(&cnd[r * cw + (b >> 5)], 1u << (b & 31), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (full[p * R + r]) {
+                        const int k = __hip_atomic_fetch_add(&scnt[p * R + r], 1, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k < 4) slots[(p * R + r) * 4 + k] = ((uint32_t)b << 8) | (uint32_t)best;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -230,7 +245,14 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             const uint32_t *c1 = (const uint32_t *)(cand + R * cw0 + tid * cw1);
             Bytes<true> r{rstage + roff[tid]};
             Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2);
+            KnownPass kn[2];
+            for (int p = 0; p < 2; ++p) {
+                const int cnt = scnt[p * R + tid];
+                const LDS uint32_t *e = slots + (p * R + tid) * 4;
+                // more than four survivors (or a read outside the class): exact evaluation instead
+                kn[p] = KnownPass{p < npass && full[p * R + tid] && cnt <= 4, e[0], e[1], e[2], e[3], cnt};
+            }
+            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn[0], kn[1]);
         } else {  // span larger than the staging area: unfiltered evaluation straight from HBM/L2
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
@@ -322,6 +344,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + al((size_t)R * 16);
+    o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += 2 * al((size_t)bp.stage_bytes);
     return o;
 }
@@ -352,6 +375,8 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     }
     a.ncodes = bp.ncodes;
     a.dbg = 0;
+    a.known_ok[0] = bp.known_ok[0];
+    a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
     const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp);
     switch (bp.reads_per_block) {

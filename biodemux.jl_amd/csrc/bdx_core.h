@@ -277,6 +277,65 @@ struct PassOut {
     double delta;
 };
 
+// The two sequential reducers of the reference as one state machine:
+// find_best_matching_bc_no_delta (classification.jl:632-667) when min_delta == 0.0 (:723),
+// find_best_matching_bc_with_delta (:669-713) otherwise.  Every comparison is the Float64
+// comparison written there; `rate` is the tightening max_error_rate.
+struct Reducer {
+    double rate, min_score, sub_min;
+    int best, bs, be, braw;
+    bool with_delta;
+
+    __device__ __forceinline__ void init(const BdxDevCfg &cfg) {
+        rate = cfg.max_error_rate;
+        min_score = __builtin_inf();
+        sub_min = __builtin_inf();
+        best = 0;
+        bs = -1;
+        be = -1;
+        braw = -1;
+        with_delta = !(cfg.min_delta == 0.0);  // :723
+    }
+    __device__ __forceinline__ void feed(const int b /*0-based*/, const AlignOut &a, const double score) {
+        if (!with_delta) {  // :658-664
+            if (score <= rate && score < min_score) {
+                min_score = score;
+                best = b + 1;
+                rate = rate < min_score ? rate : min_score;
+                bs = a.start;
+                be = a.end;
+                braw = a.raw;
+            }
+        } else if (score <= rate) {  // :696-708
+            if (score < min_score) {
+                sub_min = min_score;
+                min_score = score;
+                best = b + 1;
+                rate = rate < sub_min ? rate : sub_min;
+                bs = a.start;
+                be = a.end;
+                braw = a.raw;
+            } else if (score < sub_min) {
+                sub_min = score;
+                rate = rate < sub_min ? rate : sub_min;
+            }
+        }
+    }
+    __device__ __forceinline__ PassOut finish(const BdxDevCfg &cfg) const {
+        PassOut po{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
+        const double delta = with_delta ? (sub_min - min_score) : __builtin_inf();  // :711 / :666
+        po.bc = best;
+        po.start = bs;
+        po.end = be;
+        po.raw = braw;
+        po.score = min_score;
+        po.delta = delta;
+        if (best == 0) return po;                        // :820-821
+        po.status = (delta < cfg.min_delta) ? -1 : 1;    // :822-823, :867
+        return po;
+    }
+};
+
 // match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
 // reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
 template <bool STAGED>
@@ -292,11 +351,8 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
     const int trim_side = P.trim_side;
     const bool need_tb = (trim_side != 0) || cfg.need_traceback;  // :812
     const Costs c{cfg.match, cfg.mismatch, cfg.indel, cfg.nindel};
-    const bool with_delta = !(cfg.min_delta == 0.0);  // :723
-
-    double rate = cfg.max_error_rate;
-    double min_score = __builtin_inf(), sub_min = __builtin_inf();
-    int best = 0, bs = -1, be = -1, braw = -1;
+    Reducer red;
+    red.init(cfg);
 
     const bool align_one = P.explicit_window == BDX_WINDOW_ALIGN_ONE;
     const int B = align_one ? 1 : P.n_barcodes;
@@ -325,7 +381,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         AlignOut a;
         double score;
         if (cfg.algorithm == BDX_ALG_HAMMING) {
-            const int allowed = (int)__builtin_floor(rate * (double)m);  // :567
+            const int allowed = (int)__builtin_floor(red.rate * (double)m);  // :567
             a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :607
         } else if (cfg.algorithm == BDX_ALG_EXACT) {
@@ -333,7 +389,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             score = a.raw >= BDX_INF32 ? __builtin_inf() : 0.0;
         } else {
             const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476
-            const int ae = (int)__builtin_floor(rate * (double)norm);     // :254
+            const int ae = (int)__builtin_floor(red.rate * (double)norm);  // :254
             if (cfg.has_nindel) {
                 a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
                             : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
@@ -354,44 +410,53 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             }
             return po;
         }
-        if (!with_delta) {  // :658-664
-            if (score <= rate && score < min_score) {
-                min_score = score;
-                best = b + 1;
-                rate = rate < min_score ? rate : min_score;
-                bs = a.start;
-                be = a.end;
-                braw = a.raw;
-            }
-        } else if (score <= rate) {  // :696-708
-            if (score < min_score) {
-                sub_min = min_score;
-                min_score = score;
-                best = b + 1;
-                rate = rate < sub_min ? rate : sub_min;
-                bs = a.start;
-                be = a.end;
-                braw = a.raw;
-            } else if (score < sub_min) {
-                sub_min = score;
-                rate = rate < sub_min ? rate : sub_min;
-            }
-        }
+        red.feed(b, a, score);
     }
-    const double delta = with_delta ? (sub_min - min_score) : __builtin_inf();  // :711 / :666
-    po.bc = best;
-    po.start = bs;
-    po.end = be;
-    po.raw = braw;
-    po.score = min_score;
-    po.delta = delta;
-    if (best == 0) return po;  // :820-821
-    po.status = (delta < cfg.min_delta) ? -1 : 1;  // :822-823, :867
-    return po;
+    return red.finish(cfg);
+}
+
+// The same pass when the per-barcode alignment result is already known as a function of the
+// threshold: for the class delimited in bdx_bitpar.hip ("known-score class") the reference's
+// semiglobal_alignment returns  d  if d <= floor(max_error * m)  else Inf, d being the exact
+// unit-cost semi-global distance delivered by the bit-vector sweep.  `entries` holds up to four
+// (barcode << 8 | d) words of this read in arbitrary order; they are replayed in ascending
+// barcode (= file) order through the very same reducer.
+__device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const LDS uint32_t *bc_off,
+                                                  const uint32_t e0, const uint32_t e1, const uint32_t e2,
+                                                  const uint32_t e3, const int count) {
+    Reducer red;
+    red.init(cfg);
+    uint32_t last = 0;  // entries are > 0 only if barcode > 0 or d > 0; use +1 bias below
+    for (int k = 0; k < count; ++k) {
+        // smallest biased entry greater than `last` (static scan: no dynamic register indexing)
+        uint32_t pick = 0xFFFFFFFFu;
+        const uint32_t c0 = e0 + 1u, c1 = e1 + 1u, c2 = e2 + 1u, c3 = e3 + 1u;
+        if (count > 0 && c0 > last && c0 < pick) pick = c0;
+        if (count > 1 && c1 > last && c1 < pick) pick = c1;
+        if (count > 2 && c2 > last && c2 < pick) pick = c2;
+        if (count > 3 && c3 > last && c3 < pick) pick = c3;
+        last = pick;
+        const uint32_t e = pick - 1u;
+        const int b = (int)(e >> 8);
+        const int d = (int)(e & 255u);
+        const int m = (int)bc_off[b + 1] - (int)bc_off[b];
+        const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
+        AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};
+        const double score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :155-160
+        red.feed(b, a, score);
+    }
+    return red.finish(cfg);
 }
 
 struct Verdict {
     int bc1, bc2, keep_start, keep_end;
+};
+
+// Per-pass hand-over from the bit-vector sweep for reads of the known-score class.
+struct KnownPass {
+    bool use;
+    uint32_t e0, e1, e2, e3;
+    int count;
 };
 
 template <bool STAGED>
@@ -400,17 +465,21 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
                                              const LDS uint32_t *off1, const LDS int *nn0, const LDS int *nn1,
                                              const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
                                              const int S, const uint32_t *cand0, const uint32_t *cand1,
-                                             Verdict &v, PassOut &p1, PassOut &p2) {
+                                             Verdict &v, PassOut &p1, PassOut &p2,
+                                             const KnownPass kn0 = KnownPass{false, 0, 0, 0, 0, 0},
+                                             const KnownPass kn1 = KnownPass{false, 0, 0, 0, 0, 0}) {
     // determine_filename, classification.jl:871-938
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-    p1 = run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0);  // :875
+    p1 = kn0.use ? run_pass_known(cfg, off0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
+                 : run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
-        p2 = run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1);
+        p2 = kn1.use ? run_pass_known(cfg, off1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
+                     : run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

@@ -75,6 +75,7 @@ struct BdxBitparPlan {
     int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
     int read_len_hint;     // the read length the geometry was planned for
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
+    int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
     const uint8_t *d_lut;          // device, 256 bytes
     const uint32_t *d_peq[2];      // device, [ncodes][bpad]

@@ -815,3 +815,78 @@ int orc_classify_batch(const orc_config_t *cfg, const uint8_t *seq_bytes, const 
     free(tids);
     return 0;
 }
+
+/* ---- differential self-test supporting the "known-score class" of the HIP path ----
+ * Claim: with SimpleScoring unit costs (match 0, mismatch 1, indel 1),
+ * ScoreOnly output, ref_search_range = 1:n, max_start_pos >= n and min_end_pos <= 1,
+ * semiglobal_alignment_core returns  d  when d <= floor(max_error*m)  and Inf otherwise, where
+ * d = min over read substrings of the unit-cost edit distance (plain full-matrix DP below).
+ * Returns the number of disagreeing cases among `iters` random (barcode, read, rate) triples. */
+static uint64_t st_next(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+int64_t orc_unit_distance(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n) {
+    int64_t *prev = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    int64_t best = m;
+    for (int64_t i = 0; i <= m; i++) prev[i] = i;
+    for (int64_t j = 1; j <= n; j++) {
+        cur[0] = 0;
+        for (int64_t i = 1; i <= m; i++) {
+            int64_t a = prev[i] + 1, b = cur[i - 1] + 1, c = prev[i - 1] + (q[i - 1] != r[j - 1]);
+            cur[i] = a < b ? (a < c ? a : c) : (b < c ? b : c);
+        }
+        if (cur[m] < best) best = cur[m];
+        int64_t *t = prev;
+        prev = cur;
+        cur = t;
+    }
+    free(prev);
+    free(cur);
+    return best;
+}
+
+int64_t orc_selftest_known_class(uint64_t seed, int64_t iters, int64_t *first_bad /* 6 ints or NULL */) {
+    static const char AL[5] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[200];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 1 + (int64_t)(st_next(&s) % 32);
+        int64_t n = (int64_t)(st_next(&s) % 160);
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % 4];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % ((st_next(&s) % 50) ? 4 : 5)];
+        if (n > 0 && (st_next(&s) % 4)) { /* plant a mutated copy */
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 6) r[pos++] = (uint8_t)AL[st_next(&s) % 4];      /* substitution */
+                else if (u < 9) continue;                                  /* deletion */
+                else if (u < 12) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = q[i]; } /* insertion */
+                else r[pos++] = q[i];
+            }
+        }
+        double rate = RATES[st_next(&s) % 8];
+        int64_t max_start = n + (int64_t)(st_next(&s) % 3) * 50; /* n, n+50, n+100: all non-binding */
+        int64_t min_end = 1 - (int64_t)(st_next(&s) % 2);         /* 1 or 0 */
+        orc_align_t a = orc_semiglobal_core(DP, OG, q, m, r, n, rate, 0, 1, 1, 0, 0, ORC_OUT_SCOREONLY, 0,
+                                            1, n, max_start, min_end, m);
+        int64_t d = n > 0 ? orc_unit_distance(q, m, r, n) : m;
+        int64_t ae = (int64_t)floor(rate * (double)m);
+        int64_t expect = (n > 0 && d <= ae) ? d : INF_INT;
+        if (a.raw != expect) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = a.raw;
+                first_bad[4] = expect; first_bad[5] = ae;
+            }
+            bad++;
+        }
+    }
+    return bad;
+}

@@ -142,6 +142,10 @@ def lib():
             C.POINTER(OrcConfig), u8p, i64p, C.c_int64, i32p, i32p, i32p, i32p, i32p, i32p, f64p, i32p, f64p, i64p,
             C.c_int32,
         ]
+        L.orc_selftest_known_class.restype = C.c_int64
+        L.orc_selftest_known_class.argtypes = [C.c_uint64, C.c_int64, i64p]
+        L.orc_unit_distance.restype = C.c_int64
+        L.orc_unit_distance.argtypes = [u8p, C.c_int64, u8p, C.c_int64]
         _lib = L
     return _lib
 

@@ -1,0 +1,22 @@
+"""Evidence for the 'known-score class' used by the fused HIP kernel:
+under SimpleScoring unit costs, ScoreOnly output and non-binding ranges, the reference's
+banded cut-off DP (restated line by line in the oracle) returns exactly the plain full-matrix
+semi-global distance d when d <= floor(rate*m), else Inf.  Differential test on random
+(barcode, read, rate) triples incl. planted/mutated copies, N bases, empty reads, m = 1..32."""
+import ctypes as C
+
+import helpers as H
+
+
+def test_core_equals_plain_dp_in_class():
+    fb = (C.c_int64 * 6)()
+    bad = H.orc.lib().orc_selftest_known_class(20260515, 400_000, fb)
+    assert bad == 0, f"first disagreement (iter, m, n, core, plain, ae): {list(fb)}"
+
+
+def test_unit_distance_sanity():
+    u8 = lambda b: (C.c_uint8 * len(b)).from_buffer_copy(b)
+    d = H.orc.lib().orc_unit_distance
+    assert d(u8(b"ACGT"), 4, u8(b"TTACGTTT"), 8) == 0
+    assert d(u8(b"ACGT"), 4, u8(b"TTACTTT"), 7) == 1
+    assert d(u8(b"AAAA"), 4, u8(b"CCCC"), 4) == 4
