@@ -252,21 +252,34 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
     if (bp.read_len_hint == read_len && bp.reads_per_block > 0) return true;
     int forced = 0;
     if (const char *e = getenv("BDX_BITPAR_R")) forced = atoi(e);
+    // Pick the R that keeps the most waves resident per CU (the sweep is latency-bound):
+    // workgroups/CU = min(8, floor(160 KiB / LDS(R))) with 4 waves each; ties -> larger R
+    // (fewer table reloads).  R = 16 is only taken when nothing larger fits.
     const int tries[5] = {256, 128, 64, 32, 16};
-    for (int pass = 0; pass < 2; ++pass) {
-        const size_t limit = pass == 0 ? 80 * 1024 : LDS_MAX;
-        for (int R : tries) {
-            if (forced && R != forced) continue;
-            bp.reads_per_block = R;
-            size_t st = (size_t)R * (size_t)read_len + 64;
-            st = (st + 15) & ~(size_t)15;
-            if (st > (size_t)1 << 20) continue;
-            bp.stage_bytes = (int)st;
-            if (bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan) <= limit) {
-                bp.read_len_hint = read_len;
-                return true;
-            }
+    int best_R = 0, best_blocks = 0, best_stage = 0;
+    for (int R : tries) {
+        if (forced && R != forced) continue;
+        size_t st = (size_t)R * (size_t)read_len + 64;
+        st = (st + 15) & ~(size_t)15;
+        if (st > (size_t)1 << 20) continue;
+        bp.reads_per_block = R;
+        bp.stage_bytes = (int)st;
+        const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan);
+        if (lds > LDS_MAX) continue;
+        int blocks = (int)(LDS_MAX / lds);
+        if (blocks > 8) blocks = 8;
+        if (R == 16 && best_R) continue;
+        if (blocks > best_blocks) {
+            best_blocks = blocks;
+            best_R = R;
+            best_stage = (int)st;
         }
+    }
+    if (best_R) {
+        bp.reads_per_block = best_R;
+        bp.stage_bytes = best_stage;
+        bp.read_len_hint = read_len;
+        return true;
     }
     bp.reads_per_block = 0;
     bp.read_len_hint = 0;

@@ -183,47 +183,85 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             const LDS int *wf = win + (p * 2 + 0) * R;
             const LDS int *wl = win + (p * 2 + 1) * R;
             const int total = nr * B;
-            for (int pair = tid; pair < ((a.dbg & 2) ? 0 : total); pair += BS) {
+            // Two independent pairs per lane per trip (pair, pair + BS): the recurrence is a serial
+            // chain of ~14 dependent VALU ops per column, so a second chain fills the issue slots
+            // the first one leaves while waiting (the sweep is latency-bound at 2-4 waves/SIMD).
+            struct Sweep {
+                const LDS unsigned char *c;
+                const LDS unsigned char *pq;
+                uint32_t Pv, Mv;
+                int score, best, ncol, r, b;
+            };
+            auto setup = [&](int pair, Sweep &w) {
+                w.ncol = 0;
+                w.r = 0;
+                w.b = 0;
+                w.c = codes;
+                w.pq = (const LDS unsigned char *)peq;
+                w.Pv = 0;
+                w.Mv = 0;
+                w.score = 0;
+                w.best = 0x7FFFFFFF;
+                if (pair >= total) return;
                 const int r = pair / B;
                 const int b = pair - r * B;
                 const int jf = wf[r];
                 int jl = wl[r];
-                if (jl < jf) continue;
-                uint32_t Pv = pv[b], Mv = 0;
-                int score = __builtin_popcount(Pv);  // = barcode length m
+                if (jl < jf) return;
+                w.r = r;
+                w.b = b;
+                w.Pv = pv[b];
+                w.score = __builtin_popcount(w.Pv);  // = barcode length m
+                w.best = w.score;
                 if (!sg) {
                     // :hamming / :exact bound the START positions by the window (SURVEY Q11,
                     // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
                     const int nread = roff[r + 1] - roff[r];
-                    jl = jl + score - 1 < nread ? jl + score - 1 : nread;
+                    jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
                 }
-                const LDS unsigned char *c = codes + roff[r] + (jf - 1);
-                const int ncol = jl - jf + 1;
-                const LDS unsigned char *pq = (const LDS unsigned char *)(peq + b);
-                int best = score;
-#pragma unroll 4
-                for (int j = 0; j < ncol; ++j) {
-                    const uint32_t Eq = *(const LDS uint32_t *)(pq + ((uint32_t)c[j] << sh));
-                    const uint32_t Xv = Eq | Mv;
-                    const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                    uint32_t Ph = Mv | ~(Xh | Pv);
-                    uint32_t Mh = Pv & Xh;
-                    score += (int)(Ph >> 31) - (int)(Mh >> 31);
-                    Ph <<= 1;
-                    Mh <<= 1;
-                    Pv = Mh | ~(Xv | Ph);
-                    Mv = Ph & Xv;
-                    best = score < best ? score : best;
-                }
-                if (best <= kb[b]) {
-                    __hip_atomic_fetch_or(&cnd[r * cw + (b >> 5)], 1u << (b & 31), __ATOMIC_RELAXED,
+                w.c = codes + roff[r] + (jf - 1);
+                w.ncol = jl - jf + 1;
+                w.pq = (const LDS unsigned char *)(peq + b);
+            };
+            auto step = [&](Sweep &w, int j) {
+                const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
+                const uint32_t Xv = Eq | w.Mv;
+                const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
+                uint32_t Ph = w.Mv | ~(Xh | w.Pv);
+                uint32_t Mh = w.Pv & Xh;
+                w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
+                Ph <<= 1;
+                Mh <<= 1;
+                w.Pv = Mh | ~(Xv | Ph);
+                w.Mv = Ph & Xv;
+                w.best = w.score < w.best ? w.score : w.best;
+            };
+            auto finish = [&](const Sweep &w) {
+                if (w.ncol > 0 && w.best <= kb[w.b]) {
+                    __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (full[p * R + r]) {
-                        const int k = __hip_atomic_fetch_add(&scnt[p * R + r], 1, __ATOMIC_RELAXED,
+                    if (full[p * R + w.r]) {
+                        const int k = __hip_atomic_fetch_add(&scnt[p * R + w.r], 1, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (k < 4) slots[(p * R + r) * 4 + k] = ((uint32_t)b << 8) | (uint32_t)best;
+                        if (k < 4) slots[(p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
                     }
                 }
+            };
+            for (int pair = tid; pair < ((a.dbg & 2) ? 0 : total); pair += 2 * BS) {
+                Sweep A, Bw;
+                setup(pair, A);
+                setup(pair + BS, Bw);
+                const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
+                int j = 0;
+#pragma unroll 4
+                for (; j < common; ++j) {
+                    step(A, j);
+                    step(Bw, j);
+                }
+                for (int ja = j; ja < A.ncol; ++ja) step(A, ja);
+                for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb);
+                finish(A);
+                finish(Bw);
             }
         }
         __syncthreads();
