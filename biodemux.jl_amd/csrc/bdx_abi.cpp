@@ -45,6 +45,8 @@ struct bdx_ctx {
     BdxDevCfg dev{};
     BdxGenericPlan plan{};
     BdxBitparPlan bplan{};
+    BdxSeedPlan splan{};
+    DevBuf seed_tables;
     DevBuf bp_tables;
     DevBuf d_maxlen;
     int user_len_hint = 0;  // 0 = measure every device batch
@@ -243,6 +245,111 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     return BDX_OK;
 }
 
+
+// ---- q-gram seeding (pigeonhole) in front of the sweep -------------------------------------
+// A recordable alignment of barcode b has at most kb[b] edit operations (see the sweep), so of
+// kb[b]+1 disjoint pieces of the barcode at least one occurs in the read unchanged; a fortiori
+// the first q bases of that piece do.  Pairs without any such seed hit cannot be candidates and
+// are not swept.  Keys use 2 bits per base (symbol code & 3): equal bytes give equal keys, other
+// bytes may alias — that only adds sweeps, never removes one.
+int build_seed_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxSeedPlan &sp = ctx->splan;
+    sp = BdxSeedPlan{};
+    if (!ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || getenv("BDX_NO_SEED")) return BDX_OK;
+    const int npass = c.is_dual ? 2 : 1;
+    int cmin = 1;
+    if (c.algorithm == BDX_ALG_SEMIGLOBAL) {
+        cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
+        if (c.has_nindel && c.nindel < cmin) cmin = c.nindel;
+    }
+    const bool n_wild = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) || c.algorithm == BDX_ALG_HAMMING;
+    // same symbol coding as the sweep
+    int code_of[256];
+    for (int i = 0; i < 256; ++i) code_of[i] = -1;
+    int K = 0;
+    for (int k = 0; k < npass; ++k)
+        for (uint32_t i = 0; i < c.pass[k].bc_off[c.pass[k].n_barcodes]; ++i) {
+            const uint8_t ch = c.pass[k].bc_bytes[i];
+            if (code_of[ch] < 0) code_of[ch] = K++;
+        }
+    struct Piece { int pass, b, start; };
+    std::vector<Piece> pieces;
+    std::vector<uint16_t> always[2];
+    int q = 8;
+    int total_bc = 0;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        if (p.n_barcodes > 32767) return BDX_OK;
+        total_bc += p.n_barcodes;
+        for (int b = 0; b < p.n_barcodes; ++b) {
+            const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+            long long ae;
+            if (c.algorithm == BDX_ALG_EXACT) ae = 0;
+            else if (c.algorithm == BDX_ALG_HAMMING) ae = (long long)std::floor(c.max_error_rate * (double)m);
+            else ae = (long long)std::floor(c.max_error_rate * (double)(c.has_nindel ? p.bc_len_no_N[b] : m));
+            if (ae < 0) continue;  // can never be recorded: neither seeded nor swept
+            const long long kb = ae / cmin;
+            bool wild = false;
+            for (int i = 0; i < m; ++i) wild |= n_wild && p.bc_bytes[p.bc_off[b] + i] == 'N';
+            const long long L = m / (kb + 1);
+            if (wild || L < 5) {
+                always[k].push_back((uint16_t)b);
+                continue;
+            }
+            if (L < q) q = (int)L;
+            for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{k, b, (int)(t * L)});
+        }
+    }
+    if (pieces.empty()) return BDX_OK;
+    if ((int)(always[0].size() + always[1].size()) * 4 > total_bc) return BDX_OK;  // seeding would not pay
+    if (pieces.size() > 8192) return BDX_OK;
+    // selectivity: expected seed-hit pairs per read of ~150 bases must be well below B
+    const double space = std::pow(4.0, q);
+    const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
+    if (expected * 3.0 > (double)total_bc) return BDX_OK;
+    sp.q = q;
+    sp.bm_words = (int)(space / 32.0);
+    if (sp.bm_words < 1) sp.bm_words = 1;
+    sp.hash_log2 = 8;
+    while ((1u << sp.hash_log2) < pieces.size() * 4) sp.hash_log2++;
+    std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
+    const uint32_t hmask = (1u << sp.hash_log2) - 1;
+    for (const Piece &pc : pieces) {
+        const bdx_pass_t &p = c.pass[pc.pass];
+        uint32_t key = 0;
+        for (int i = 0; i < q; ++i) key |= (uint32_t)(code_of[p.bc_bytes[p.bc_off[pc.b] + pc.start + i]] & 3) << (2 * i);
+        bitmap[key >> 5] |= 1u << (key & 31);
+        const uint32_t entry = (key << 16) | ((uint32_t)pc.pass << 15) | (uint32_t)(pc.b + 1);
+        uint32_t slot = (key * 0x9E3779B1u) >> (32 - sp.hash_log2);
+        bool dup = false;
+        while (hash[slot] != 0) {
+            if (hash[slot] == entry) { dup = true; break; }
+            slot = (slot + 1) & hmask;
+        }
+        if (!dup) hash[slot] = entry;
+    }
+    size_t bytes = bitmap.size() * 4 + hash.size() * 4;
+    const size_t o_always[2] = {bytes, bytes + ((always[0].size() * 2 + 15) & ~(size_t)15)};
+    bytes = o_always[1] + ((always[1].size() * 2 + 15) & ~(size_t)15) + 16;
+    std::vector<uint8_t> blob(bytes, 0);
+    memcpy(blob.data(), bitmap.data(), bitmap.size() * 4);
+    memcpy(blob.data() + bitmap.size() * 4, hash.data(), hash.size() * 4);
+    for (int k = 0; k < 2; ++k)
+        if (!always[k].empty()) memcpy(blob.data() + o_always[k], always[k].data(), always[k].size() * 2);
+    HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
+    sp.d_bitmap = (const uint32_t *)base;
+    sp.d_hash = (const uint32_t *)(base + bitmap.size() * 4);
+    for (int k = 0; k < 2; ++k) {
+        sp.n_always[k] = (int)always[k].size();
+        sp.d_always[k] = (const uint16_t *)(base + o_always[k]);
+    }
+    sp.enabled = 1;
+    return BDX_OK;
+}
+
 // Geometry of the fused kernel for a given typical read length: the largest R whose LDS
 // footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
 bool size_bitpar(bdx_ctx *ctx, int read_len) {
@@ -264,7 +371,8 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         if (st > (size_t)1 << 20) continue;
         bp.reads_per_block = R;
         bp.stage_bytes = (int)st;
-        const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan);
+        bp.read_len_hint_for_lds = read_len;
+        const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->splan);
         if (lds > LDS_MAX) continue;
         int blocks = (int)(LDS_MAX / lds);
         if (blocks > 8) blocks = 8;
@@ -279,6 +387,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         bp.reads_per_block = best_R;
         bp.stage_bytes = best_stage;
         bp.read_len_hint = read_len;
+        bp.read_len_hint_for_lds = read_len;
         return true;
     }
     bp.reads_per_block = 0;
@@ -446,8 +555,10 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = build_bitpar_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
-    ctx->path = ctx->bplan.enabled ? "bitpar+verify" : "generic";
-    ctx->filter_used = ctx->bplan.enabled ? BDX_FILTER_BITPAR : BDX_FILTER_OFF;
+    rc = build_seed_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
+    ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify") : "generic";
+    ctx->filter_used = ctx->bplan.enabled ? (ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
     if (ctx->bplan.enabled) {
         if (ctx->d_maxlen.ensure(256) != hipSuccess) {
             ctx->err = "hipMalloc failed";
@@ -483,6 +594,7 @@ void bdx_destroy(bdx_ctx *ctx) {
     }
     ctx->counts_own.release();
     ctx->bp_tables.release();
+    ctx->seed_tables.release();
     ctx->d_maxlen.release();
     ctx->d_seq.release();
     ctx->d_off.release();
@@ -540,11 +652,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         filtered = size_bitpar(ctx, len);
     }
     if (filtered) {
-        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, d_seq_bytes, (const long long *)d_seq_off,
+        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes, (const long long *)d_seq_off,
                                        n_reads, o, ctx->counts, ctx->stream));
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
-        ctx->path = "bitpar+verify";
-        ctx->filter_used = BDX_FILTER_BITPAR;
+        ctx->path = ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify";
+        ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                         ctx->counts, nullptr, nullptr, ctx->stream));
@@ -639,9 +751,9 @@ const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str()
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;
-    const bool f = ctx->filter_used == BDX_FILTER_BITPAR && ctx->bplan.reads_per_block > 0;
+    const bool f = ctx->filter_used != BDX_FILTER_OFF && ctx->bplan.reads_per_block > 0;
     out->threads_per_block = f ? 256 : ctx->plan.threads;
-    out->lds_bytes_per_block = f ? (int32_t)bdx_bitpar_lds_bytes(ctx->dev, ctx->bplan, ctx->plan) : (int32_t)ctx->plan.lds_bytes;
+    out->lds_bytes_per_block = f ? (int32_t)bdx_bitpar_lds_bytes(ctx->dev, ctx->bplan, ctx->plan, &ctx->splan) : (int32_t)ctx->plan.lds_bytes;
     out->blocks = ctx->last_blocks;
     out->reads_per_block = f ? ctx->bplan.reads_per_block : ctx->plan.threads;
     out->filter_used = ctx->filter_used;

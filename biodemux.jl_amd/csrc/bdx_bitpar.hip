@@ -48,12 +48,19 @@ struct BitparArgs {
     int ncodes;
     int bpad[2];
     int bshift[2];
+    // q-gram seeding (SEED variant only)
+    int seed_q, seed_groups, seed_hash_log2, seed_bm_words;
+    int seed_n_always[2];
+    const uint32_t *seed_bitmap;
+    const uint32_t *seed_hash;
+    const uint16_t *seed_always[2];
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
 };
 
-template <int BS, int R>
+template <int BS, int R, bool SEED>
 __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
+    constexpr int SQCAP = 8 * R;  // capacity of the seed-hit and pair queues
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -92,7 +99,16 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *scnt = (LDS int *)take((size_t)2 * R * 4);                 // [pass][R] entries pushed
     LDS unsigned char *full = take((size_t)2 * R);                      // [pass][R] read is in the known-score class
     LDS unsigned char *rstage = take((size_t)a.stage_bytes);
-    LDS unsigned char *codes = take((size_t)a.stage_bytes);
+    LDS unsigned char *codes = take((size_t)a.stage_bytes + 16);
+    // seeding work areas (SEED variant only)
+    LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
+    LDS uint32_t *shash = (LDS uint32_t *)take(SEED ? ((size_t)4 << a.seed_hash_log2) : 0);
+    LDS unsigned char *spk = take(SEED ? (size_t)R * (a.seed_groups + 4) : 0);
+    LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
+    LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
+    LDS uint32_t *seedm = (LDS uint32_t *)take(SEED ? (size_t)R * (cw0 + cw1) * 4 : 0);
+    LDS int *sqn = (LDS int *)take(SEED ? 16 : 0);
+    LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
     // ---- tables -> LDS ----
     for (int i = tid; i <= B0; i += BS) off0[i] = cfg.pass[0].bc_off[i];
@@ -115,6 +131,13 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
     for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
     for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
+    if (SEED) {
+        for (int i = tid; i < a.seed_bm_words; i += BS) sbm[i] = a.seed_bitmap[i];
+        for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) shash[i] = a.seed_hash[i];
+        for (int i = tid; i < R * (cw0 + cw1); i += BS) seedm[i] = 0;
+        for (int i = tid; i < R; i += BS) sall[i] = 0;
+        if (tid < 4) sqn[tid] = 0;
+    }
     __syncthreads();
     const int bytes0 = (int)off0[B0];
     const int bytes1 = cfg.is_dual ? (int)off1[B1] : 0;
@@ -171,97 +194,222 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         __syncthreads();
 
         // ---- stage 1: Myers bit-vector sweep, one lane per (read, barcode) pair ----
+        // Two independent pairs per lane per trip: the recurrence is a serial chain of ~14
+        // dependent VALU ops per column, a second chain fills the issue slots the first leaves.
         const bool sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
-        for (int p = 0; p < npass; ++p) {
-            const int B = p ? B1 : B0;
-            const int cw = p ? cw1 : cw0;
-            const LDS uint32_t *peq = p ? peq1 : peq0;
-            const LDS uint32_t *pv = p ? pv1 : pv0;
-            const LDS int *kb = p ? kb1 : kb0;
-            const int sh = a.bshift[p];  // log2(bytes per code row of peq)
-            LDS uint32_t *cnd = cand + (p ? R * cw0 : 0);
-            const LDS int *wf = win + (p * 2 + 0) * R;
-            const LDS int *wl = win + (p * 2 + 1) * R;
-            const int total = nr * B;
-            // Two independent pairs per lane per trip (pair, pair + BS): the recurrence is a serial
-            // chain of ~14 dependent VALU ops per column, so a second chain fills the issue slots
-            // the first one leaves while waiting (the sweep is latency-bound at 2-4 waves/SIMD).
-            struct Sweep {
-                const LDS unsigned char *c;
-                const LDS unsigned char *pq;
-                uint32_t Pv, Mv;
-                int score, best, ncol, r, b;
-            };
-            auto setup = [&](int pair, Sweep &w) {
-                w.ncol = 0;
-                w.r = 0;
-                w.b = 0;
-                w.c = codes;
-                w.pq = (const LDS unsigned char *)peq;
-                w.Pv = 0;
-                w.Mv = 0;
-                w.score = 0;
-                w.best = 0x7FFFFFFF;
-                if (pair >= total) return;
-                const int r = pair / B;
-                const int b = pair - r * B;
-                const int jf = wf[r];
-                int jl = wl[r];
-                if (jl < jf) return;
-                w.r = r;
-                w.b = b;
-                w.Pv = pv[b];
-                w.score = __builtin_popcount(w.Pv);  // = barcode length m
-                w.best = w.score;
-                if (!sg) {
-                    // :hamming / :exact bound the START positions by the window (SURVEY Q11,
-                    // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
-                    const int nread = roff[r + 1] - roff[r];
-                    jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
+        struct Sweep {
+            const LDS unsigned char *c;
+            const LDS unsigned char *pq;
+            uint32_t Pv, Mv;
+            int score, best, ncol, r, b, p;
+        };
+        auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w) {
+            w.ncol = 0;
+            w.r = 0;
+            w.b = 0;
+            w.p = p;
+            w.c = codes;
+            w.pq = (const LDS unsigned char *)peq0;
+            w.Pv = 0;
+            w.Mv = 0;
+            w.score = 0;
+            w.best = 0x7FFFFFFF;
+            if (!valid) return;
+            const int jf = win[(p * 2 + 0) * R + r];
+            int jl = win[(p * 2 + 1) * R + r];
+            if (jl < jf) return;
+            w.r = r;
+            w.b = b;
+            w.Pv = (p ? pv1 : pv0)[b];
+            w.score = __builtin_popcount(w.Pv);  // = barcode length m
+            w.best = w.score;
+            if (!sg) {
+                // :hamming / :exact bound the START positions by the window (SURVEY Q11,
+                // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
+                const int nread = roff[r + 1] - roff[r];
+                jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
+            }
+            w.c = codes + roff[r] + (jf - 1);
+            w.ncol = jl - jf + 1;
+            w.pq = (const LDS unsigned char *)((p ? peq1 : peq0) + b);
+        };
+        auto step = [&](Sweep &w, const int j, const int sh) {
+            const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
+            const uint32_t Xv = Eq | w.Mv;
+            const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
+            uint32_t Ph = w.Mv | ~(Xh | w.Pv);
+            uint32_t Mh = w.Pv & Xh;
+            w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
+            Ph += Ph;  // << 1 as an add: full-rate on gfx950, shifts are not
+            Mh += Mh;
+            w.Pv = Mh | ~(Xv | Ph);
+            w.Mv = Ph & Xv;
+            w.best = w.score < w.best ? w.score : w.best;
+        };
+        auto finish = [&](const Sweep &w) {
+            if (w.ncol > 0 && w.best <= (w.p ? kb1 : kb0)[w.b]) {
+                const int cw = w.p ? cw1 : cw0;
+                LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
+                __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (full[w.p * R + w.r]) {
+                    const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (k < 4) slots[(w.p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
                 }
-                w.c = codes + roff[r] + (jf - 1);
-                w.ncol = jl - jf + 1;
-                w.pq = (const LDS unsigned char *)(peq + b);
-            };
-            auto step = [&](Sweep &w, int j) {
-                const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
-                const uint32_t Xv = Eq | w.Mv;
-                const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
-                uint32_t Ph = w.Mv | ~(Xh | w.Pv);
-                uint32_t Mh = w.Pv & Xh;
-                w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
-                Ph <<= 1;
-                Mh <<= 1;
-                w.Pv = Mh | ~(Xv | Ph);
-                w.Mv = Ph & Xv;
-                w.best = w.score < w.best ? w.score : w.best;
-            };
-            auto finish = [&](const Sweep &w) {
-                if (w.ncol > 0 && w.best <= kb[w.b]) {
-                    __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (full[p * R + w.r]) {
-                        const int k = __hip_atomic_fetch_add(&scnt[p * R + w.r], 1, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (k < 4) slots[(p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
+            }
+        };
+        auto sweep2 = [&](Sweep &A, Sweep &Bw) {
+            // both chains use the same symbol shift only when they belong to the same pass;
+            // the shifts are per chain (uniform in the non-seeded path, per lane otherwise)
+            const int shA = a.bshift[A.p], shB = a.bshift[Bw.p];
+            const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
+            int j = 0;
+#pragma unroll 4
+            for (; j < common; ++j) {
+                step(A, j, shA);
+                step(Bw, j, shB);
+            }
+            for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
+            for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
+            finish(A);
+            finish(Bw);
+        };
+
+        if (!SEED) {
+            for (int p = 0; p < npass; ++p) {
+                const int B = p ? B1 : B0;
+                const int total = (a.dbg & 2) ? 0 : nr * B;
+                for (int pair = tid; pair < total; pair += 2 * BS) {
+                    Sweep A, Bw;
+                    const int pb = pair + BS;
+                    const int rA = pair / B, rB = pb / B;
+                    setup(true, p, rA, pair - rA * B, A);
+                    setup(pb < total, p, rB, pb - rB * B, Bw);
+                    sweep2(A, Bw);
+                }
+            }
+        } else {
+            // ---- stage 0: q-gram seeds (pigeonhole) decide which pairs are swept at all ----
+            const int q = a.seed_q;
+            const uint32_t kmask = (q >= 16) ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u);
+            const int G = a.seed_groups;  // 4-base groups per read (uniform upper bound)
+            // 2-bit packing of every read, 4 bases per byte, aligned to the read start
+            for (int idx = tid; idx < nr * G; idx += BS) {
+                const int r = idx / G, g = idx - r * G;
+                const LDS unsigned char *c = codes + roff[r] + 4 * g;
+                const uint32_t pk = (uint32_t)(c[0] & 3) | ((uint32_t)(c[1] & 3) << 2) | ((uint32_t)(c[2] & 3) << 4) |
+                                    ((uint32_t)(c[3] & 3) << 6);
+                spk[r * (G + 4) + g] = (unsigned char)pk;
+                // a read longer than the planned group count would leave its tail unscanned:
+                // sweep every barcode of it instead (lossless fallback)
+                if (g == 0 && roff[r + 1] - roff[r] > 4 * (G - 1)) sall[r] = 1;
+            }
+            for (int idx = tid; idx < nr * 4; idx += BS) spk[(idx >> 2) * (G + 4) + G + (idx & 3)] = 0;
+            __syncthreads();
+            // scan: lane = (read, group of 4 start positions); key = 2q bits starting at the position
+            for (int idx = tid; idx < nr * G; idx += BS) {
+                const int r = idx / G, g = idx - r * G;
+                const int nread = roff[r + 1] - roff[r];
+                int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
+                if (npass == 1) {
+                    lo = win[0 * R + r] - 1;
+                    hi = (sg ? win[1 * R + r] : nread) - q;
+                    if (win[1 * R + r] < win[0 * R + r]) hi = -1;
+                } else {
+                    lo = 0;
+                    hi = nread - q;
+                }
+                if (4 * g + 3 < lo || 4 * g > hi) continue;
+                const LDS unsigned char *pk = spk + r * (G + 4) + g;
+                const uint32_t w = (uint32_t)pk[0] | ((uint32_t)pk[1] << 8) | ((uint32_t)pk[2] << 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pos = 4 * g + i;
+                    const uint32_t key = (w >> (2 * i)) & kmask;
+                    if (pos >= lo && pos <= hi && ((sbm[key >> 5] >> (key & 31)) & 1u)) {
+                        const int k = __hip_atomic_fetch_add(&sqn[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k < SQCAP)
+                            shq[k] = ((uint32_t)r << 16) | key;
+                        else
+                            sall[r] = 1;  // hit queue full: sweep every barcode of this read instead
                     }
                 }
-            };
-            for (int pair = tid; pair < ((a.dbg & 2) ? 0 : total); pair += 2 * BS) {
-                Sweep A, Bw;
-                setup(pair, A);
-                setup(pair + BS, Bw);
-                const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
-                int j = 0;
-#pragma unroll 4
-                for (; j < common; ++j) {
-                    step(A, j);
-                    step(Bw, j);
+            }
+            __syncthreads();
+            // resolve hits through the hash table -> de-duplicated (read, pass, barcode) pair queue
+            {
+                const int nh = sqn[0] < SQCAP ? sqn[0] : SQCAP;
+                const uint32_t hmask = (1u << a.seed_hash_log2) - 1u;
+                for (int k = tid; k < nh; k += BS) {
+                    const uint32_t h = shq[k];
+                    const int r = (int)(h >> 16);
+                    const uint32_t key = h & 0xFFFFu;
+                    uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.seed_hash_log2);
+                    for (;;) {
+                        const uint32_t e = shash[slot];
+                        if (e == 0u) break;
+                        if ((e >> 16) == key) {
+                            const int p = (int)((e >> 15) & 1u);
+                            const int b = (int)(e & 0x7FFFu) - 1;
+                            LDS uint32_t *sm = seedm + (p ? R * cw0 : 0) + r * (p ? cw1 : cw0) + (b >> 5);
+                            const uint32_t old = __hip_atomic_fetch_or(sm, 1u << (b & 31), __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (!((old >> (b & 31)) & 1u)) {
+                                const int kk = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (kk < SQCAP)
+                                    spq[kk] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)b;
+                                else
+                                    sall[r] = 1;
+                            }
+                        }
+                        slot = (slot + 1) & hmask;
+                    }
                 }
-                for (int ja = j; ja < A.ncol; ++ja) step(A, ja);
-                for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb);
-                finish(A);
-                finish(Bw);
+                // barcodes that are swept unconditionally (wildcards, pieces shorter than 5)
+                for (int p = 0; p < npass; ++p) {
+                    const int na = a.seed_n_always[p];
+                    for (int idx = tid; idx < nr * na; idx += BS) {
+                        const int r = idx / na;
+                        const int b = a.seed_always[p][idx - r * na];
+                        const int kk = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (kk < SQCAP)
+                            spq[kk] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)b;
+                        else
+                            sall[r] = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                const int np = (a.dbg & 2) ? 0 : (sqn[1] < SQCAP ? sqn[1] : SQCAP);
+                for (int k = tid; k < np; k += 2 * BS) {
+                    Sweep A, Bw;
+                    const uint32_t ea = spq[k];
+                    const bool hb = k + BS < np;
+                    const uint32_t eb = hb ? spq[k + BS] : 0u;
+                    const int ra = (int)(ea >> 16), rb = (int)(eb >> 16);
+                    setup(!sall[ra], (int)((ea >> 15) & 1u), ra, (int)(ea & 0x7FFFu), A);
+                    setup(hb && !sall[rb], (int)((eb >> 15) & 1u), rb, (int)(eb & 0x7FFFu), Bw);
+                    sweep2(A, Bw);
+                }
+                // reads whose queues overflowed: every barcode, exactly once
+                for (int p = 0; p < npass; ++p) {
+                    const int B = p ? B1 : B0;
+                    const int total = (a.dbg & 2) ? 0 : nr * B;
+                    for (int pair = tid; pair < total; pair += 2 * BS) {
+                        Sweep A, Bw;
+                        const int pb = pair + BS;
+                        const int rA = pair / B, rB = pb / B;
+                        const bool va = sall[rA] != 0;
+                        const bool vb = pb < total && sall[rB < nr ? rB : 0] != 0;
+                        if (!__builtin_amdgcn_ballot_w64(va || vb)) continue;
+                        setup(va, p, rA, pair - rA * B, A);
+                        setup(vb, p, rB, pb - rB * B, Bw);
+                        sweep2(A, Bw);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -352,24 +500,25 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 }
 
-template <int BS, int R>
+template <int BS, int R, bool SEED>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R>,
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long long blocks = (n_reads + R - 1) / R;
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
+    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp) {
+size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp,
+                            const BdxSeedPlan *sp) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const int R = bp.reads_per_block;
     const int B0 = cfg.pass[0].n_barcodes, B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -383,12 +532,17 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
-    o += 2 * al((size_t)bp.stage_bytes);
+    o += al((size_t)bp.stage_bytes) + al((size_t)bp.stage_bytes + 16);
+    if (sp && sp->enabled) {
+        const int G = (bp.read_len_hint_for_lds + 3) / 4 + 1;
+        o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
+        o += 2 * al((size_t)8 * R * 4) + al((size_t)R * (cw0 + cw1) * 4) + al(16) + al((size_t)R);
+    }
     return o;
 }
 
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
-                             const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
+                             const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, hipStream_t stream) {
     if (n_reads <= 0) return hipSuccess;
     BitparArgs a;
@@ -416,19 +570,32 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.known_ok[0] = bp.known_ok[0];
     a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
-    const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp);
+    a.seed_q = sp.q;
+    a.seed_groups = (bp.read_len_hint_for_lds + 3) / 4 + 1;
+    a.seed_hash_log2 = sp.hash_log2;
+    a.seed_bm_words = sp.bm_words;
+    a.seed_bitmap = sp.d_bitmap;
+    a.seed_hash = sp.d_hash;
+    for (int k = 0; k < 2; ++k) {
+        a.seed_n_always[k] = sp.n_always[k];
+        a.seed_always[k] = sp.d_always[k];
+    }
+    const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp, &sp);
+    const bool seed = sp.enabled != 0;
+#define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream) : launch_one<256, RR, false>(a, lds, n_reads, stream)
     switch (bp.reads_per_block) {
         case 256:
-            return launch_one<256, 256>(a, lds, n_reads, stream);
+            BDX_LAUNCH_R(256);
         case 128:
-            return launch_one<256, 128>(a, lds, n_reads, stream);
+            BDX_LAUNCH_R(128);
         case 64:
-            return launch_one<256, 64>(a, lds, n_reads, stream);
+            BDX_LAUNCH_R(64);
         case 32:
-            return launch_one<256, 32>(a, lds, n_reads, stream);
+            BDX_LAUNCH_R(32);
         case 16:
-            return launch_one<256, 16>(a, lds, n_reads, stream);
+            BDX_LAUNCH_R(16);
         default:
             return hipErrorInvalidValue;
     }
+#undef BDX_LAUNCH_R
 }

@@ -74,6 +74,7 @@ struct BdxBitparPlan {
     int reads_per_block;   // R: 256 / 128 / 64 / 32 / 16
     int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
     int read_len_hint;     // the read length the geometry was planned for
+    int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
@@ -83,10 +84,23 @@ struct BdxBitparPlan {
     const int32_t *d_kb[2];        // device, [B]: max unit edit operations of a recordable alignment
 };
 
+// q-gram seeding in front of the sweep (pigeonhole): tables built in bdx_abi.cpp.
+struct BdxSeedPlan {
+    int enabled;
+    int q;                 // seed length in bases (5..8); key = 2 bits per base
+    int bm_words;          // bitmap words = 4^q / 32
+    int hash_log2;         // hash slots = 1 << hash_log2; entry = key << 16 | pass << 15 | (barcode + 1)
+    int n_always[2];       // barcodes swept unconditionally (wildcards / too-short pieces)
+    const uint32_t *d_bitmap;
+    const uint32_t *d_hash;
+    const uint16_t *d_always[2];
+};
+
 // Implemented in bdx_bitpar.hip.
-size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp);
+size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp,
+                            const BdxSeedPlan *sp = nullptr);
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
-                             const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
+                             const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, hipStream_t stream);
 // max read length of a device-resident batch (one tiny kernel; result written to *d_out)
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
