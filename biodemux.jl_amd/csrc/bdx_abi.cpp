@@ -312,7 +312,7 @@ int build_seed_tables(bdx_ctx *ctx) {
     sp.bm_words = (int)(space / 32.0);
     if (sp.bm_words < 1) sp.bm_words = 1;
     sp.hash_log2 = 8;
-    while ((1u << sp.hash_log2) < pieces.size() * 4) sp.hash_log2++;
+    while ((1u << sp.hash_log2) < pieces.size() * 2) sp.hash_log2++;
     std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
     const uint32_t hmask = (1u << sp.hash_log2) - 1;
     for (const Piece &pc : pieces) {
@@ -375,7 +375,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->splan);
         if (lds > LDS_MAX) continue;
         int blocks = (int)(LDS_MAX / lds);
-        if (blocks > 8) blocks = 8;
+        if (blocks > 4) blocks = 4;  // 16 waves/CU already hide the latency; beyond that prefer larger tiles
         if (R == 16 && best_R) continue;
         if (blocks > best_blocks) {
             best_blocks = blocks;
@@ -652,6 +652,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         filtered = size_bitpar(ctx, len);
     }
     if (filtered) {
+        ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->bplan.d_tile_counter, 0, sizeof(int), ctx->stream));
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes, (const long long *)d_seq_off,
                                        n_reads, o, ctx->counts, ctx->stream));
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;

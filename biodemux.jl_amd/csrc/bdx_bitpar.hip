@@ -54,6 +54,7 @@ struct BitparArgs {
     const uint32_t *seed_bitmap;
     const uint32_t *seed_hash;
     const uint16_t *seed_always[2];
+    int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
 };
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
     LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
     LDS uint32_t *seedm = (LDS uint32_t *)take(SEED ? (size_t)R * (cw0 + cw1) * 4 : 0);
-    LDS int *sqn = (LDS int *)take(SEED ? 16 : 0);
+    LDS int *sqn = (LDS int *)take(16);  // [0] hits, [1] pairs, [2] current tile
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
     // ---- tables -> LDS ----
@@ -129,14 +130,9 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     }
     for (int i = tid; i < 256; i += BS) lut[i] = a.lut[i];
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
-    for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
-    for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
     if (SEED) {
         for (int i = tid; i < a.seed_bm_words; i += BS) sbm[i] = a.seed_bitmap[i];
         for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) shash[i] = a.seed_hash[i];
-        for (int i = tid; i < R * (cw0 + cw1); i += BS) seedm[i] = 0;
-        for (int i = tid; i < R; i += BS) sall[i] = 0;
-        if (tid < 4) sqn[tid] = 0;
     }
     __syncthreads();
     const int bytes0 = (int)off0[B0];
@@ -144,8 +140,25 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < bytes0; i += BS) bcs[i] = cfg.pass[0].bc_bytes[i];
     for (int i = tid; i < bytes1; i += BS) bcs[bytes0 + i] = cfg.pass[1].bc_bytes[i];
 
-    // ---- this workgroup's reads [r0, r1): one contiguous span of the packed batch ----
-    const long long r0 = (long long)blockIdx.x * R;
+    // ---- persistent workgroup: the tables above are loaded once, then the workgroup walks
+    // tiles of R consecutive reads (tile = blockIdx.x, + gridDim.x, ...).  Tiles are independent;
+    // nothing is exchanged between workgroups, so no placement or ordering is assumed. ----
+    const long long ntiles = (a.n_reads + R - 1) / R;
+    for (;;) {
+    __syncthreads();  // the previous tile's stage 2 is done with the per-tile LDS state
+    if (tid == 0) sqn[2] = atomicAdd(a.tile_counter, 1);  // dynamic tile queue (exit: queue drained)
+    __syncthreads();
+    const long long tile = sqn[2];
+    if (tile >= ntiles) break;
+    for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
+    for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
+    if (SEED) {
+        for (int i = tid; i < R * (cw0 + cw1); i += BS) seedm[i] = 0;
+        for (int i = tid; i < R; i += BS) sall[i] = 0;
+        if (tid < 2) sqn[tid] = 0;
+    }
+    // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
+    const long long r0 = tile * R;
     long long r1 = r0 + R;
     if (r1 > a.n_reads) r1 = a.n_reads;
     const int nr = (int)(r1 - r0);
@@ -474,28 +487,28 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         }
     }
 
-    // ---- DemuxStats scalar counters ----
-    if (a.counts) {
+    // ---- DemuxStats scalar counters (accumulated in LDS across this workgroup's tiles) ----
+    if (a.counts && active) {
         int slot = -1;
-        if (active) {
-            if (v.bc1 > 0) slot = 4 + (v.bc1 - 1) * cfg.counts_stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
-            const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
-            if (a.hist_entries > 0) {
-                __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (slot >= 0) __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                atomicAdd(&a.counts[0], 1ULL);
-                atomicAdd(&a.counts[cls], 1ULL);
-                if (slot >= 0) atomicAdd(&a.counts[slot], 1ULL);
-            }
-        }
+        if (v.bc1 > 0) slot = 4 + (v.bc1 - 1) * cfg.counts_stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
+        const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
         if (a.hist_entries > 0) {
-            __syncthreads();
-            for (int i = tid; i < a.hist_entries; i += BS) {
-                const int h = hist[i];
-                if (h) atomicAdd(&a.counts[i], (unsigned long long)h);
-            }
+            __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot >= 0) __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            atomicAdd(&a.counts[0], 1ULL);
+            atomicAdd(&a.counts[cls], 1ULL);
+            if (slot >= 0) atomicAdd(&a.counts[slot], 1ULL);
+        }
+    }
+    }  // tile loop
+
+    if (a.counts && a.hist_entries > 0) {
+        __syncthreads();
+        for (int i = tid; i < a.hist_entries; i += BS) {
+            const int h = hist[i];
+            if (h) atomicAdd(&a.counts[i], (unsigned long long)h);
         }
     }
 }
@@ -509,8 +522,16 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const long long blocks = (n_reads + R - 1) / R;
-    if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    // persistent grid: enough workgroups to fill every CU at the LDS-limited residency,
+    // never more than there are tiles
+    const long long tiles = (n_reads + R - 1) / R;
+    long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    long long blocks = 256 * per_cu;  // exactly the resident set; the tile queue balances it
+    if (const char *e = getenv("BDX_GRID")) blocks = atoll(e);
+    if (blocks > tiles) blocks = tiles;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
@@ -536,8 +557,9 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     if (sp && sp->enabled) {
         const int G = (bp.read_len_hint_for_lds + 3) / 4 + 1;
         o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
-        o += 2 * al((size_t)8 * R * 4) + al((size_t)R * (cw0 + cw1) * 4) + al(16) + al((size_t)R);
+        o += 2 * al((size_t)8 * R * 4) + al((size_t)R * (cw0 + cw1) * 4) + al((size_t)R);
     }
+    o += al(16);
     return o;
 }
 
@@ -567,6 +589,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     }
     a.ncodes = bp.ncodes;
     a.dbg = 0;
+    a.tile_counter = bp.d_tile_counter;
     a.known_ok[0] = bp.known_ok[0];
     a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);

@@ -78,6 +78,7 @@ struct BdxBitparPlan {
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
+    int *d_tile_counter;           // device int, zeroed before each launch
     const uint8_t *d_lut;          // device, 256 bytes
     const uint32_t *d_peq[2];      // device, [ncodes][bpad]
     const uint32_t *d_pvinit[2];   // device, [B]: top-aligned mask of the barcode's rows
