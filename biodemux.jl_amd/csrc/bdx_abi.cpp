@@ -654,8 +654,25 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     if (filtered) {
         ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);
         HIP_TRY(ctx, hipMemsetAsync(ctx->bplan.d_tile_counter, 0, sizeof(int), ctx->stream));
-        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes, (const long long *)d_seq_off,
-                                       n_reads, o, ctx->counts, ctx->stream));
+        // Configs whose passes all sit in the known-score class finish inside the fused kernel.
+        // Otherwise (trimming / summary / weighted costs / N-scoring / Hamming / exact) the fused
+        // kernel only filters and the exact DP runs at full width in the generic kernel.
+        const int npass = ctx->dev.is_dual ? 2 : 1;
+        bool split = false;
+        for (int k = 0; k < npass; ++k) split |= !ctx->bplan.known_ok[k];
+        if (getenv("BDX_NO_SPLIT")) split = false;
+        uint32_t *c0 = nullptr, *c1 = nullptr;
+        if (split) {
+            for (int k = 0; k < npass; ++k)
+                HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
+            c0 = (uint32_t *)ctx->d_cand[0].p;
+            c1 = npass > 1 ? (uint32_t *)ctx->d_cand[1].p : c0;
+        }
+        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes,
+                                       (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream));
+        if (split)
+            HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                            ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream));
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
         ctx->path = ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify";
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;

@@ -54,6 +54,7 @@ struct BitparArgs {
     const uint32_t *seed_bitmap;
     const uint32_t *seed_hash;
     const uint16_t *seed_always[2];
+    uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
@@ -428,6 +429,18 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         __syncthreads();
     }
 
+    if (a.cand_out[0]) {
+        // split mode: hand the candidate masks to the full-width exact kernel (bdx_generic_kernel,
+        // 256 reads per workgroup).  Tiles that could not be staged pass every barcode.
+        for (int p = 0; p < npass; ++p) {
+            const int cw = p ? cw1 : cw0;
+            const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0);
+            uint32_t *dst = a.cand_out[p] + r0 * cw;
+            for (int i = tid; i < nr * cw; i += BS) dst[i] = staged ? cnd[i] : 0xFFFFFFFFu;
+        }
+        continue;
+    }
+
     // ---- stage 2: exact evaluation, one lane per read ----
     const bool active = tid < nr;
     const long long ridx = r0 + tid;
@@ -565,7 +578,8 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
 
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
-                             unsigned long long *d_counts, hipStream_t stream) {
+                             unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1,
+                             hipStream_t stream) {
     if (n_reads <= 0) return hipSuccess;
     BitparArgs a;
     a.cfg = cfg;
@@ -589,6 +603,8 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     }
     a.ncodes = bp.ncodes;
     a.dbg = 0;
+    a.cand_out[0] = cand_out0;
+    a.cand_out[1] = cand_out1;
     a.tile_counter = bp.d_tile_counter;
     a.known_ok[0] = bp.known_ok[0];
     a.known_ok[1] = bp.known_ok[1];

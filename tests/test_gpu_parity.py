@@ -217,3 +217,69 @@ def test_c2_full_size_properties():
     soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
     exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
     assert np.array_equal(bc1[idx], exp["bc1"])
+
+
+# ---- seeded (q-gram) path: fallbacks must stay lossless ----
+def _all_filters_agree(cfg, seq, off, expect_path=None, hint=None):
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    paths = {}
+    for flt in ("off", "bitpar", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            if hint is not None:
+                hc.set_read_length_hint(hint)
+            got = hc.classify(seq, off)
+            paths[flt] = hc.kernel_path
+            fuzz.assert_same(got, exp, f"filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+    if expect_path:
+        assert paths["auto"] == expect_path, paths
+    return exp
+
+
+def test_seed_path_is_taken_for_c2():
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150)
+    _all_filters_agree(_c2_config(bcs), seq, off, expect_path="qgram+bitpar+verify")
+
+
+def test_seed_queue_overflow_low_complexity():
+    """Low-complexity barcodes and reads make almost every position a seed hit: the hit and pair
+    queues overflow and the affected reads must fall back to sweeping every barcode."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    bcs = ["A" * 24, "AC" * 12, "ACG" * 8, "AAAACCCCGGGGTTTTAAAACCCC", "ACGT" * 6, "T" * 24, "TTTTTTTTAAAAAAAAGGGGGGGG"]
+    bcs += synth.make_barcodes(25, 24, seed=11)
+    motifs = ["A", "AC", "ACG", "ACGT", "T", "TTTTAAAA", "AAAACCCCGGGGTTTT"]
+    reads = []
+    for i in range(6000):
+        mo = motifs[int(rng.integers(0, len(motifs)))]
+        s = list((mo * 200)[int(rng.integers(0, 8)):][:150])
+        for _ in range(int(rng.integers(0, 4))):  # a few point mutations
+            s[int(rng.integers(0, 150))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s))
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(), dict(min_delta=0.05), dict(trim_side=3)):
+        exp = _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path="qgram+bitpar+verify")
+    assert (exp["bc1"] != 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("hint", [40, 150, 400])
+def test_seed_ragged_reads_and_wrong_hint(hint):
+    """A read-length hint that is too small (tiles not staged / tails beyond the planned group
+    count) or too large must not change any result."""
+    bcs = synth.make_barcodes(48, 24, seed=21)
+    seq, off, _ = synth.make_ragged_reads(bcs, 20000, 0, 260, seed=21)
+    _all_filters_agree(_c2_config(bcs), seq, off, hint=hint)
+
+
+def test_seed_with_wildcard_and_short_barcodes():
+    """Barcodes with N under NScoring and barcodes too short for a seed are swept unconditionally."""
+    bcs = synth.make_barcodes(20, 24, seed=31)
+    bcs[3] = bcs[3][:5] + "NN" + bcs[3][7:]
+    bcs[7] = bcs[7][:10] + "N" + bcs[7][11:]
+    bcs += ["ACGTTGCA", "TTGACCAGT"]  # too short for pieces of >= 5 at k >= 1
+    nn = [sum(c != "N" for c in b) for b in bcs]
+    seq, off, _ = synth.make_reads([b.replace("N", "G") for b in bcs], 20000, 120, seed=31)
+    cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=nn, ids=[str(i) for i in range(len(bcs))],
+                            max_error_rate=0.13, nindel=1)
+    _all_filters_agree(cfg, seq, off)
