@@ -362,11 +362,54 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
     // Pick the R that keeps the most waves resident per CU (the sweep is latency-bound):
     // workgroups/CU = min(8, floor(160 KiB / LDS(R))) with 4 waves each; ties -> larger R
     // (fewer table reloads).  R = 16 is only taken when nothing larger fits.
+    // Column-window bound for this read length: the union over the passes of
+    // final_search_range (classification.jl:799-800), resolved exactly like the device does.
+    // Window lengths are non-decreasing in n, so the bound at the hint covers shorter reads.
+    int wmax = read_len;
+    {
+        long long ulo = (1LL << 40), uhi = 0;
+        const int npass = ctx->dev.is_dual ? 2 : 1;
+        for (int k = 0; k < npass; ++k) {
+            const BdxDevPass &P = ctx->dev.pass[k];
+            long long f, l;
+            if (P.explicit_window) {
+                f = P.win_first;
+                l = P.win_last;
+            } else {
+                auto res = [&](const BdxDevRange &dr, long long &a, long long &b) {
+                    long long s = dr.start_from_end ? read_len + dr.start_offset : dr.start_offset;
+                    long long e = dr.end_from_end ? read_len + dr.end_offset : dr.end_offset;
+                    a = s > 1 ? s : 1;
+                    b = e < read_len ? e : read_len;
+                    if (b < a) b = a - 1;
+                };
+                long long rf, rl, bf, bl, ef, el;
+                res(P.ref_search, rf, rl);
+                res(P.bc_start, bf, bl);
+                res(P.bc_end, ef, el);
+                f = rf > bf ? rf : bf;
+                l = rl < el ? rl : el;
+            }
+            if (f < 1) f = 1;
+            if (l > read_len) l = read_len;
+            if (l < f) continue;
+            long long h = ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL ? l : l + ctx->dev.max_m - 1;
+            if (h > read_len) h = read_len;
+            if (f - 1 < ulo) ulo = f - 1;
+            if (h > uhi) uhi = h;
+        }
+        if (uhi > ulo) wmax = (int)(uhi - ulo);
+        else wmax = 16;
+    }
+    const bool slot_mode = (long long)wmax * 2 + 96 <= (long long)read_len && !getenv("BDX_NO_SLOT");
+    const int slot = slot_mode ? ((wmax + 15 + 16 + 15) & ~15) : 0;
+    bp.slot_bytes = slot;
+    bp.seed_span = slot_mode ? wmax : read_len;
     const int tries[5] = {256, 128, 64, 32, 16};
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
         if (forced && R != forced) continue;
-        size_t st = (size_t)R * (size_t)read_len + 64;
+        size_t st = slot_mode ? (size_t)R * (size_t)slot : (size_t)R * (size_t)read_len + 64;
         st = (st + 15) & ~(size_t)15;
         if (st > (size_t)1 << 20) continue;
         bp.reads_per_block = R;

@@ -57,6 +57,7 @@ struct BitparArgs {
     uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
+    int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
 };
 
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *kb0 = (LDS int *)take((size_t)B0 * 4);
     LDS int *kb1 = (LDS int *)take((size_t)B1 * 4);
     LDS uint32_t *cand = (LDS uint32_t *)take((size_t)R * (cw0 + cw1) * 4);
-    LDS int *roff = (LDS int *)take((size_t)(R + 1) * 4);   // byte offset of each read in the stage
+    LDS int *roff = (LDS int *)take((size_t)(R + 1) * 4);   // stage offset of base 1 of each read (may precede its slot)
+    LDS int *rlen = (LDS int *)take((size_t)R * 4);         // read length n
+    LDS int *wlo = (LDS int *)take((size_t)R * 4);          // first staged base (0-based) of each read
+    LDS int *wlen = (LDS int *)take((size_t)R * 4);         // staged bases of each read
     LDS int *win = (LDS int *)take((size_t)R * 4 * 4);      // [pass][first|last][R]
     LDS uint32_t *slots = (LDS uint32_t *)take((size_t)2 * R * 4 * 4);  // [pass][R][4] (barcode << 8 | d)
     LDS int *scnt = (LDS int *)take((size_t)2 * R * 4);                 // [pass][R] entries pushed
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
     LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
     LDS uint32_t *seedm = (LDS uint32_t *)take(SEED ? (size_t)R * (cw0 + cw1) * 4 : 0);
-    LDS int *sqn = (LDS int *)take(16);  // [0] hits, [1] pairs, [2] current tile
+    LDS int *sqn = (LDS int *)take(16);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
     // ---- tables -> LDS ----
@@ -158,29 +162,39 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         for (int i = tid; i < R; i += BS) sall[i] = 0;
         if (tid < 2) sqn[tid] = 0;
     }
+    if (tid == 0) sqn[3] = 0;
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
     const long long r0 = tile * R;
     long long r1 = r0 + R;
     if (r1 > a.n_reads) r1 = a.n_reads;
     const int nr = (int)(r1 - r0);
+    // Two staging modes (chosen on the host from the config's ranges and the read-length hint):
+    //  * flat: the tile's reads are one contiguous span of the batch -> one coalesced copy;
+    //  * slot (a.slot_bytes > 0): only each read's column window is needed (e.g. 10 kbp reads
+    //    with ref_search_range "1:200"): every read gets a fixed-size slot holding just the
+    //    union of its pass windows, so HBM traffic and LDS follow the window, not the read.
+    const int slot = a.slot_bytes;
+    const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
     const long long span0 = a.off[r0];
     const long long span1 = a.off[r1];
     const uintptr_t g0 = (uintptr_t)(a.seq + span0);
     const uintptr_t g0a = g0 & ~(uintptr_t)15;
     const int head = (int)(g0 - g0a);
-    const long long need = (span1 - span0) + head;
-    const bool staged = need + 16 <= (long long)a.stage_bytes;  // wave-uniform (whole workgroup)
-    if (staged) {
+    const long long need = slot ? (long long)nr * slot : (span1 - span0) + head;
+    bool staged = slot ? true : (need + 16 <= (long long)a.stage_bytes);  // wave-uniform (whole workgroup)
+    if (!slot && staged) {
         const int nvec = (int)((need + 15) >> 4);
         const u32x4 *src = (const u32x4 *)g0a;
         LDS u32x4 *dst = (LDS u32x4 *)rstage;
         for (int k = tid; k < nvec; k += BS) dst[k] = __builtin_nontemporal_load(src + k);
     }
-    // per-read stage offsets and column windows of both passes
-    for (int t = tid; t <= nr; t += BS) roff[t] = head + (int)(a.off[r0 + t] - span0);
+    // per-read lengths, stage offsets and column windows of both passes
     for (int t = tid; t < nr; t += BS) {
-        const long long rn = a.off[r0 + t + 1] - a.off[r0 + t];
+        const long long ro = a.off[r0 + t];
+        const long long rn = a.off[r0 + t + 1] - ro;
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
+        rlen[t] = n;
+        int ulo = 0x7FFFFFFF, uhi = 0;
         for (int p = 0; p < npass; ++p) {
             PassWindow w;
             const bool ok = pass_window(cfg.pass[p], n, w);
@@ -188,13 +202,49 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             int l = ok ? (w.last < n ? w.last : n) : 0;
             win[(p * 2 + 0) * R + t] = f;
             win[(p * 2 + 1) * R + t] = l;
-            // known-score class, per read: every column 1..n is swept and neither the start nor
-            // the end range binds (band_offset = m-n-steps, min_valid_start <= 1, j >= min_end always)
-            full[p * R + t] = (unsigned char)(a.known_ok[p] && ok && n > 0 && w.first == 1 && w.last == n &&
-                                              w.max_start >= n && w.min_end <= 1);
+            if (l >= f) {
+                // :hamming / :exact occurrences reach max_m - 1 past the last start position
+                int h = sgm ? l : l + cfg.max_m - 1;
+                if (h > n) h = n;
+                ulo = f - 1 < ulo ? f - 1 : ulo;
+                uhi = h > uhi ? h : uhi;
+            }
+            // known-score class, per read: neither the start nor the end range binds (band_offset =
+            // m-n-steps, min_valid_start <= 1, j >= min_end always); any column window first:last
+            full[p * R + t] = (unsigned char)(a.known_ok[p] && ok && n > 0 && w.max_start >= n && w.min_end <= 1);
+        }
+        if (uhi <= ulo) {
+            ulo = 0;
+            uhi = 0;
+        }
+        if (slot) {
+            const int hd = (int)((uintptr_t)(a.seq + ro + ulo) & 15);
+            if (uhi - ulo + hd + 16 > slot) sqn[3] = 1;  // window larger than planned: tile not staged
+            roff[t] = t * slot + hd - ulo;
+            wlo[t] = ulo;
+            wlen[t] = uhi - ulo;
+        } else {
+            roff[t] = head + (int)(ro - span0);
+            wlo[t] = 0;
+            wlen[t] = n;
         }
     }
     __syncthreads();
+    if (slot) {
+        staged = sqn[3] == 0;
+        if (staged) {
+            const int cpr = slot >> 4;  // 16-byte chunks per slot
+            for (int idx = tid; idx < nr * cpr; idx += BS) {
+                const int r = idx / cpr, k = idx - r * cpr;
+                const int hd = roff[r] - r * slot + wlo[r];
+                if (16 * k < wlen[r] + hd) {
+                    const uintptr_t src = ((uintptr_t)(a.seq + a.off[r0 + r] + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
+                    *(LDS u32x4 *)(rstage + r * slot + 16 * k) = __builtin_nontemporal_load((const u32x4 *)src);
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     if (staged) {
         // ---- transcode bytes -> symbol codes (4 per lane per step) ----
@@ -240,7 +290,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             if (!sg) {
                 // :hamming / :exact bound the START positions by the window (SURVEY Q11,
                 // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
-                const int nread = roff[r + 1] - roff[r];
+                const int nread = rlen[r];
                 jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
             }
             w.c = codes + roff[r] + (jf - 1);
@@ -311,35 +361,37 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             // 2-bit packing of every read, 4 bases per byte, aligned to the read start
             for (int idx = tid; idx < nr * G; idx += BS) {
                 const int r = idx / G, g = idx - r * G;
-                const LDS unsigned char *c = codes + roff[r] + 4 * g;
+                const LDS unsigned char *c = codes + roff[r] + wlo[r] + 4 * g;
                 const uint32_t pk = (uint32_t)(c[0] & 3) | ((uint32_t)(c[1] & 3) << 2) | ((uint32_t)(c[2] & 3) << 4) |
                                     ((uint32_t)(c[3] & 3) << 6);
                 spk[r * (G + 4) + g] = (unsigned char)pk;
                 // a read longer than the planned group count would leave its tail unscanned:
                 // sweep every barcode of it instead (lossless fallback)
-                if (g == 0 && roff[r + 1] - roff[r] > 4 * (G - 1)) sall[r] = 1;
+                if (g == 0 && wlen[r] > 4 * (G - 1)) sall[r] = 1;
             }
             for (int idx = tid; idx < nr * 4; idx += BS) spk[(idx >> 2) * (G + 4) + G + (idx & 3)] = 0;
             __syncthreads();
             // scan: lane = (read, group of 4 start positions); key = 2q bits starting at the position
             for (int idx = tid; idx < nr * G; idx += BS) {
                 const int r = idx / G, g = idx - r * G;
-                const int nread = roff[r + 1] - roff[r];
+                const int nread = rlen[r];
+                const int base = wlo[r];  // group g covers read positions base + 4g .. base + 4g + 3
                 int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
                 if (npass == 1) {
                     lo = win[0 * R + r] - 1;
                     hi = (sg ? win[1 * R + r] : nread) - q;
                     if (win[1 * R + r] < win[0 * R + r]) hi = -1;
                 } else {
-                    lo = 0;
-                    hi = nread - q;
+                    lo = base;
+                    hi = base + wlen[r] - q;
                 }
-                if (4 * g + 3 < lo || 4 * g > hi) continue;
+                if (hi > base + wlen[r] - q) hi = base + wlen[r] - q;  // never beyond the staged bases
+                if (base + 4 * g + 3 < lo || base + 4 * g > hi) continue;
                 const LDS unsigned char *pk = spk + r * (G + 4) + g;
                 const uint32_t w = (uint32_t)pk[0] | ((uint32_t)pk[1] << 8) | ((uint32_t)pk[2] << 16);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int pos = 4 * g + i;
+                    const int pos = base + 4 * g + i;
                     const uint32_t key = (w >> (2 * i)) & kmask;
                     if (pos >= lo && pos <= hi && ((sbm[key >> 5] >> (key & 31)) & 1u)) {
                         const int k = __hip_atomic_fetch_add(&sqn[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -564,11 +616,11 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)gp.bc_stage_bytes) + al((size_t)gp.hist_entries * 4) + al(256);
     o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
-    o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + al((size_t)R * 16);
+    o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 3 * al((size_t)R * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes) + al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled) {
-        const int G = (bp.read_len_hint_for_lds + 3) / 4 + 1;
+        const int G = (bp.seed_span + 3) / 4 + 1;
         o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
         o += 2 * al((size_t)8 * R * 4) + al((size_t)R * (cw0 + cw1) * 4) + al((size_t)R);
     }
@@ -603,6 +655,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     }
     a.ncodes = bp.ncodes;
     a.dbg = 0;
+    a.slot_bytes = bp.slot_bytes;
     a.cand_out[0] = cand_out0;
     a.cand_out[1] = cand_out1;
     a.tile_counter = bp.d_tile_counter;
@@ -610,7 +663,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
     a.seed_q = sp.q;
-    a.seed_groups = (bp.read_len_hint_for_lds + 3) / 4 + 1;
+    a.seed_groups = (bp.seed_span + 3) / 4 + 1;
     a.seed_hash_log2 = sp.hash_log2;
     a.seed_bm_words = sp.bm_words;
     a.seed_bitmap = sp.d_bitmap;

@@ -75,6 +75,8 @@ struct BdxBitparPlan {
     int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
     int read_len_hint;     // the read length the geometry was planned for
     int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
+    int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
+    int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32

@@ -818,9 +818,10 @@ int orc_classify_batch(const orc_config_t *cfg, const uint8_t *seq_bytes, const 
 
 /* ---- differential self-test supporting the "known-score class" of the HIP path ----
  * Claim: with SimpleScoring unit costs (match 0, mismatch 1, indel 1),
- * ScoreOnly output, ref_search_range = 1:n, max_start_pos >= n and min_end_pos <= 1,
- * semiglobal_alignment_core returns  d  when d <= floor(max_error*m)  and Inf otherwise, where
- * d = min over read substrings of the unit-cost edit distance (plain full-matrix DP below).
+ * ScoreOnly output, any column window first:last inside the read, max_start_pos >= n and
+ * min_end_pos <= 1, semiglobal_alignment_core returns  d  when d <= floor(max_error*m)  and Inf
+ * otherwise, where d = min over substrings of r[first..last] of the unit-cost edit distance
+ * (plain full-matrix DP below).
  * Returns the number of disagreeing cases among `iters` random (barcode, read, rate) triples. */
 static uint64_t st_next(uint64_t *s) {
     uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
@@ -875,9 +876,16 @@ int64_t orc_selftest_known_class(uint64_t seed, int64_t iters, int64_t *first_ba
         double rate = RATES[st_next(&s) % 8];
         int64_t max_start = n + (int64_t)(st_next(&s) % 3) * 50; /* n, n+50, n+100: all non-binding */
         int64_t min_end = 1 - (int64_t)(st_next(&s) % 2);         /* 1 or 0 */
+        /* column window first:last — the whole read half of the time, else a random sub-range
+         * (ref_search_range windows; the start/end ranges stay non-binding) */
+        int64_t first = 1, last = n;
+        if (n > 0 && (st_next(&s) % 2)) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
         orc_align_t a = orc_semiglobal_core(DP, OG, q, m, r, n, rate, 0, 1, 1, 0, 0, ORC_OUT_SCOREONLY, 0,
-                                            1, n, max_start, min_end, m);
-        int64_t d = n > 0 ? orc_unit_distance(q, m, r, n) : m;
+                                            first, last, max_start, min_end, m);
+        int64_t d = n > 0 ? orc_unit_distance(q, m, r + (first - 1), last - first + 1) : m;
         int64_t ae = (int64_t)floor(rate * (double)m);
         int64_t expect = (n > 0 && d <= ae) ? d : INF_INT;
         if (a.raw != expect) {

@@ -283,3 +283,44 @@ def test_seed_with_wildcard_and_short_barcodes():
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=nn, ids=[str(i) for i in range(len(bcs))],
                             max_error_rate=0.13, nindel=1)
     _all_filters_agree(cfg, seq, off)
+
+
+# ---- window-slot staging (long reads, short column windows) ----
+@pytest.mark.parametrize("kw", [
+    dict(ref_search_range="1:200"),
+    dict(ref_search_range="end-300:end"),
+    dict(ref_search_range="500:900", max_error_rate=0.1),
+    dict(ref_search_range="end-250:end-20", trim_side=3),
+    dict(ref_search_range="1:150", matching_algorithm="hamming", max_error_rate=0.1),
+    dict(ref_search_range="100:400", min_delta=0.1),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_long_ragged_reads_with_windows(kw):
+    lens = np.random.Generator(np.random.PCG64(7)).integers(16, 33, size=24)
+    bcs = synth.make_barcodes(24, 24, seed=7, lengths=lens)
+    seq, off, _ = synth.make_ragged_reads(bcs, 1500, 1200, 6000, seed=7, plant_lo=0, plant_hi=None)
+    # plant additional copies near both ends so end-anchored windows see matches too
+    rng = np.random.Generator(np.random.PCG64(8))
+    seq = seq.copy()
+    for i in range(0, 1500, 2):
+        b = np.frombuffer(bcs[int(rng.integers(0, 24))].encode(), dtype=np.uint8)
+        n = int(off[i + 1] - off[i])
+        for pos in (int(rng.integers(0, 150)), n - 260 + int(rng.integers(0, 200)), 520 + int(rng.integers(0, 300))):
+            if 0 <= pos and pos + len(b) <= n:
+                seq[off[i] + pos: off[i] + pos + len(b)] = b
+    kw = dict(kw)
+    rs = kw.pop("ref_search_range")
+    cfg = _c2_config(bcs, **{"max_error_rate": 0.2, **kw}, ref_search_range=H.bdx.parse_dynamic_range(rs))
+    exp = _all_filters_agree(cfg, seq, off)
+    assert (exp["bc1"] > 0).mean() > 0.1
+
+
+def test_long_reads_dual_windows():
+    b1 = synth.make_barcodes(12, 20, seed=41, min_hamming=6)
+    b2 = synth.make_barcodes(10, 20, seed=42, min_hamming=6)
+    seq, off, _ = synth.make_reads(b1, 1200, 3000, seed=41, plant_lo=0, plant_hi=60, second=(b2, 2900, 2975))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[20] * 12, ids=[f"x{i}" for i in range(12)], is_dual=True,
+                            bc_seqs2=b2, bc_lengths_no_N2=[20] * 10, ids2=[f"y{i}" for i in range(10)],
+                            max_error_rate=0.15, ref_search_range=H.bdx.parse_dynamic_range("1:100"),
+                            ref_search_range2=H.bdx.parse_dynamic_range("end-120:end"))
+    exp = _all_filters_agree(cfg, seq, off)
+    assert (exp["bc1"] > 0).mean() > 0.4
