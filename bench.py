@@ -85,6 +85,7 @@ def main():
     # memset all live on it (handle 0 would mean "library's own stream" to bdx_set_stream)
     stream = torch.cuda.Stream(dev)
     hc.set_stream(stream.cuda_stream)
+    hc.set_read_length_hint(150)  # C2 reads are 150 bp: skips the per-batch max-length measurement (a sync)
     d_seq = torch.from_numpy(seq).to(dev)
     d_off = torch.from_numpy(off).to(dev)
     d_bc1 = torch.empty(n, dtype=torch.int32, device=dev)

@@ -145,6 +145,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     BdxBitparPlan &bp = ctx->bplan;
     bp = BdxBitparPlan{};
     if (c.filter == BDX_FILTER_OFF) return BDX_OK;
+    if (ctx->plan.bc_stage_bytes == 0) return BDX_OK;  // the fused kernel keeps all barcodes in LDS
     const int npass = c.is_dual ? 2 : 1;
     // cost domain: every edit operation must cost >= 1 and a match >= 0
     int cmin = 1;
@@ -176,6 +177,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     }
     if (cand_words > 64) return BDX_OK;
     bp.ncodes = K + 1;
+    bp.ncode_N = code_of['N'] >= 0 ? code_of['N'] : 255;
     std::vector<uint8_t> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)(code_of[i] < 0 ? K : code_of[i]);
     size_t bytes = 256;
@@ -309,8 +311,9 @@ int build_seed_tables(bdx_ctx *ctx) {
     const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
     if (expected * 3.0 > (double)total_bc) return BDX_OK;
     sp.q = q;
-    sp.bm_words = (int)(space / 32.0);
-    if (sp.bm_words < 1) sp.bm_words = 1;
+    sp.bm_log2 = 2 * q < 13 ? 2 * q : 13;  // <= 8192 bits (1 KiB); hashed, so larger key spaces alias
+    if (sp.bm_log2 < 5) sp.bm_log2 = 5;
+    sp.bm_words = (1 << sp.bm_log2) / 32;
     sp.hash_log2 = 8;
     while ((1u << sp.hash_log2) < pieces.size() * 2) sp.hash_log2++;
     std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
@@ -319,7 +322,8 @@ int build_seed_tables(bdx_ctx *ctx) {
         const bdx_pass_t &p = c.pass[pc.pass];
         uint32_t key = 0;
         for (int i = 0; i < q; ++i) key |= (uint32_t)(code_of[p.bc_bytes[p.bc_off[pc.b] + pc.start + i]] & 3) << (2 * i);
-        bitmap[key >> 5] |= 1u << (key & 31);
+        const uint32_t hb = (key * 0x9E3779B1u) >> (32 - sp.bm_log2);
+        bitmap[hb >> 5] |= 1u << (hb & 31);
         const uint32_t entry = (key << 16) | ((uint32_t)pc.pass << 15) | (uint32_t)(pc.b + 1);
         uint32_t slot = (key * 0x9E3779B1u) >> (32 - sp.hash_log2);
         bool dup = false;
@@ -418,10 +422,13 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->splan);
         if (lds > LDS_MAX) continue;
         int blocks = (int)(LDS_MAX / lds);
-        if (blocks > 4) blocks = 4;  // 16 waves/CU already hide the latency; beyond that prefer larger tiles
+        // Measured on MI355X (tools/probe.py): tile size matters more than residency once 3
+        // workgroups (12 waves) share a CU — larger tiles fill the 256 lanes of the sparse
+        // sweep / exact stages better.  Rank: >= 3 resident (largest R wins), then 2, then 1.
+        const int rank = blocks >= 3 ? 3 : blocks;
         if (R == 16 && best_R) continue;
-        if (blocks > best_blocks) {
-            best_blocks = blocks;
+        if (rank > best_blocks) {
+            best_blocks = rank;
             best_R = R;
             best_stage = (int)st;
         }

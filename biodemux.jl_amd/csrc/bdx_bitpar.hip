@@ -49,7 +49,7 @@ struct BitparArgs {
     int bpad[2];
     int bshift[2];
     // q-gram seeding (SEED variant only)
-    int seed_q, seed_groups, seed_hash_log2, seed_bm_words;
+    int seed_q, seed_groups, seed_hash_log2, seed_bm_words, seed_bm_log2;
     int seed_n_always[2];
     const uint32_t *seed_bitmap;
     const uint32_t *seed_hash;
@@ -57,6 +57,7 @@ struct BitparArgs {
     uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
+    int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
     int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
 };
@@ -104,8 +105,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *slots = (LDS uint32_t *)take((size_t)2 * R * 4 * 4);  // [pass][R][4] (barcode << 8 | d)
     LDS int *scnt = (LDS int *)take((size_t)2 * R * 4);                 // [pass][R] entries pushed
     LDS unsigned char *full = take((size_t)2 * R);                      // [pass][R] read is in the known-score class
-    LDS unsigned char *rstage = take((size_t)a.stage_bytes);
-    LDS unsigned char *codes = take((size_t)a.stage_bytes + 16);
+    // one staging area: the raw bytes are transcoded IN PLACE to symbol codes; the in-kernel exact
+    // stage then compares codes (equal bytes <=> equal codes for every byte a barcode contains)
+    LDS unsigned char *rstage = take((size_t)a.stage_bytes + 16);
+    LDS unsigned char *codes = rstage;
     // seeding work areas (SEED variant only)
     LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
     LDS uint32_t *shash = (LDS uint32_t *)take(SEED ? ((size_t)4 << a.seed_hash_log2) : 0);
@@ -142,8 +145,9 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     __syncthreads();
     const int bytes0 = (int)off0[B0];
     const int bytes1 = cfg.is_dual ? (int)off1[B1] : 0;
-    for (int i = tid; i < bytes0; i += BS) bcs[i] = cfg.pass[0].bc_bytes[i];
-    for (int i = tid; i < bytes1; i += BS) bcs[bytes0 + i] = cfg.pass[1].bc_bytes[i];
+    for (int i = tid; i < bytes0; i += BS) bcs[i] = lut[cfg.pass[0].bc_bytes[i]];  // barcodes as codes too
+    for (int i = tid; i < bytes1; i += BS) bcs[bytes0 + i] = lut[cfg.pass[1].bc_bytes[i]];
+    const int ncode = a.ncode;
 
     // ---- persistent workgroup: the tables above are loaded once, then the workgroup walks
     // tiles of R consecutive reads (tile = blockIdx.x, + gridDim.x, ...).  Tiles are independent;
@@ -393,7 +397,8 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int pos = base + 4 * g + i;
                     const uint32_t key = (w >> (2 * i)) & kmask;
-                    if (pos >= lo && pos <= hi && ((sbm[key >> 5] >> (key & 31)) & 1u)) {
+                    const uint32_t hb = (key * 0x9E3779B1u) >> (32 - a.seed_bm_log2);  // hashed bitmap index
+                    if (pos >= lo && pos <= hi && ((sbm[hb >> 5] >> (hb & 31)) & 1u)) {
                         const int k = __hip_atomic_fetch_add(&sqn[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (k < SQCAP)
                             shq[k] = ((uint32_t)r << 16) | key;
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                 // more than four survivors (or a read outside the class): exact evaluation instead
                 kn[p] = KnownPass{p < npass && full[p * R + tid] && cnt <= 4, e[0], e[1], e[2], e[3], cnt};
             }
-            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn[0], kn[1]);
+            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn[0], kn[1], ncode);
         } else {  // span larger than the staging area: unfiltered evaluation straight from HBM/L2
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
@@ -618,7 +623,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 3 * al((size_t)R * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
-    o += al((size_t)bp.stage_bytes) + al((size_t)bp.stage_bytes + 16);
+    o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled) {
         const int G = (bp.seed_span + 3) / 4 + 1;
         o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
@@ -656,6 +661,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.ncodes = bp.ncodes;
     a.dbg = 0;
     a.slot_bytes = bp.slot_bytes;
+    a.ncode = bp.ncode_N;
     a.cand_out[0] = cand_out0;
     a.cand_out[1] = cand_out1;
     a.tile_counter = bp.d_tile_counter;
@@ -666,6 +672,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_groups = (bp.seed_span + 3) / 4 + 1;
     a.seed_hash_log2 = sp.hash_log2;
     a.seed_bm_words = sp.bm_words;
+    a.seed_bm_log2 = sp.bm_log2;
     a.seed_bitmap = sp.d_bitmap;
     a.seed_hash = sp.d_hash;
     for (int k = 0; k < 2; ++k) {

@@ -10,6 +10,7 @@ namespace {
 
 struct Costs {
     int match, mismatch, indel, nindel;
+    int ncode;  // value that stands for barcode 'N': 0x4E on raw bytes, its symbol code on transcoded data
 };
 
 struct AlignOut {
@@ -93,7 +94,7 @@ __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int 
         if (TB) diag_o = (fact == 1) ? j : OG[(fact - 1) * S];
         for (int i = fact; i <= lact; ++i) {
             const int qi = q[i - 1];
-            const bool isN = NS && (qi == 'N');
+            const bool isN = NS && (qi == c.ncode);
             const int cost = isN ? c.nindel : c.indel;       // :196-197
             const int dpi = DP[i * S];
             const int ins = (i == m) ? BDX_INF32 : dpi + cost;  // :213 / :229, :183
@@ -153,7 +154,7 @@ template <bool STAGED>
 __device__ __forceinline__ AlignOut hamming_dev(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
                                                 const int n, const int allowed, const int first,
                                                 const int last, const int max_start, const int min_end,
-                                                const int trim_side) {
+                                                const int trim_side, const int ncode) {
     AlignOut best{BDX_INF32, -1, -1};
     const int sf = first > 1 ? first : 1;  // :570
     int sl = last < max_start ? last : max_start;
@@ -168,7 +169,7 @@ __device__ __forceinline__ AlignOut hamming_dev(const Bytes<STAGED> q, const int
         for (int k = 0; k < m; ++k) {  // :592-604
             const int qc = q[k];
             const int rc = r[j - 1 + k];
-            if (qc != rc && qc != 0x4E) {
+            if (qc != rc && qc != ncode) {
                 if (++mism > allowed) {
                     failed = true;
                     break;
@@ -342,7 +343,7 @@ template <bool STAGED>
 __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPass &P, const Bytes<STAGED> bcb,
                                             const LDS uint32_t *bc_off, const LDS int *bc_nn,
                                             const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
-                                            const int S, const uint32_t *cand) {
+                                            const int S, const uint32_t *cand, const int ncode = 0x4E) {
     PassOut po{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     PassWindow w;
     if (!pass_window(P, n, w)) return po;  // :805-807
@@ -350,7 +351,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 
     const int trim_side = P.trim_side;
     const bool need_tb = (trim_side != 0) || cfg.need_traceback;  // :812
-    const Costs c{cfg.match, cfg.mismatch, cfg.indel, cfg.nindel};
+    const Costs c{cfg.match, cfg.mismatch, cfg.indel, cfg.nindel, ncode};
     Reducer red;
     red.init(cfg);
 
@@ -382,7 +383,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         double score;
         if (cfg.algorithm == BDX_ALG_HAMMING) {
             const int allowed = (int)__builtin_floor(red.rate * (double)m);  // :567
-            a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side);
+            a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side, ncode);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :607
         } else if (cfg.algorithm == BDX_ALG_EXACT) {
             a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side);
@@ -467,19 +468,20 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
                                              const int S, const uint32_t *cand0, const uint32_t *cand1,
                                              Verdict &v, PassOut &p1, PassOut &p2,
                                              const KnownPass kn0 = KnownPass{false, 0, 0, 0, 0, 0},
-                                             const KnownPass kn1 = KnownPass{false, 0, 0, 0, 0, 0}) {
+                                             const KnownPass kn1 = KnownPass{false, 0, 0, 0, 0, 0},
+                                             const int ncode = 0x4E) {
     // determine_filename, classification.jl:871-938
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     p1 = kn0.use ? run_pass_known(cfg, off0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
-                 : run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0);  // :875
+                 : run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.use ? run_pass_known(cfg, off1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
-                     : run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1);
+                     : run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

@@ -77,6 +77,7 @@ struct BdxBitparPlan {
     int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
     int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
+    int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
@@ -91,7 +92,8 @@ struct BdxBitparPlan {
 struct BdxSeedPlan {
     int enabled;
     int q;                 // seed length in bases (5..8); key = 2 bits per base
-    int bm_words;          // bitmap words = 4^q / 32
+    int bm_words;          // bitmap words (hashed: bit index = (key * 0x9E3779B1) >> (32 - bm_log2))
+    int bm_log2;
     int hash_log2;         // hash slots = 1 << hash_log2; entry = key << 16 | pass << 15 | (barcode + 1)
     int n_always[2];       // barcodes swept unconditionally (wildcards / too-short pieces)
     const uint32_t *d_bitmap;
