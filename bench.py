@@ -163,6 +163,21 @@ def main():
                "sample": f"first {sample} reads of the same C2 batch, oracle (C restatement of the reference "
                          f"algorithm) on {cores} host threads, {cpu_s:.1f} s; verdicts equal the HIP output"}
 
+    # HBM traffic per launch: PMC counters cannot be read from inside the process; use the committed
+    # rocprofv3 --pmc summary of this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    # x2 correction on FETCH_SIZE — MI355X_MICROARCH.md §HBM), produced by tools/summarize_prof.py.
+    traffic, traffic_src = None, None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_final_pmc.json"))
+        if prof and n == 10_000_000 and path.startswith("qgram"):
+            pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+            for kname, e in pj["kernels"].items():
+                if "bitpar" in kname and "hbm_read_bytes_corrected" in e:
+                    traffic = e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
+                    traffic_src = f"profiles/{prof[-1]} ({kname})"
+    except Exception:
+        pass
+
     if rank == 0:
         reads_total = n * world * args.steps
         value = reads_total / elapsed_max
@@ -178,9 +193,10 @@ def main():
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "parallelism": f"reads sharded x{world}",
                        "matched_fraction": float(counts[1]) / float(counts[0]), "gen_seconds": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
                          "kernel_ms_avg": kern_ms_avg, "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                         "note": "integer-VALU/LDS bound path (SURVEY F6); HBM fraction reported as asked"},
+                         "note": "integer-VALU / latency bound path (SURVEY F6); HBM fraction reported as asked"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
