@@ -106,7 +106,11 @@ const size_t LDS_MAX = 160 * 1024;
 int plan_generic(bdx_ctx *ctx) {
     const BdxDevCfg &d = ctx->dev;
     BdxGenericPlan &p = ctx->plan;
-    p.dp_rows = d.max_m + 1;
+    // SimpleScoring barcodes of <= 32 rows run the register-resident DP: no LDS columns at all
+    p.reg_rows = (!d.has_nindel && d.algorithm == BDX_ALG_SEMIGLOBAL && !d.force_lds_dp)
+                     ? (d.max_m <= 24 ? 24 : (d.max_m <= 32 ? 32 : 0)) : 0;
+    p.dp_rows = p.reg_rows ? 1 : d.max_m + 1;
+    p.dp_rows_fused = d.max_m + 1;
     const size_t per_thread = (size_t)p.dp_rows * 4 * (d.any_traceback ? 2 : 1);
     const int B0 = d.pass[0].n_barcodes, B1 = d.is_dual ? d.pass[1].n_barcodes : 0;
     size_t bc_total = 0;
@@ -513,6 +517,7 @@ int upload_tables(bdx_ctx *ctx) {
     d.has_nindel = c.has_nindel != 0;
     d.nindel = c.has_nindel ? c.nindel : 0;
     d.need_traceback = c.need_traceback != 0;
+    d.force_lds_dp = getenv("BDX_LDS_DP") ? 1 : 0;
     d.max_m = 1;
     d.any_traceback = d.need_traceback;
     const int npass = d.is_dual ? 2 : 1;

@@ -615,8 +615,8 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     const int B0 = cfg.pass[0].n_barcodes, B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
     const int cw0 = cfg.pass[0].cand_words, cw1 = cfg.is_dual ? cfg.pass[1].cand_words : 0;
     size_t o = 0;
-    o += al((size_t)gp.dp_rows * R * 4);
-    o += al(cfg.any_traceback ? (size_t)gp.dp_rows * R * 4 : 0);
+    o += al((size_t)gp.dp_rows_fused * R * 4);
+    o += al(cfg.any_traceback ? (size_t)gp.dp_rows_fused * R * 4 : 0);
     o += al((size_t)(B0 + 1) * 4) + al((size_t)(B1 + 1) * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4);
     o += al((size_t)gp.bc_stage_bytes) + al((size_t)gp.hist_entries * 4) + al(256);
     o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
@@ -645,7 +645,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.n_reads = n_reads;
     a.out = out;
     a.counts = d_counts;
-    a.dp_rows = gp.dp_rows;
+    a.dp_rows = gp.dp_rows_fused;
     a.stage_bytes = bp.stage_bytes;
     a.bc_stage_bytes = gp.bc_stage_bytes;
     a.hist_entries = gp.hist_entries;

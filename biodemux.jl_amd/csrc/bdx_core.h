@@ -148,6 +148,124 @@ __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int 
     return res;  // :444
 }
 
+// Register-resident variant of sg_core for barcodes of at most M rows: the DP column, the
+// origin column and the barcode itself live in VGPRs (statically indexed, rows fully unrolled);
+// rows outside fact..lact are predicated off and keep their (stale) values, exactly like the
+// array of the reference.  Semantics are identical to sg_core above — same seeds, same stale
+// cells, same tie-breaks, same early exits — only the storage differs:
+//   * the reference writes row i-1 while visiting row i (:326-331, :364-367) and row lact after the
+//     loop (:412-415); net effect per column: rows fact..lact receive their new values, row
+//     fact-1 (if any) receives the seed (allowed_error, origin j), all other rows are untouched.
+//     Here row i is written in its own iteration and the old value is carried to row i+1 as the
+//     diagonal operand, which is the same data flow without the one-row shift.
+// Why: lanes of a wave sit in their barcode's match region at different columns, so the wave
+// runs ~m rows in every column anyway; without LDS round-trips in the dependent chain the
+// statically unrolled form is several times faster.
+template <bool TB, bool NS, int M, bool STAGED>
+__device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
+                                                const int n, const int ae, const Costs c, const int trim_side,
+                                                int first, const int last, const int max_start,
+                                                const int min_end) {
+    AlignOut res{BDX_INF32, -1, -1};
+    if (m == 0 || n == 0) return res;  // :250-252
+
+    const int steps = ae / (NS ? (c.indel < c.nindel ? c.indel : c.nindel) : c.indel);  // :257
+    const int min_valid_start = min_end - (m + steps) + 1;                            // :259
+    if (min_valid_start > max_start) return res;                                      // :261-263
+    if (min_valid_start > first) first = min_valid_start;                             // :266-268
+    const int b1 = m - n - steps, b2 = -max_start - steps;
+    const int band = b1 > b2 ? b1 : b2;  // :270
+
+    int DP[M + 1], OG[M + 1];
+    uint32_t QP[(M + 3) / 4];  // barcode code units, four per register (rows beyond m: 0xFF)
+#pragma unroll
+    for (int i = 1; i <= M; ++i) {  // :278-283 (rows beyond m exist only as dead registers)
+        DP[i] = c.indel * i;
+        OG[i] = 1 - i;
+    }
+#pragma unroll
+    for (int w = 0; w < (M + 3) / 4; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)((4 * w + k < m) ? q[4 * w + k] : 0xFF) << (8 * k);
+        QP[w] = v;
+    }
+
+    int lact = (ae + 1 < m) ? ae + 1 : m;  // :286
+    for (int j = first; j <= last; ++j) {  // :287
+        int prev_o = j;                    // :288
+        int fact, prev;
+        if (j + band >= 1) {  // :289-295
+            fact = j + band;
+            prev = ae;
+        } else {
+            fact = 1;
+            prev = 0;
+        }
+        if (fact > lact) return res;  // :297-299
+
+        const int rj = r[j - 1];
+        const int seed = prev;
+        int diag = 0;    // row-0 value (:215 "i == 1 ? 0")
+        int diag_o = j;  // row-0 origin (:308)
+#pragma unroll
+        for (int i = 1; i <= M; ++i) {
+            const int old = DP[i];
+            const int old_o = OG[i];
+            const bool inb = (i >= fact) && (i <= lact);
+            const int qi = (int)((QP[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu);
+            const bool isN = NS && (qi == c.ncode);
+            const int cost = isN ? c.nindel : c.indel;
+            const int ins = (i == m) ? BDX_INF32 : old + cost;
+            const int del = prev + cost;
+            const int sub = diag + ((qi == rj || isN) ? c.match : c.mismatch);
+            int cur_o = prev_o;
+            if (TB) {  // :310-321
+                int best = del;
+                if (sub < best) {
+                    best = sub;
+                    cur_o = diag_o;
+                }
+                if (ins < best) cur_o = old_o;
+            }
+            const int t = del < sub ? del : sub;
+            const int nv = ins < t ? ins : t;
+            const bool seedrow = (i == fact - 1);  // :326-331 (fact != 1 is implied by i >= 1)
+            DP[i] = inb ? nv : (seedrow ? seed : old);
+            if (TB) OG[i] = inb ? cur_o : (seedrow ? j : old_o);
+            prev = inb ? nv : prev;
+            if (TB) prev_o = inb ? cur_o : prev_o;
+            diag = old;
+            diag_o = old_o;
+        }
+
+        if (lact == m && prev <= ae) {  // :417
+            lact -= 1;
+            if (j >= min_end) {
+                if (prev == 0 && (!TB || trim_side == 5)) {  // :420-430
+                    AlignOut z{0, TB ? prev_o : -1, TB ? j : -1};
+                    return z;
+                }
+                if (TB) {  // :142-153
+                    if (prev < res.raw || (prev == res.raw && trim_side == 3 && prev_o > res.start)) {
+                        res.raw = prev;
+                        res.start = prev_o;
+                        res.end = j;
+                    }
+                } else {
+                    res.raw = prev < res.raw ? prev : res.raw;
+                }
+            }
+        }
+        // :439-442  while lact > 0 && DP[lact] > allowed_error: lact -= 1;  lact += 1
+#pragma unroll
+        for (int i = M; i >= 1; --i)
+            if (lact == i && DP[i] > ae) lact = i - 1;
+        ++lact;
+    }
+    return res;  // :444
+}
+
 // hamming_align, classification.jl:557-625.  Scores of one call share the divisor m, so the
 // reference's Float64 `score < best_score` / `==` are decided on the integer numerators.
 template <bool STAGED>
@@ -339,7 +457,7 @@ struct Reducer {
 
 // match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
 // reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
-template <bool STAGED>
+template <bool STAGED, int REGM = 0>
 __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPass &P, const Bytes<STAGED> bcb,
                                             const LDS uint32_t *bc_off, const LDS int *bc_nn,
                                             const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
@@ -394,6 +512,9 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             if (cfg.has_nindel) {
                 a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
                             : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
+            } else if (REGM > 0) {
+                a = need_tb ? sg_core_reg<true, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
+                            : sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
             } else {
                 a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
                             : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
@@ -460,7 +581,7 @@ struct KnownPass {
     int count;
 };
 
-template <bool STAGED>
+template <bool STAGED, int REGM = 0>
 __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<STAGED> bcb0,
                                              const Bytes<STAGED> bcb1, const LDS uint32_t *off0,
                                              const LDS uint32_t *off1, const LDS int *nn0, const LDS int *nn1,
@@ -474,14 +595,14 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     p1 = kn0.use ? run_pass_known(cfg, off0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
-                 : run_pass<STAGED>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode);  // :875
+                 : run_pass<STAGED, REGM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.use ? run_pass_known(cfg, off1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
-                     : run_pass<STAGED>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode);
+                     : run_pass<STAGED, REGM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

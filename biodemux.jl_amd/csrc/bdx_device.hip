@@ -43,7 +43,9 @@ struct GenericArgs {
 // LDS carve-up (all 16-byte aligned):
 //   [DP: dp_rows*BS int][OG: dp_rows*BS int if any_traceback][off0|off1: uint32][nn0|nn1: int]
 //   [barcode bytes pass0|pass1][hist: int[hist_entries]][read bytes: stage_bytes]
-template <int BS>
+// REGM > 0: the exact DP of SimpleScoring barcodes up to REGM rows runs register-resident
+// (sg_core_reg); the kernel then needs no DP/origin columns in LDS.
+template <int BS, int REGM>
 __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
         if (staged) {
             Bytes<true> r{rstage + head + (ro - span0)};
             Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
+            classify_one<true, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
         } else {
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
-            classify_one<false>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
+            classify_one<false, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
         }
         // outputs (coalesced: consecutive lanes -> consecutive reads)
         if (a.out.bc1) a.out.bc1[ridx] = v.bc1;
@@ -218,14 +220,19 @@ hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_o
     return hipGetLastError();
 }
 
+template <int BS, int REGM>
+static hipError_t generic_attr(size_t bytes) {
+    return hipFuncSetAttribute((const void *)bdx_generic_kernel<BS, REGM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 hipError_t bdx_generic_set_lds_limit(size_t bytes) {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)bdx_generic_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bdx_generic_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)bdx_generic_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e;
+    if ((e = generic_attr<256, 0>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<128, 0>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<64, 0>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 24>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 32>(bytes)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,
@@ -249,18 +256,24 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     const long long blocks = (n_reads + plan.threads - 1) / plan.threads;
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block((unsigned)plan.threads);
-    switch (plan.threads) {
-        case 256:
-            hipLaunchKernelGGL(bdx_generic_kernel<256>, grid, block, plan.lds_bytes, stream, a);
-            break;
-        case 128:
-            hipLaunchKernelGGL(bdx_generic_kernel<128>, grid, block, plan.lds_bytes, stream, a);
-            break;
-        case 64:
-            hipLaunchKernelGGL(bdx_generic_kernel<64>, grid, block, plan.lds_bytes, stream, a);
-            break;
-        default:
-            return hipErrorInvalidValue;
+    if (plan.reg_rows == 24 && plan.threads == 256) {
+        hipLaunchKernelGGL((bdx_generic_kernel<256, 24>), grid, block, plan.lds_bytes, stream, a);
+    } else if (plan.reg_rows == 32 && plan.threads == 256) {
+        hipLaunchKernelGGL((bdx_generic_kernel<256, 32>), grid, block, plan.lds_bytes, stream, a);
+    } else {
+        switch (plan.threads) {
+            case 256:
+                hipLaunchKernelGGL((bdx_generic_kernel<256, 0>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            case 128:
+                hipLaunchKernelGGL((bdx_generic_kernel<128, 0>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            case 64:
+                hipLaunchKernelGGL((bdx_generic_kernel<64, 0>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

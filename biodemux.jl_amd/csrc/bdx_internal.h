@@ -16,6 +16,7 @@
 #define BDX_MAX_COST 32767
 #define BDX_MAX_M 8192
 #define BDX_MAX_RATE 1.0e4
+#define BDX_REG_ROWS 32  // barcodes up to this length run the register-resident exact DP
 
 struct BdxDevRange {
     long long start_offset;
@@ -45,6 +46,7 @@ struct BdxDevCfg {
     int has_nindel, nindel;
     int need_traceback;
     int max_m;
+    int force_lds_dp;   // testing: use the LDS-resident DP even for short barcodes (env BDX_LDS_DP)
     int any_traceback;  // origin array needed (trim or summary in any pass)
     int counts_stride2; // max(1, B2 when dual)
     int n_counts;
@@ -60,7 +62,9 @@ struct BdxDevOut {
 // Launch geometry chosen on the host for the generic (unfiltered / verify) kernel.
 struct BdxGenericPlan {
     int threads;         // 64 / 128 / 256
-    int dp_rows;         // max_m + 1
+    int reg_rows;        // 24 / 32: register-resident exact DP (no DP columns in LDS); 0: LDS columns
+    int dp_rows;         // generic kernel: max_m + 1, or 1 in register mode
+    int dp_rows_fused;   // fused kernel's in-kernel exact stage always keeps LDS columns: max_m + 1
     int stage_bytes;     // LDS bytes reserved for staged read bytes (0 = read from HBM/L2 directly)
     int bc_stage_bytes;  // LDS bytes for the staged barcode bytes of both passes (0 = not staged)
     int hist_entries;    // LDS histogram entries (0 = global atomics)
