@@ -20,6 +20,7 @@ import numpy as np
 from .classification import DemuxStats, filename_for
 from .config import DemuxConfig, build_config
 from .fileio import read_fastq
+from . import nativeio
 from .hipabi import HipClassifier
 
 _PREFIX_RE = re.compile(r"\.fastq(\.gz)?$")
@@ -137,11 +138,13 @@ def _demux(fastq1: str, fastq2: Optional[str], config: DemuxConfig, output_direc
 
 
 def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxConfig], object]] = None,
-                           _batch_reads: int = DEFAULT_BATCH_READS, device: int = 0, **kw):
+                           _batch_reads: int = DEFAULT_BATCH_READS, _io: str = "auto", device: int = 0, **kw):
     """execute_demultiplexing(FASTQ_file, barcode_file, output_directory; kwargs...)      core.jl:500
     execute_demultiplexing(FASTQ_file1, FASTQ_file2, barcode_file, output_directory; ...)  core.jl:360
 
     Keyword arguments and defaults are the reference's (core.jl:365-391 / :504-528).
+    ``_io`` selects the host-side reader/writer: "native" (csrc/bdx_io.cpp, threads), "python" (the
+    plain reference implementation below) or "auto" (native when the library was built).
     ``_classifier_factory`` is a test seam: the parity tests on CPU pass the oracle here to
     check this file contract; the product default is the HIP classifier and nothing else.
     Returns the DemuxStats scalar counters (the reference returns nothing)."""
@@ -203,7 +206,13 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
 
     classifier = _classifier_factory(config) if _classifier_factory else HipClassifier(config, device=device)
     try:
-        _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads)
+        if _io not in ("auto", "native", "python"):
+            raise ValueError("_io must be 'auto', 'native' or 'python'")
+        use_native = _io == "native" or (_io == "auto" and nativeio.available())
+        if use_native:
+            nativeio.demux_native(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads)
+        else:
+            _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads)
         counts = np.asarray(classifier.counts)
     finally:
         classifier.close()

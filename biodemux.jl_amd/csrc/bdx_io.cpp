@@ -1,0 +1,343 @@
+// bdx_io.cpp — native host-side FASTQ reader / packer and in-order demultiplexing writer
+// (libbdx_io.so, plain C ABI, no GPU code).  SURVEY.md §8(f) rank 1: the callers either side
+// of the hot path.  Behaviour follows the reference's reader_task / writer_task
+// (BioDemuX.jl src/core.jl:43-110, :118-224):
+//   * a record is four readline() calls; readline strips "\n" and a preceding "\r"; a truncated
+//     last record is padded with empty lines (readline at EOF returns "");
+//   * records of one output file keep input order; files are opened in append mode; a path
+//     ending in ".gz" (or gzip forced) is written through zlib;
+//   * trimming applies to R1's sequence and quality only, clamped to the sequence length
+//     (core.jl:162-173).
+// The reference does this with one reader and one writer task; here line indexing, packing and
+// the per-file gather are spread over host threads so the 1 G reads/s kernel is not starved more
+// than the file system dictates.
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" {
+
+struct bdx_fq_file {
+    const uint8_t *data = nullptr;
+    int64_t size = 0;
+    bool mapped = false;
+    std::vector<uint8_t> owned;  // inflated .gz contents
+};
+
+static thread_local std::string g_io_err;
+const char *bdx_io_last_error(void) { return g_io_err.c_str(); }
+
+// Opens a FASTQ file: plain files are mmap'ed, ".gz" (case-insensitive, fileio.jl:78) is inflated
+// into memory with zlib.  Returns 0 on success.
+int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
+    *out = nullptr;
+    auto *f = new bdx_fq_file();
+    std::string p(path), low(p);
+    std::transform(low.begin(), low.end(), low.begin(), ::tolower);
+    const bool gz = low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0;
+    if (gz) {
+        gzFile g = gzopen(path, "rb");
+        if (!g) {
+            g_io_err = "cannot open " + p;
+            delete f;
+            return -1;
+        }
+        gzbuffer(g, 1 << 20);
+        std::vector<uint8_t> &o = f->owned;
+        o.resize(1 << 22);
+        size_t used = 0;
+        for (;;) {
+            if (o.size() - used < (1 << 20)) o.resize(o.size() * 2);
+            int got = gzread(g, o.data() + used, (unsigned)std::min<size_t>(o.size() - used, 1u << 30));
+            if (got < 0) {
+                g_io_err = "gzread failed on " + p;
+                gzclose(g);
+                delete f;
+                return -1;
+            }
+            if (got == 0) break;
+            used += (size_t)got;
+        }
+        gzclose(g);
+        o.resize(used);
+        f->data = o.data();
+        f->size = (int64_t)used;
+    } else {
+        int fd = open(path, O_RDONLY);
+        if (fd < 0) {
+            g_io_err = "cannot open " + p;
+            delete f;
+            return -1;
+        }
+        struct stat st;
+        if (fstat(fd, &st) != 0) {
+            g_io_err = "fstat failed on " + p;
+            close(fd);
+            delete f;
+            return -1;
+        }
+        f->size = (int64_t)st.st_size;
+        if (f->size > 0) {
+            void *m = mmap(nullptr, (size_t)f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                g_io_err = "mmap failed on " + p;
+                close(fd);
+                delete f;
+                return -1;
+            }
+            madvise(m, (size_t)f->size, MADV_SEQUENTIAL);
+            f->data = (const uint8_t *)m;
+            f->mapped = true;
+        }
+        close(fd);
+    }
+    *out = f;
+    return 0;
+}
+
+void bdx_fq_close(bdx_fq_file *f) {
+    if (!f) return;
+    if (f->mapped && f->data) munmap((void *)f->data, (size_t)f->size);
+    delete f;
+}
+
+const uint8_t *bdx_fq_data(const bdx_fq_file *f) { return f->data; }
+int64_t bdx_fq_size(const bdx_fq_file *f) { return f->size; }
+
+// Line index of the bytes [start, size): fills line_off[k] / line_len[k] for up to 4*max_reads
+// lines (len excludes "\n" and a preceding "\r").  Returns the number of RECORDS (a trailing
+// partial record counts; its missing lines get offset = size, len = 0) and stores the cursor
+// after the last consumed line in *next.  nthreads chunks scan for '\n' in parallel.
+int64_t bdx_fq_index(const bdx_fq_file *f, int64_t start, int64_t max_reads, int64_t *line_off,
+                     int32_t *line_len, int64_t *next, int32_t nthreads) {
+    const uint8_t *d = f->data;
+    const int64_t size = f->size;
+    if (start >= size || max_reads <= 0) {
+        *next = start;
+        return 0;
+    }
+    const int64_t want = 4 * max_reads;
+    // bound the scanned region: records average a few hundred bytes; grow until enough lines
+    std::vector<int64_t> nl;  // positions of '\n'
+    int64_t lo = start, scanned_to = start;
+    int64_t region = std::min<int64_t>(size - start, std::max<int64_t>(1 << 20, max_reads * 400));
+    while ((int64_t)nl.size() < want && scanned_to < size) {
+        const int64_t hi = std::min(size, scanned_to + region);
+        const int T = std::max(1, std::min<int>(nthreads, (int)((hi - scanned_to) >> 20) + 1));
+        std::vector<std::vector<int64_t>> parts(T);
+        std::vector<std::thread> th;
+        const int64_t span = (hi - scanned_to + T - 1) / T;
+        for (int t = 0; t < T; ++t) {
+            th.emplace_back([&, t]() {
+                const int64_t a = scanned_to + span * t, b = std::min(hi, a + span);
+                const uint8_t *p = d + a, *e = d + b;
+                auto &v = parts[t];
+                v.reserve((size_t)((b - a) / 80 + 16));
+                while (p < e) {
+                    const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+                    if (!q) break;
+                    v.push_back((int64_t)(q - d));
+                    p = q + 1;
+                }
+            });
+        }
+        for (auto &t : th) t.join();
+        for (auto &v : parts) nl.insert(nl.end(), v.begin(), v.end());
+        scanned_to = hi;
+        region *= 2;
+    }
+    (void)lo;
+    int64_t nlines = std::min<int64_t>((int64_t)nl.size(), want);
+    int64_t cur = start;
+    for (int64_t k = 0; k < nlines; ++k) {
+        int64_t e = nl[k];
+        line_off[k] = cur;
+        int64_t len = e - cur;
+        if (len > 0 && d[e - 1] == '\r') len -= 1;
+        line_len[k] = (int32_t)len;
+        cur = e + 1;
+    }
+    // data not terminated by '\n': the rest is one more line (readline at EOF)
+    if (nlines < want && scanned_to >= size && cur < size) {
+        int64_t len = size - cur;
+        line_off[nlines] = cur;
+        if (len > 0 && d[size - 1] == '\r') len -= 1;
+        line_len[nlines] = (int32_t)len;
+        nlines += 1;
+        cur = size;
+    }
+    const int64_t nrec = (nlines + 3) / 4;
+    for (int64_t k = nlines; k < 4 * nrec; ++k) {  // pad a truncated last record with empty lines
+        line_off[k] = size;
+        line_len[k] = 0;
+    }
+    *next = cur;
+    return nrec;
+}
+
+// Packs the sequence lines (line 1 of every record) into the C-ABI chunk layout:
+// seq_off[0] = 0, seq_off[i+1] = seq_off[i] + len_i; bytes copied in parallel.
+void bdx_fq_pack(const bdx_fq_file *f, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
+                 uint8_t *seq_bytes, int64_t *seq_off, int32_t nthreads) {
+    seq_off[0] = 0;
+    for (int64_t i = 0; i < nrec; ++i) seq_off[i + 1] = seq_off[i] + line_len[4 * i + 1];
+    const int T = std::max(1, std::min<int>(nthreads, (int)(nrec >> 14) + 1));
+    std::vector<std::thread> th;
+    const int64_t per = (nrec + T - 1) / T;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([=]() {
+            const int64_t a = per * t, b = std::min(nrec, a + per);
+            for (int64_t i = a; i < b; ++i)
+                memcpy(seq_bytes + seq_off[i], f->data + line_off[4 * i + 1], (size_t)line_len[4 * i + 1]);
+        });
+    for (auto &t : th) t.join();
+}
+
+int64_t bdx_fq_seq_bytes(const int32_t *line_len, int64_t nrec) {
+    int64_t s = 0;
+    for (int64_t i = 0; i < nrec; ++i) s += line_len[4 * i + 1];
+    return s;
+}
+
+// One output stream of a batch: records of file `src` (with its line tables) are appended to
+// class_paths[cls[i]] in input order.  trim != 0: keep_start/keep_end (1-based inclusive, -1 =
+// untrimmed) are applied to sequence and quality (core.jl:162-173).  force_gzip: config.gzip_output.
+int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
+                           const int32_t *cls, int32_t n_classes, const char *const *class_paths,
+                           const int32_t *keep_start, const int32_t *keep_end, int32_t trim, int32_t force_gzip,
+                           int32_t nthreads) {
+    const uint8_t *d = src->data;
+    // pass 1: output size per record and per class; destination offsets keep input order
+    std::vector<int64_t> csize((size_t)n_classes, 0), dst((size_t)nrec);
+    std::vector<int32_t> ta((size_t)(trim ? nrec : 0)), tb((size_t)(trim ? nrec : 0));
+    for (int64_t i = 0; i < nrec; ++i) {
+        const int32_t c = cls[i];
+        if (c < 0 || c >= n_classes) {
+            g_io_err = "class index out of range";
+            return -1;
+        }
+        int64_t sl = line_len[4 * i + 1], ql = line_len[4 * i + 3];
+        if (trim && keep_start[i] != -1) {
+            const int64_t slen = sl;
+            int64_t a = std::max<int64_t>(keep_start[i], 1), b = std::min<int64_t>(keep_end[i], slen);
+            if (a > b) {
+                a = 1;
+                b = 0;
+            }
+            ta[i] = (int32_t)a;
+            tb[i] = (int32_t)b;
+            sl = b - a + 1;
+            // the quality string is sliced with the same range; clamp to its own length
+            const int64_t qb = std::min<int64_t>(b, ql);
+            ql = qb >= a ? qb - a + 1 : 0;
+        } else if (trim) {
+            ta[i] = 1;
+            tb[i] = -1;  // marker: untrimmed
+        }
+        dst[i] = csize[c];
+        csize[c] += line_len[4 * i] + sl + line_len[4 * i + 2] + ql + 4;
+    }
+    std::vector<std::vector<uint8_t>> bufs((size_t)n_classes);
+    for (int c = 0; c < n_classes; ++c) bufs[c].resize((size_t)csize[c]);
+    // pass 2: parallel gather
+    {
+        const int T = std::max(1, std::min<int>(nthreads, (int)(nrec >> 13) + 1));
+        std::vector<std::thread> th;
+        const int64_t per = (nrec + T - 1) / T;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const int64_t a0 = per * t, b0 = std::min(nrec, a0 + per);
+                for (int64_t i = a0; i < b0; ++i) {
+                    uint8_t *o = bufs[cls[i]].data() + dst[i];
+                    const int64_t hl = line_len[4 * i], pl = line_len[4 * i + 2];
+                    int64_t so = line_off[4 * i + 1], sl = line_len[4 * i + 1];
+                    int64_t qo = line_off[4 * i + 3], ql = line_len[4 * i + 3];
+                    if (trim && tb[i] != -1) {
+                        const int64_t a = ta[i], b = tb[i];
+                        so += a - 1;
+                        sl = b - a + 1;
+                        const int64_t qb = std::min<int64_t>(b, ql);
+                        qo += a - 1;
+                        ql = qb >= a ? qb - a + 1 : 0;
+                    }
+                    memcpy(o, d + line_off[4 * i], (size_t)hl);
+                    o += hl;
+                    *o++ = '\n';
+                    memcpy(o, d + so, (size_t)sl);
+                    o += sl;
+                    *o++ = '\n';
+                    memcpy(o, d + line_off[4 * i + 2], (size_t)pl);
+                    o += pl;
+                    *o++ = '\n';
+                    memcpy(o, d + qo, (size_t)ql);
+                    o += ql;
+                    *o++ = '\n';
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    // pass 3: append each class buffer to its file (parallel over files)
+    std::vector<int> todo;
+    for (int c = 0; c < n_classes; ++c)
+        if (csize[c] > 0) todo.push_back(c);
+    std::vector<int> fail((size_t)todo.size(), 0);
+    {
+        const int T = std::max(1, std::min<int>(nthreads, (int)todo.size()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                for (size_t k = (size_t)t; k < todo.size(); k += (size_t)T) {
+                    const int c = todo[k];
+                    std::string p(class_paths[c]), low(p);
+                    std::transform(low.begin(), low.end(), low.begin(), ::tolower);
+                    const bool gz = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
+                    if (gz) {
+                        gzFile g = gzopen(p.c_str(), "ab");
+                        if (!g) {
+                            fail[k] = 1;
+                            continue;
+                        }
+                        size_t off = 0;
+                        while (off < bufs[c].size()) {
+                            const unsigned chunk = (unsigned)std::min<size_t>(bufs[c].size() - off, 1u << 30);
+                            if (gzwrite(g, bufs[c].data() + off, chunk) <= 0) {
+                                fail[k] = 1;
+                                break;
+                            }
+                            off += chunk;
+                        }
+                        gzclose(g);
+                    } else {
+                        FILE *fp = fopen(p.c_str(), "ab");
+                        if (!fp) {
+                            fail[k] = 1;
+                            continue;
+                        }
+                        if (fwrite(bufs[c].data(), 1, bufs[c].size(), fp) != bufs[c].size()) fail[k] = 1;
+                        fclose(fp);
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    for (size_t k = 0; k < todo.size(); ++k)
+        if (fail[k]) {
+            g_io_err = std::string("cannot write ") + class_paths[todo[k]];
+            return -1;
+        }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""Native host I/O (csrc/bdx_io.cpp) must behave exactly like the plain-Python reader/writer of
+core.py (itself held to the reference's goldens): same files, same bytes, same order — incl. CRLF
+input, a truncated last record, a trailing blank line, paired lock-step, trimming, gzip in/out."""
+import functools
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from biodemux_jl_amd import nativeio, synth
+
+run_py = functools.partial(H.bdx.execute_demultiplexing, _classifier_factory=H.oracle_factory, _io="python")
+run_nat = functools.partial(H.bdx.execute_demultiplexing, _classifier_factory=H.oracle_factory, _io="native")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    nativeio.build()
+
+
+def test_goldens_through_native_io(tmp_path):
+    assert H.scenario_demo1_R1(run_nat, str(tmp_path / "a")) == 24
+    assert H.scenario_demo1_R2(run_nat, str(tmp_path / "b")) == 24
+    assert H.scenario_demo2(run_nat, str(tmp_path / "c")) == 76  # gz in, classify_both, revcomp
+
+
+@pytest.mark.parametrize("scenario", H.SCENARIOS_SMALL, ids=[s.__name__ for s in H.SCENARIOS_SMALL])
+def test_reference_scenarios_through_native_io(tmp_path, scenario):
+    scenario(run_nat, str(tmp_path))
+
+
+def _same_tree(a, b):
+    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+    assert fa == fb
+    for f in fa:
+        assert H._read_maybe_gz(os.path.join(a, f)) == H._read_maybe_gz(os.path.join(b, f)), f
+
+
+def _fastq(path, seqs, crlf=False, tail=b"", gz=False):
+    nl = b"\r\n" if crlf else b"\n"
+    blob = b"".join(b"@r%d some header" % i + nl + s + nl + b"+" + nl + b"I" * len(s) + nl for i, s in enumerate(seqs)) + tail
+    (gzip.open if gz else open)(path, "wb").write(blob)
+
+
+@pytest.mark.parametrize("case", ["plain", "crlf", "truncated", "blankline", "no_final_newline", "gz", "small_batches"])
+def test_native_equals_python_io(tmp_path, case):
+    bcs = synth.make_barcodes(6, 12, seed=5, min_hamming=4)
+    seq, off, _ = synth.make_ragged_reads(bcs, 700, 0, 90, seed=5)
+    seqs = [seq[off[i]:off[i + 1]].tobytes() for i in range(700)]
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    tail = {"truncated": b"@last\nACGTAC", "blankline": b"\n", "no_final_newline": b"@x\nACGT\n+\nIIII"}.get(case, b"")
+    fq = str(tmp_path / ("reads.fastq.gz" if case == "gz" else "reads.fastq"))
+    _fastq(fq, seqs, crlf=(case == "crlf"), tail=tail, gz=(case == "gz"))
+    kw = dict(max_error_rate=0.2, trim_side=5)
+    if case == "small_batches":
+        kw["_batch_reads"] = 37
+    run_py(fq, str(bc), str(tmp_path / "py"), **kw)
+    run_nat(fq, str(bc), str(tmp_path / "nat"), **kw)
+    _same_tree(str(tmp_path / "py"), str(tmp_path / "nat"))
+
+
+def test_native_paired_lockstep_and_classify_both(tmp_path):
+    bcs = synth.make_barcodes(5, 12, seed=6, min_hamming=4)
+    seq, off, _ = synth.make_reads(bcs, 500, 60, seed=6)
+    s1 = [seq[off[i]:off[i + 1]].tobytes() for i in range(500)]
+    s2 = [b"ACGT" * 10 for _ in range(430)]  # R2 is shorter: stop at the shorter file
+    bc = tmp_path / "bc.tsv"
+    bc.write_text("ID\tFull_seq\tFull_annotation\n" + "".join(f"b{i}\t{b}\t{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    f1, f2 = str(tmp_path / "x_R1.fastq"), str(tmp_path / "x_R2.fastq")
+    _fastq(f1, s1)
+    _fastq(f2, s2)
+    for both in (False, True):
+        kw = dict(classify_both=both, trim_side=3, _batch_reads=128)
+        run_py(f1, f2, str(bc), str(tmp_path / f"py{both}"), **kw)
+        run_nat(f1, f2, str(bc), str(tmp_path / f"nat{both}"), **kw)
+        _same_tree(str(tmp_path / f"py{both}"), str(tmp_path / f"nat{both}"))
