@@ -116,7 +116,6 @@ int plan_generic(bdx_ctx *ctx) {
     size_t bc_total = 0;
     for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) bc_total += ctx->cfg.pass[k].bc_off[ctx->cfg.pass[k].n_barcodes];
     p.bc_stage_bytes = bc_total <= 32 * 1024 ? (int)((bc_total + 15) & ~(size_t)15) : 0;
-    if (p.bc_stage_bytes == 0 && bc_total > 0 && bc_total <= 32 * 1024) p.bc_stage_bytes = 16;
     p.hist_entries = d.n_counts <= 4096 ? d.n_counts : 0;
     const size_t fixed = (size_t)(B0 + 1 + B1 + 1 + B0 + B1) * 4 + 16 + (size_t)p.bc_stage_bytes + 16 +
                          (size_t)p.hist_entries * 4 + 16;
@@ -141,7 +140,6 @@ int plan_generic(bdx_ctx *ctx) {
                 "(limit: 64 lanes within 160 KiB)",
                 d.max_m, per_thread);
 }
-
 
 // ---- bit-parallel pre-filter: eligibility and tables (see bdx_bitpar.hip for the argument) ----
 int build_bitpar_tables(bdx_ctx *ctx) {
