@@ -313,12 +313,15 @@ int build_seed_tables(bdx_ctx *ctx) {
     const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
     if (expected * 3.0 > (double)total_bc) return BDX_OK;
     sp.q = q;
-    sp.bm_log2 = 2 * q < 13 ? 2 * q : 13;  // <= 8192 bits (1 KiB); hashed, so larger key spaces alias
+    // hashed bitmap, <= 32768 bits (4 KiB): at ~300 keys that is < 1 % false hits per position, so
+    // the per-read hit lists rarely overflow (an overflow costs a whole-read sweep of every barcode)
+    sp.bm_log2 = 2 * q < 14 ? 2 * q : 14;
     if (sp.bm_log2 < 5) sp.bm_log2 = 5;
     sp.bm_words = (1 << sp.bm_log2) / 32;
     sp.hash_log2 = 8;
     while ((1u << sp.hash_log2) < pieces.size() * 2) sp.hash_log2++;
     std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
+    std::vector<uint8_t> hash_ps((size_t)1 << sp.hash_log2, 0);
     const uint32_t hmask = (1u << sp.hash_log2) - 1;
     for (const Piece &pc : pieces) {
         const bdx_pass_t &p = c.pass[pc.pass];
@@ -328,19 +331,24 @@ int build_seed_tables(bdx_ctx *ctx) {
         bitmap[hb >> 5] |= 1u << (hb & 31);
         const uint32_t entry = (key << 16) | ((uint32_t)pc.pass << 15) | (uint32_t)(pc.b + 1);
         uint32_t slot = (key * 0x9E3779B1u) >> (32 - sp.hash_log2);
+        // one entry per (key, barcode, piece start): two pieces of one barcode may share a key
         bool dup = false;
         while (hash[slot] != 0) {
-            if (hash[slot] == entry) { dup = true; break; }
+            if (hash[slot] == entry && hash_ps[slot] == (uint8_t)pc.start) { dup = true; break; }
             slot = (slot + 1) & hmask;
         }
-        if (!dup) hash[slot] = entry;
+        if (!dup) {
+            hash[slot] = entry;
+            hash_ps[slot] = (uint8_t)pc.start;
+        }
     }
-    size_t bytes = bitmap.size() * 4 + hash.size() * 4;
+    size_t bytes = bitmap.size() * 4 + hash.size() * 4 + ((hash_ps.size() + 15) & ~(size_t)15);
     const size_t o_always[2] = {bytes, bytes + ((always[0].size() * 2 + 15) & ~(size_t)15)};
     bytes = o_always[1] + ((always[1].size() * 2 + 15) & ~(size_t)15) + 16;
     std::vector<uint8_t> blob(bytes, 0);
     memcpy(blob.data(), bitmap.data(), bitmap.size() * 4);
     memcpy(blob.data() + bitmap.size() * 4, hash.data(), hash.size() * 4);
+    memcpy(blob.data() + bitmap.size() * 4 + hash.size() * 4, hash_ps.data(), hash_ps.size());
     for (int k = 0; k < 2; ++k)
         if (!always[k].empty()) memcpy(blob.data() + o_always[k], always[k].data(), always[k].size() * 2);
     HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
@@ -348,6 +356,7 @@ int build_seed_tables(bdx_ctx *ctx) {
     const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
     sp.d_bitmap = (const uint32_t *)base;
     sp.d_hash = (const uint32_t *)(base + bitmap.size() * 4);
+    sp.d_hash_ps = base + bitmap.size() * 4 + hash.size() * 4;
     for (int k = 0; k < 2; ++k) {
         sp.n_always[k] = (int)always[k].size();
         sp.d_always[k] = (const uint16_t *)(base + o_always[k]);

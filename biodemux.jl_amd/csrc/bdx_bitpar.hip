@@ -53,6 +53,7 @@ struct BitparArgs {
     int seed_n_always[2];
     const uint32_t *seed_bitmap;
     const uint32_t *seed_hash;
+    const uint8_t *seed_hash_ps;
     const uint16_t *seed_always[2];
     uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
@@ -64,7 +65,9 @@ struct BitparArgs {
 
 template <int BS, int R, bool SEED>
 __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
-    constexpr int SQCAP = 8 * R;  // capacity of the seed-hit and pair queues
+    constexpr int SQCAP = 8 * R;  // capacity of the seed-hit queue
+    constexpr int PQCAP = 4 * R;  // capacity of the sweep-record queue
+    constexpr int RCAP = 8;       // merged sweep records per read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -113,9 +116,14 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
     LDS uint32_t *shash = (LDS uint32_t *)take(SEED ? ((size_t)4 << a.seed_hash_log2) : 0);
     LDS unsigned char *spk = take(SEED ? (size_t)R * (a.seed_groups + 4) : 0);
-    LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
-    LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);
-    LDS uint32_t *seedm = (LDS uint32_t *)take(SEED ? (size_t)R * (cw0 + cw1) * 4 : 0);
+    LDS unsigned char *shps = take(SEED ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
+    LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);      // seed hits: position << 16 | key
+    LDS unsigned char *shr = take(SEED ? (size_t)SQCAP : 0);                       // ... and their read
+    LDS uint32_t *srid = (LDS uint32_t *)take(SEED ? (size_t)R * RCAP * 4 : 0);   // per-read sweep records: id
+    LDS int *srlo = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window start (min)
+    LDS int *srhi = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
+    LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // read << 16 | pass << 15 | barcode + 1
+    LDS uint32_t *spw = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // window lo << 16 | hi
     LDS int *sqn = (LDS int *)take(16);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
@@ -140,7 +148,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
     if (SEED) {
         for (int i = tid; i < a.seed_bm_words; i += BS) sbm[i] = a.seed_bitmap[i];
-        for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) shash[i] = a.seed_hash[i];
+        for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) {
+            shash[i] = a.seed_hash[i];
+            shps[i] = a.seed_hash_ps[i];
+        }
     }
     __syncthreads();
     const int bytes0 = (int)off0[B0];
@@ -162,8 +173,12 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
     for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
     if (SEED) {
-        for (int i = tid; i < R * (cw0 + cw1); i += BS) seedm[i] = 0;
         for (int i = tid; i < R; i += BS) sall[i] = 0;
+        for (int i = tid; i < R * RCAP; i += BS) {
+            srid[i] = 0u;
+            srlo[i] = 0x7FFFFFFF;
+            srhi[i] = 0;
+        }
         if (tid < 2) sqn[tid] = 0;
     }
     if (tid == 0) sqn[3] = 0;
@@ -271,7 +286,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             uint32_t Pv, Mv;
             int score, best, ncol, r, b, p;
         };
-        auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w) {
+        // wlo_rel / whi_rel: optional column sub-window [lo, hi) relative to the read's first staged
+        // base (seeded path); (0, 0xFFFF) = the whole pass window
+        auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w, const int wlo_rel = 0,
+                         const int whi_rel = 0xFFFF) {
             w.ncol = 0;
             w.r = 0;
             w.b = 0;
@@ -283,9 +301,10 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             w.score = 0;
             w.best = 0x7FFFFFFF;
             if (!valid) return;
-            const int jf = win[(p * 2 + 0) * R + r];
+            int jf = win[(p * 2 + 0) * R + r];
             int jl = win[(p * 2 + 1) * R + r];
             if (jl < jf) return;
+            const bool sub = whi_rel != 0xFFFF;
             w.r = r;
             w.b = b;
             w.Pv = (p ? pv1 : pv0)[b];
@@ -296,6 +315,15 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                 // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
                 const int nread = rlen[r];
                 jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
+            }
+            if (sub) {  // intersect with the seed window (1-based inclusive columns)
+                const int a1 = wlo[r] + wlo_rel + 1, b1 = wlo[r] + whi_rel;
+                jf = a1 > jf ? a1 : jf;
+                jl = b1 < jl ? b1 : jl;
+                if (jl < jf) {
+                    w.ncol = 0;
+                    return;
+                }
             }
             w.c = codes + roff[r] + (jf - 1);
             w.ncol = jl - jf + 1;
@@ -358,11 +386,18 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                 }
             }
         } else {
-            // ---- stage 0: q-gram seeds (pigeonhole) decide which pairs are swept at all ----
+            // ---- stage 0: q-gram seeds (pigeonhole) decide which pairs are swept, and WHERE ----
+            // A recordable alignment of barcode b has <= kb[b] operations, so one of its kb+1 pieces
+            // sits unchanged in the read; with the piece starting at barcode offset ps and found at
+            // read position pos, the alignment starts within kb of  diag = pos - ps  and ends no
+            // later than diag + m + kb.  Only that column window is swept (all windows of one
+            // (read, barcode) pair are merged into one).  The windowed minimum equals the
+            // whole-window minimum whenever the latter is <= kb — the only case anything
+            // downstream looks at.
             const int q = a.seed_q;
             const uint32_t kmask = (q >= 16) ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u);
             const int G = a.seed_groups;  // 4-base groups per read (uniform upper bound)
-            // 2-bit packing of every read, 4 bases per byte, aligned to the read start
+            // 2-bit packing of every read, 4 bases per byte, aligned to the first staged base
             for (int idx = tid; idx < nr * G; idx += BS) {
                 const int r = idx / G, g = idx - r * G;
                 const LDS unsigned char *c = codes + roff[r] + wlo[r] + 4 * g;
@@ -400,22 +435,27 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                     const uint32_t hb = (key * 0x9E3779B1u) >> (32 - a.seed_bm_log2);  // hashed bitmap index
                     if (pos >= lo && pos <= hi && ((sbm[hb >> 5] >> (hb & 31)) & 1u)) {
                         const int k = __hip_atomic_fetch_add(&sqn[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (k < SQCAP)
-                            shq[k] = ((uint32_t)r << 16) | key;
-                        else
+                        if (k < SQCAP) {
+                            shq[k] = ((uint32_t)(pos - base) << 16) | key;
+                            shr[k] = (unsigned char)r;
+                        } else {
                             sall[r] = 1;  // hit queue full: sweep every barcode of this read instead
+                        }
                     }
                 }
             }
             __syncthreads();
-            // resolve hits through the hash table -> de-duplicated (read, pass, barcode) pair queue
+            // resolve: one lane per hit probes the hash table; every (pass, barcode) it finds is merged
+            // into the read's small record table (CAS on the id, atomic min/max on the window)
             {
                 const int nh = sqn[0] < SQCAP ? sqn[0] : SQCAP;
                 const uint32_t hmask = (1u << a.seed_hash_log2) - 1u;
                 for (int k = tid; k < nh; k += BS) {
                     const uint32_t h = shq[k];
-                    const int r = (int)(h >> 16);
+                    const int t = shr[k];
+                    const int prel = (int)(h >> 16);
                     const uint32_t key = h & 0xFFFFu;
+                    const int wl_r = wlen[t];
                     uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.seed_hash_log2);
                     for (;;) {
                         const uint32_t e = shash[slot];
@@ -423,49 +463,81 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                         if ((e >> 16) == key) {
                             const int p = (int)((e >> 15) & 1u);
                             const int b = (int)(e & 0x7FFFu) - 1;
-                            LDS uint32_t *sm = seedm + (p ? R * cw0 : 0) + r * (p ? cw1 : cw0) + (b >> 5);
-                            const uint32_t old = __hip_atomic_fetch_or(sm, 1u << (b & 31), __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (!((old >> (b & 31)) & 1u)) {
-                                const int kk = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED,
-                                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (kk < SQCAP)
-                                    spq[kk] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)b;
-                                else
-                                    sall[r] = 1;
+                            const int kk = (p ? kb1 : kb0)[b];
+                            const int mm = __builtin_popcount((p ? pv1 : pv0)[b]);
+                            const int diag = prel - (int)shps[slot];
+                            int lo = diag - kk - 1, hi = diag + mm + kk + 1;  // [lo, hi) relative to the staged base
+                            if (lo < 0) lo = 0;
+                            if (hi > wl_r) hi = wl_r;
+                            const uint32_t pb = e & 0xFFFFu;  // pass << 15 | barcode + 1  (never 0)
+                            int rs = (int)(pb & (RCAP - 1));
+                            bool placed = false;
+                            for (int tries = 0; tries < RCAP && !placed; ++tries) {
+                                LDS uint32_t *id = srid + t * RCAP + rs;
+                                uint32_t old = *id;
+                                if (old == 0u) {
+                                    uint32_t expect = 0u;
+                                    __hip_atomic_compare_exchange_strong(id, &expect, pb, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    old = expect == 0u ? pb : expect;
+                                }
+                                if (old == pb) {
+                                    __hip_atomic_fetch_min(&srlo[t * RCAP + rs], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_max(&srhi[t * RCAP + rs], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    placed = true;
+                                }
+                                rs = (rs + 1) & (RCAP - 1);
                             }
+                            if (!placed) sall[t] = 1;  // more than RCAP distinct barcodes seeded in this read
                         }
                         slot = (slot + 1) & hmask;
                     }
                 }
-                // barcodes that are swept unconditionally (wildcards, pieces shorter than 5)
-                for (int p = 0; p < npass; ++p) {
-                    const int na = a.seed_n_always[p];
-                    for (int idx = tid; idx < nr * na; idx += BS) {
-                        const int r = idx / na;
-                        const int b = a.seed_always[p][idx - r * na];
-                        const int kk = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (kk < SQCAP)
-                            spq[kk] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)b;
-                        else
-                            sall[r] = 1;
+            }
+            __syncthreads();
+            // emit: every occupied record becomes one sweep
+            for (int idx = tid; idx < nr * RCAP; idx += BS) {
+                const uint32_t pb = srid[idx];
+                if (pb != 0u) {
+                    const int t = idx / RCAP;
+                    const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (kq < PQCAP) {
+                        spq[kq] = ((uint32_t)t << 16) | pb;
+                        spw[kq] = ((uint32_t)srlo[idx] << 16) | (uint32_t)srhi[idx];
+                    } else {
+                        sall[t] = 1;
+                    }
+                }
+            }
+            // barcodes that are swept unconditionally (wildcards, pieces shorter than 5): whole window
+            for (int p = 0; p < npass; ++p) {
+                const int na = a.seed_n_always[p];
+                for (int idx = tid; idx < nr * na; idx += BS) {
+                    const int r = idx / na;
+                    const int b = a.seed_always[p][idx - r * na];
+                    const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (kq < PQCAP) {
+                        spq[kq] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)(b + 1);
+                        spw[kq] = 0x0000FFFFu;
+                    } else {
+                        sall[r] = 1;
                     }
                 }
             }
             __syncthreads();
             {
-                const int np = (a.dbg & 2) ? 0 : (sqn[1] < SQCAP ? sqn[1] : SQCAP);
+                const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
                 for (int k = tid; k < np; k += 2 * BS) {
                     Sweep A, Bw;
-                    const uint32_t ea = spq[k];
+                    const uint32_t ea = spq[k], wa = spw[k];
                     const bool hb = k + BS < np;
-                    const uint32_t eb = hb ? spq[k + BS] : 0u;
+                    const uint32_t eb = hb ? spq[k + BS] : 0u, wb = hb ? spw[k + BS] : 0u;
                     const int ra = (int)(ea >> 16), rb = (int)(eb >> 16);
-                    setup(!sall[ra], (int)((ea >> 15) & 1u), ra, (int)(ea & 0x7FFFu), A);
-                    setup(hb && !sall[rb], (int)((eb >> 15) & 1u), rb, (int)(eb & 0x7FFFu), Bw);
+                    setup(!sall[ra], (int)((ea >> 15) & 1u), ra, (int)(ea & 0x7FFFu) - 1, A, (int)(wa >> 16), (int)(wa & 0xFFFFu));
+                    setup(hb && !sall[rb], (int)((eb >> 15) & 1u), rb, (int)(eb & 0x7FFFu) - 1, Bw, (int)(wb >> 16), (int)(wb & 0xFFFFu));
                     sweep2(A, Bw);
                 }
-                // reads whose queues overflowed: every barcode, exactly once
+                // reads whose lists overflowed: every barcode over the whole window, exactly once
                 for (int p = 0; p < npass; ++p) {
                     const int B = p ? B1 : B0;
                     const int total = (a.dbg & 2) ? 0 : nr * B;
@@ -476,8 +548,8 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
                         const bool va = sall[rA] != 0;
                         const bool vb = pb < total && sall[rB < nr ? rB : 0] != 0;
                         if (!__builtin_amdgcn_ballot_w64(va || vb)) continue;
-                        setup(va, p, rA, pair - rA * B, A);
-                        setup(vb, p, rB, pb - rB * B, Bw);
+                        setup(va, p, rA, pair - rA * B, A, 0, 0xFFFF);
+                        setup(vb, p, rB, pb - rB * B, Bw, 0, 0xFFFF);
                         sweep2(A, Bw);
                     }
                 }
@@ -627,7 +699,8 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     if (sp && sp->enabled) {
         const int G = (bp.seed_span + 3) / 4 + 1;
         o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
-        o += 2 * al((size_t)8 * R * 4) + al((size_t)R * (cw0 + cw1) * 4) + al((size_t)R);
+        o += al((size_t)1 << sp->hash_log2) + al((size_t)8 * R * 4) + al((size_t)8 * R) + 3 * al((size_t)R * 8 * 4);
+        o += 2 * al((size_t)4 * R * 4) + al((size_t)R);
     }
     o += al(16);
     return o;
@@ -675,6 +748,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_bm_log2 = sp.bm_log2;
     a.seed_bitmap = sp.d_bitmap;
     a.seed_hash = sp.d_hash;
+    a.seed_hash_ps = sp.d_hash_ps;
     for (int k = 0; k < 2; ++k) {
         a.seed_n_always[k] = sp.n_always[k];
         a.seed_always[k] = sp.d_always[k];

@@ -102,6 +102,7 @@ struct BdxSeedPlan {
     int n_always[2];       // barcodes swept unconditionally (wildcards / too-short pieces)
     const uint32_t *d_bitmap;
     const uint32_t *d_hash;
+    const uint8_t *d_hash_ps;      // piece start offset (bases) of every hash entry
     const uint16_t *d_always[2];
 };
 
