@@ -424,6 +424,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
         if (forced && R != forced) continue;
+        if (!forced && !ctx->splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
         size_t st = slot_mode ? (size_t)R * (size_t)slot : (size_t)R * (size_t)read_len + 64;
         st = (st + 15) & ~(size_t)15;
         if (st > (size_t)1 << 20) continue;
