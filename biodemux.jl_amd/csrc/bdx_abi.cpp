@@ -452,6 +452,12 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         bp.read_len_hint_for_lds = read_len;
         return true;
     }
+    if (ctx->splan.enabled) {
+        // the seed tables do not fit next to everything else (very many barcodes): keep the
+        // sweep filter, drop the seeds, and plan again
+        ctx->splan.enabled = 0;
+        return size_bitpar(ctx, read_len);
+    }
     bp.reads_per_block = 0;
     bp.read_len_hint = 0;
     return false;

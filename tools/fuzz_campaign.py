@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Long differential campaign (not part of the default test-suite): many random configs and a few
+stress shapes, every filter mode against the oracle."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import fuzz
+import helpers as H
+from biodemux_jl_amd import synth
+
+lo, hi = int(os.environ.get("SEED_LO", "1000")), int(os.environ.get("SEED_HI", "1600"))
+bad = 0
+t0 = time.time()
+paths = {}
+for seed in range(lo, hi):
+    cfg, seq, off = fuzz.random_case(seed, n_reads=int(os.environ.get("READS", "500")))
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "bitpar", "auto"):
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+                got = hc.classify(seq, off)
+                paths[hc.kernel_path] = paths.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"seed {seed} filter {flt} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), f"seed {seed} counters"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"fuzz seeds {lo}..{hi - 1}: {bad} mismatches, paths {paths}, {time.time() - t0:.0f} s", flush=True)
+
+
+def stress(name, bcs, seq, off, **kw):
+    global bad
+    cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
+                            ids=[str(i) for i in range(len(bcs))], **kw)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
+    for flt in ("off", "auto"):
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+                fuzz.assert_same(hc.classify(seq, off), exp, f"{name} filter {flt} [{hc.kernel_path}]")
+                path = hc.kernel_path
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+    print(f"stress {name}: ok [{path}] matched {float((exp['bc1'] > 0).mean()):.2f}", flush=True)
+
+
+b = synth.make_barcodes(1500, 20, seed=3, min_hamming=5)
+s, o, _ = synth.make_reads(b, 6000, 100, seed=3)
+stress("B=1500 m=20 rate0.1", b, s, o, max_error_rate=0.1)
+stress("B=1500 m=20 rate0.1 trim3 delta", b, s, o, max_error_rate=0.1, trim_side=3, min_delta=0.06)
+b = synth.make_barcodes(3000, 16, seed=4, min_hamming=4)
+s, o, _ = synth.make_reads(b, 3000, 80, seed=4)
+stress("B=3000 m=16 (beyond the filter's barcode limit)", b, s, o, max_error_rate=0.13)
+b = synth.make_barcodes(12, 48, seed=5, min_hamming=12)
+s, o, _ = synth.make_reads(b, 4000, 200, seed=5)
+stress("m=48 (generic path)", b, s, o, max_error_rate=0.15)
+stress("m=48 trim5 (generic path)", b, s, o, max_error_rate=0.15, trim_side=5)
+b = synth.make_barcodes(4, 300, seed=6, min_hamming=60)
+s, o, _ = synth.make_reads(b, 600, 700, seed=6)
+stress("m=300 (LDS-limited geometry)", b, s, o, max_error_rate=0.1, trim_side=3)
+b = synth.make_barcodes(1, 24, seed=7)
+s, o, _ = synth.make_reads(b, 5, 150, seed=7)
+stress("B=1, 5 reads", b, s, o, max_error_rate=0.2)
+b = synth.make_barcodes(96, 24)
+s, o, _ = synth.make_reads(b, 70001, 150, seed=8)
+stress("70001 reads (ragged last tile)", b, s, o, max_error_rate=0.1)
+stress("negative match cost (filters off by domain)", b[:12], s[:150 * 3000], o[:3001], max_error_rate=0.2, match=-1, mismatch=2, indel=3)
+stress("iupac-ish alphabet (9 symbols: filter off)", ["ACGTRYKMSWACGTRYKMSW", "RYKMSWBDHVACGTACGTAC"], s[:150 * 2000], o[:2001], max_error_rate=0.2)
+print("TOTAL MISMATCHES", bad)
+sys.exit(1 if bad else 0)
