@@ -62,6 +62,7 @@ struct bdx_ctx {
     DevBuf d_seq, d_off, d_out_i32, d_out_f64;
     // candidate masks (filtered paths)
     DevBuf d_cand[2];
+    DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel
     std::string err;
     std::string path;
     int64_t launches = 0;
@@ -660,6 +661,8 @@ void bdx_destroy(bdx_ctx *ctx) {
         ctx->bc_off[k].release();
         ctx->bc_nn[k].release();
         ctx->d_cand[k].release();
+        ctx->d_wins[k].release();
+        ctx->d_wcnt[k].release();
     }
     ctx->counts_own.release();
     ctx->bp_tables.release();
@@ -730,18 +733,33 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         bool split = false;
         for (int k = 0; k < npass; ++k) split |= !ctx->bplan.known_ok[k];
         if (getenv("BDX_NO_SPLIT")) split = false;
-        uint32_t *c0 = nullptr, *c1 = nullptr;
+        uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
+        uint8_t *n0 = nullptr, *n1 = nullptr;
         if (split) {
-            for (int k = 0; k < npass; ++k)
+            const bool windows = ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !getenv("BDX_NO_WINDOWS");
+            for (int k = 0; k < npass; ++k) {
                 HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
+                if (windows) {
+                    HIP_TRY(ctx, ctx->d_wins[k].ensure((size_t)n_reads * BDX_WCAP * 3 * 4 + 64));
+                    HIP_TRY(ctx, ctx->d_wcnt[k].ensure((size_t)n_reads + 64));
+                }
+            }
             c0 = (uint32_t *)ctx->d_cand[0].p;
             c1 = npass > 1 ? (uint32_t *)ctx->d_cand[1].p : c0;
+            if (windows) {
+                w0 = (uint32_t *)ctx->d_wins[0].p;
+                n0 = (uint8_t *)ctx->d_wcnt[0].p;
+                w1 = npass > 1 ? (uint32_t *)ctx->d_wins[1].p : w0;
+                n1 = npass > 1 ? (uint8_t *)ctx->d_wcnt[1].p : n0;
+            }
         }
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes,
-                                       (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream));
+                                       (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
+                                       n1));
         if (split)
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                            ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream));
+                                            ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
+                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr));
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
         ctx->path = ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify";
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;

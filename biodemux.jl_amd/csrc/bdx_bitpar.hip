@@ -55,6 +55,8 @@ struct BitparArgs {
     const uint32_t *seed_hash;
     const uint8_t *seed_hash_ps;
     const uint16_t *seed_always[2];
+    uint32_t *wins_out[2];  // split mode: [n_reads][BDX_WCAP][3] = {barcode, first column, last column} of the exact run
+    uint8_t *wcnt_out[2];   // split mode: entries valid per read (255 = none: whole window)
     uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *srhi = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
     LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // read << 16 | pass << 15 | barcode + 1
     LDS uint32_t *spw = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // window lo << 16 | hi
-    LDS int *sqn = (LDS int *)take(16);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow
+    LDS int *sqn = (LDS int *)take(32);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow, [4] window-queue fill
+    LDS uint32_t *wq = (LDS uint32_t *)take((size_t)4 * R * 4);  // split mode: candidates to re-sweep with column tracking
+    LDS int *wcl = (LDS int *)take((size_t)2 * R * 4);          // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
     // ---- tables -> LDS ----
@@ -181,7 +185,11 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         }
         if (tid < 2) sqn[tid] = 0;
     }
-    if (tid == 0) sqn[3] = 0;
+    if (tid == 0) {
+        sqn[3] = 0;
+        sqn[4] = 0;
+    }
+    for (int i = tid; i < 2 * R; i += BS) wcl[i] = 0;
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
     const long long r0 = tile * R;
     long long r1 = r0 + R;
@@ -265,6 +273,102 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         __syncthreads();
     }
 
+    // ---- stage 1: Myers bit-vector sweep, one lane per (read, barcode) pair ----
+    // Two independent pairs per lane per trip: the recurrence is a serial chain of ~14
+    // dependent VALU ops per column, a second chain fills the issue slots the first leaves.
+    const bool sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
+    struct Sweep {
+        const LDS unsigned char *c;
+        const LDS unsigned char *pq;
+        uint32_t Pv, Mv;
+        int score, best, ncol, r, b, p;
+    };
+    // wlo_rel / whi_rel: optional column sub-window [lo, hi) relative to the read's first staged
+    // base (seeded path); (0, 0xFFFF) = the whole pass window
+    auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w, const int wlo_rel = 0,
+                     const int whi_rel = 0xFFFF) {
+        w.ncol = 0;
+        w.r = 0;
+        w.b = 0;
+        w.p = p;
+        w.c = codes;
+        w.pq = (const LDS unsigned char *)peq0;
+        w.Pv = 0;
+        w.Mv = 0;
+        w.score = 0;
+        w.best = 0x7FFFFFFF;
+        if (!valid) return;
+        int jf = win[(p * 2 + 0) * R + r];
+        int jl = win[(p * 2 + 1) * R + r];
+        if (jl < jf) return;
+        const bool sub = whi_rel != 0xFFFF;
+        w.r = r;
+        w.b = b;
+        w.Pv = (p ? pv1 : pv0)[b];
+        w.score = __builtin_popcount(w.Pv);  // = barcode length m
+        w.best = w.score;
+        if (!sg) {
+            // :hamming / :exact bound the START positions by the window (SURVEY Q11,
+            // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
+            const int nread = rlen[r];
+            jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
+        }
+        if (sub) {  // intersect with the seed window (1-based inclusive columns)
+            const int a1 = wlo[r] + wlo_rel + 1, b1 = wlo[r] + whi_rel;
+            jf = a1 > jf ? a1 : jf;
+            jl = b1 < jl ? b1 : jl;
+            if (jl < jf) {
+                w.ncol = 0;
+                return;
+            }
+        }
+        w.c = codes + roff[r] + (jf - 1);
+        w.ncol = jl - jf + 1;
+        w.pq = (const LDS unsigned char *)((p ? peq1 : peq0) + b);
+    };
+    auto step = [&](Sweep &w, const int j, const int sh) {
+        const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
+        const uint32_t Xv = Eq | w.Mv;
+        const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
+        uint32_t Ph = w.Mv | ~(Xh | w.Pv);
+        uint32_t Mh = w.Pv & Xh;
+        w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph += Ph;  // << 1 as an add: full-rate on gfx950, shifts are not
+        Mh += Mh;
+        w.Pv = Mh | ~(Xv | Ph);
+        w.Mv = Ph & Xv;
+        w.best = w.score < w.best ? w.score : w.best;
+    };
+    auto finish = [&](const Sweep &w) {
+        if (w.ncol > 0 && w.best <= (w.p ? kb1 : kb0)[w.b]) {
+            const int cw = w.p ? cw1 : cw0;
+            LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
+            __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (full[w.p * R + w.r]) {
+                const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (k < 4) slots[(w.p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
+            }
+        }
+    };
+    auto sweep2 = [&](Sweep &A, Sweep &Bw) {
+        // both chains use the same symbol shift only when they belong to the same pass;
+        // the shifts are per chain (uniform in the non-seeded path, per lane otherwise)
+        const int shA = a.bshift[A.p], shB = a.bshift[Bw.p];
+        const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
+        int j = 0;
+#pragma unroll 4
+        for (; j < common; ++j) {
+            step(A, j, shA);
+            step(Bw, j, shB);
+        }
+        for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
+        for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
+        finish(A);
+        finish(Bw);
+    };
+
     if (staged) {
         // ---- transcode bytes -> symbol codes (4 per lane per step) ----
         const int nvec4 = (int)((need + 3) >> 2);
@@ -275,102 +379,6 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             ((LDS uint32_t *)codes)[k] = c;
         }
         __syncthreads();
-
-        // ---- stage 1: Myers bit-vector sweep, one lane per (read, barcode) pair ----
-        // Two independent pairs per lane per trip: the recurrence is a serial chain of ~14
-        // dependent VALU ops per column, a second chain fills the issue slots the first leaves.
-        const bool sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
-        struct Sweep {
-            const LDS unsigned char *c;
-            const LDS unsigned char *pq;
-            uint32_t Pv, Mv;
-            int score, best, ncol, r, b, p;
-        };
-        // wlo_rel / whi_rel: optional column sub-window [lo, hi) relative to the read's first staged
-        // base (seeded path); (0, 0xFFFF) = the whole pass window
-        auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w, const int wlo_rel = 0,
-                         const int whi_rel = 0xFFFF) {
-            w.ncol = 0;
-            w.r = 0;
-            w.b = 0;
-            w.p = p;
-            w.c = codes;
-            w.pq = (const LDS unsigned char *)peq0;
-            w.Pv = 0;
-            w.Mv = 0;
-            w.score = 0;
-            w.best = 0x7FFFFFFF;
-            if (!valid) return;
-            int jf = win[(p * 2 + 0) * R + r];
-            int jl = win[(p * 2 + 1) * R + r];
-            if (jl < jf) return;
-            const bool sub = whi_rel != 0xFFFF;
-            w.r = r;
-            w.b = b;
-            w.Pv = (p ? pv1 : pv0)[b];
-            w.score = __builtin_popcount(w.Pv);  // = barcode length m
-            w.best = w.score;
-            if (!sg) {
-                // :hamming / :exact bound the START positions by the window (SURVEY Q11,
-                // classification.jl:490-491, :570-571); the occurrence itself reaches m-1 further
-                const int nread = rlen[r];
-                jl = jl + w.score - 1 < nread ? jl + w.score - 1 : nread;
-            }
-            if (sub) {  // intersect with the seed window (1-based inclusive columns)
-                const int a1 = wlo[r] + wlo_rel + 1, b1 = wlo[r] + whi_rel;
-                jf = a1 > jf ? a1 : jf;
-                jl = b1 < jl ? b1 : jl;
-                if (jl < jf) {
-                    w.ncol = 0;
-                    return;
-                }
-            }
-            w.c = codes + roff[r] + (jf - 1);
-            w.ncol = jl - jf + 1;
-            w.pq = (const LDS unsigned char *)((p ? peq1 : peq0) + b);
-        };
-        auto step = [&](Sweep &w, const int j, const int sh) {
-            const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
-            const uint32_t Xv = Eq | w.Mv;
-            const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
-            uint32_t Ph = w.Mv | ~(Xh | w.Pv);
-            uint32_t Mh = w.Pv & Xh;
-            w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
-            Ph += Ph;  // << 1 as an add: full-rate on gfx950, shifts are not
-            Mh += Mh;
-            w.Pv = Mh | ~(Xv | Ph);
-            w.Mv = Ph & Xv;
-            w.best = w.score < w.best ? w.score : w.best;
-        };
-        auto finish = [&](const Sweep &w) {
-            if (w.ncol > 0 && w.best <= (w.p ? kb1 : kb0)[w.b]) {
-                const int cw = w.p ? cw1 : cw0;
-                LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
-                __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (full[w.p * R + w.r]) {
-                    const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (k < 4) slots[(w.p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
-                }
-            }
-        };
-        auto sweep2 = [&](Sweep &A, Sweep &Bw) {
-            // both chains use the same symbol shift only when they belong to the same pass;
-            // the shifts are per chain (uniform in the non-seeded path, per lane otherwise)
-            const int shA = a.bshift[A.p], shB = a.bshift[Bw.p];
-            const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
-            int j = 0;
-#pragma unroll 4
-            for (; j < common; ++j) {
-                step(A, j, shA);
-                step(Bw, j, shB);
-            }
-            for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
-            for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
-            finish(A);
-            finish(Bw);
-        };
 
         if (!SEED) {
             for (int p = 0; p < npass; ++p) {
@@ -567,6 +575,69 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             uint32_t *dst = a.cand_out[p] + r0 * cw;
             for (int i = tid; i < nr * cw; i += BS) dst[i] = staged ? cnd[i] : 0xFFFFFFFFu;
         }
+        if (a.wins_out[0]) {
+            // Column windows for the exact kernel: every surviving candidate is swept
+            // once more over its whole pass window while tracking the first / last column whose unit
+            // distance is <= kb; recordable alignments end inside [e_lo, e_hi] and start at most m + kb
+            // earlier, and another m + kb + 1 columns of warm-up make every cell <= allowed_error
+            // independent of the fresh start -> the exact DP runs over e_lo - 2(m+kb) - 1 .. e_hi only.
+            constexpr int WQCAP = 4 * R;
+            if (staged) {
+                for (int idx = tid; idx < nr * (cw0 + cw1); idx += BS) {
+                    const int p = idx >= nr * cw0 ? 1 : 0;
+                    const int loc = p ? idx - nr * cw0 : idx;
+                    const int cw = p ? cw1 : cw0;
+                    const int r = loc / cw, w = loc - r * cw;
+                    uint32_t bits = cand[(p ? R * cw0 : 0) + r * cw + w];
+                    while (bits) {
+                        const int b = w * 32 + __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const int k = __hip_atomic_fetch_add(&sqn[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k < WQCAP) wq[k] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)b;
+                    }
+                }
+            }
+            __syncthreads();
+            const int nq = sqn[4];
+            const bool usable = staged && nq <= WQCAP;  // overflow / unstaged tile: no windows, whole-window DP
+            if (usable) {
+                for (int k = tid; k < nq; k += BS) {
+                    const uint32_t e = wq[k];
+                    const int r = (int)(e >> 16), p = (int)((e >> 15) & 1u), b = (int)(e & 0x7FFFu);
+                    Sweep A;
+                    setup(true, p, r, b, A);
+                    const int kbv = (p ? kb1 : kb0)[b];
+                    const int mm = A.score;  // barcode length before the first column
+                    const int sh = a.bshift[p];
+                    const int jf_abs = (int)(A.c - (codes + roff[r])) + 1;
+                    int e_lo = 0, e_hi = -1;
+                    for (int j = 0; j < A.ncol; ++j) {
+                        step(A, j, sh);
+                        if (A.score <= kbv) {
+                            if (e_hi < 0) e_lo = jf_abs + j;
+                            e_hi = jf_abs + j;
+                        }
+                    }
+                    if (e_hi >= 0) {
+                        const int kk = __hip_atomic_fetch_add(&wcl[p * R + r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (kk < BDX_WCAP) {
+                            uint32_t *dst = a.wins_out[p] + ((r0 + r) * BDX_WCAP + kk) * 3;
+                            dst[0] = (uint32_t)b;
+                            dst[1] = (uint32_t)(e_lo - 2 * (mm + kbv) - 1);
+                            dst[2] = (uint32_t)e_hi;
+                        }
+                    } else {
+                        wcl[p * R + r] = 1000;  // cannot happen for a candidate; if it did: no restriction
+                    }
+                }
+            }
+            __syncthreads();
+            for (int p = 0; p < npass; ++p)
+                for (int t = tid; t < nr; t += BS) {
+                    const int c = wcl[p * R + t];
+                    a.wcnt_out[p][r0 + t] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
+                }
+        }
         continue;
     }
 
@@ -702,14 +773,15 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
         o += al((size_t)1 << sp->hash_log2) + al((size_t)8 * R * 4) + al((size_t)8 * R) + 3 * al((size_t)R * 8 * 4);
         o += 2 * al((size_t)4 * R * 4) + al((size_t)R);
     }
-    o += al(16);
+    o += al(32) + al((size_t)4 * R * 4) + al((size_t)2 * R * 4);
     return o;
 }
 
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1,
-                             hipStream_t stream) {
+                             hipStream_t stream, uint32_t *wins_out0, uint32_t *wins_out1, uint8_t *wcnt_out0,
+                             uint8_t *wcnt_out1) {
     if (n_reads <= 0) return hipSuccess;
     BitparArgs a;
     a.cfg = cfg;
@@ -737,6 +809,10 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.ncode = bp.ncode_N;
     a.cand_out[0] = cand_out0;
     a.cand_out[1] = cand_out1;
+    a.wins_out[0] = wins_out0;
+    a.wins_out[1] = wins_out1;
+    a.wcnt_out[0] = wcnt_out0;
+    a.wcnt_out[1] = wcnt_out1;
     a.tile_counter = bp.d_tile_counter;
     a.known_ok[0] = bp.known_ok[0];
     a.known_ok[1] = bp.known_ok[1];

@@ -58,8 +58,9 @@ __device__ __forceinline__ void resolve_range(const BdxDevRange &dr, long long l
 template <bool TB, bool NS, bool STAGED>
 __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int S, const Bytes<STAGED> q,
                                             const int m, const Bytes<STAGED> r, const int n, const int ae,
-                                            const Costs c, const int trim_side, int first, const int last,
-                                            const int max_start, const int min_end) {
+                                            const Costs c, const int trim_side, int first, int last,
+                                            const int max_start, const int min_end,
+                                            const int jlo = -0x40000000, const int jhi = 0x40000000) {
     AlignOut res{BDX_INF32, -1, -1};
     if (m == 0 || n == 0) return res;  // :250-252
 
@@ -76,6 +77,10 @@ __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int 
     }
 
     int lact = (ae + 1 < m) ? ae + 1 : m;  // :286
+    // restricted run: columns outside jlo..jhi can neither record anything nor
+    // influence a cell <= allowed_error inside — the loop bounds are the only thing that changes
+    if (jlo > first) first = jlo;
+    if (jhi < last) last = jhi;
     for (int j = first; j <= last; ++j) {  // :287
         int prev_o = j;                    // :288
         int fact, prev;
@@ -164,8 +169,9 @@ __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int 
 template <bool TB, bool NS, int M, bool STAGED>
 __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
                                                 const int n, const int ae, const Costs c, const int trim_side,
-                                                int first, const int last, const int max_start,
-                                                const int min_end) {
+                                                int first, int last, const int max_start,
+                                                const int min_end, const int jlo = -0x40000000,
+                                                const int jhi = 0x40000000) {
     AlignOut res{BDX_INF32, -1, -1};
     if (m == 0 || n == 0) return res;  // :250-252
 
@@ -192,6 +198,8 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
     }
 
     int lact = (ae + 1 < m) ? ae + 1 : m;  // :286
+    if (jlo > first) first = jlo;  // restricted run, DESIGN.md §3.2
+    if (jhi < last) last = jhi;
     for (int j = first; j <= last; ++j) {  // :287
         int prev_o = j;                    // :288
         int fact, prev;
@@ -461,7 +469,8 @@ template <bool STAGED, int REGM = 0>
 __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPass &P, const Bytes<STAGED> bcb,
                                             const LDS uint32_t *bc_off, const LDS int *bc_nn,
                                             const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
-                                            const int S, const uint32_t *cand, const int ncode = 0x4E) {
+                                            const int S, const uint32_t *cand, const int ncode = 0x4E,
+                                            const uint32_t *went = nullptr, const int wcount = 255) {
     PassOut po{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     PassWindow w;
     if (!pass_window(P, n, w)) return po;  // :805-807
@@ -507,17 +516,27 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : 0.0;
         } else {
+            // column restriction of this candidate (split mode hands over up to BDX_WCAP entries
+            // {barcode, first column, last column} per read and pass; none -> the whole window)
+            int cjlo = -0x40000000, cjhi = 0x40000000;
+            if (wcount <= BDX_WCAP) {
+                for (int e = 0; e < wcount; ++e)
+                    if ((int)went[3 * e] == b) {
+                        cjlo = (int)went[3 * e + 1];
+                        cjhi = (int)went[3 * e + 2];
+                    }
+            }
             const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476
             const int ae = (int)__builtin_floor(red.rate * (double)norm);  // :254
             if (cfg.has_nindel) {
-                a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
-                            : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
+                a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
+                            : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             } else if (REGM > 0) {
-                a = need_tb ? sg_core_reg<true, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
-                            : sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
+                a = need_tb ? sg_core_reg<true, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
+                            : sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             } else {
-                a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end)
-                            : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end);
+                a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
+                            : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             }
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)norm;  // :155-168
         }
@@ -590,19 +609,21 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
                                              Verdict &v, PassOut &p1, PassOut &p2,
                                              const KnownPass kn0 = KnownPass{false, 0, 0, 0, 0, 0},
                                              const KnownPass kn1 = KnownPass{false, 0, 0, 0, 0, 0},
-                                             const int ncode = 0x4E) {
+                                             const int ncode = 0x4E, const uint32_t *went0 = nullptr,
+                                             const int wcount0 = 255, const uint32_t *went1 = nullptr,
+                                             const int wcount1 = 255) {
     // determine_filename, classification.jl:871-938
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     p1 = kn0.use ? run_pass_known(cfg, off0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
-                 : run_pass<STAGED, REGM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode);  // :875
+                 : run_pass<STAGED, REGM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode, went0, wcount0);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.use ? run_pass_known(cfg, off1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
-                     : run_pass<STAGED, REGM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode);
+                     : run_pass<STAGED, REGM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode, went1, wcount1);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

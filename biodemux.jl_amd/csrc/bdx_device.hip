@@ -34,6 +34,8 @@ struct GenericArgs {
     unsigned long long *counts;
     const uint32_t *cand0;  // [n_reads][cand_words] or null
     const uint32_t *cand1;
+    const uint32_t *wins[2];  // [n_reads][BDX_WCAP][3] column-window entries per pass, or null
+    const uint8_t *wcnt[2];   // [n_reads] entries valid (255: none -> whole window)
     int dp_rows;
     int stage_bytes;    // capacity of the read staging area (0: never stage)
     int bc_stage_bytes; // bytes of the barcode staging area (both passes; 0: barcodes not staged)
@@ -124,14 +126,21 @@ __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
         const uint32_t *c1 = a.cand1 ? a.cand1 + ridx * cfg.pass[1].cand_words : nullptr;
         LDS int *DP = DPbase + tid;
         LDS int *OG = OGbase + tid;
+        const uint32_t *we0 = a.wins[0] ? a.wins[0] + ridx * (BDX_WCAP * 3) : nullptr;
+        const uint32_t *we1 = a.wins[1] ? a.wins[1] + ridx * (BDX_WCAP * 3) : nullptr;
+        const int wc0 = a.wcnt[0] ? (int)a.wcnt[0][ridx] : 255;
+        const int wc1 = a.wcnt[1] ? (int)a.wcnt[1][ridx] : 255;
+        const KnownPass nokn{false, 0, 0, 0, 0, 0};
         if (staged) {
             Bytes<true> r{rstage + head + (ro - span0)};
             Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            classify_one<true, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
+            classify_one<true, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn, 0x4E, we0,
+                                     wc0, we1, wc1);
         } else {
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
-            classify_one<false, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2);
+            classify_one<false, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn, 0x4E,
+                                      we0, wc0, we1, wc1);
         }
         // outputs (coalesced: consecutive lanes -> consecutive reads)
         if (a.out.bc1) a.out.bc1[ridx] = v.bc1;
@@ -238,7 +247,8 @@ hipError_t bdx_generic_set_lds_limit(size_t bytes) {
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,
                               const long long *d_off, long long n_reads, const BdxDevOut &out,
                               unsigned long long *d_counts, const uint32_t *d_cand0, const uint32_t *d_cand1,
-                              hipStream_t stream) {
+                              hipStream_t stream, const uint32_t *d_wins0, const uint32_t *d_wins1,
+                              const uint8_t *d_wcnt0, const uint8_t *d_wcnt1) {
     if (n_reads <= 0) return hipSuccess;
     GenericArgs a;
     a.cfg = cfg;
@@ -249,6 +259,10 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     a.counts = d_counts;
     a.cand0 = d_cand0;
     a.cand1 = d_cand1;
+    a.wins[0] = d_wins0;
+    a.wins[1] = d_wins1;
+    a.wcnt[0] = d_wcnt0;
+    a.wcnt[1] = d_wcnt1;
     a.dp_rows = plan.dp_rows;
     a.stage_bytes = plan.stage_bytes;
     a.bc_stage_bytes = plan.bc_stage_bytes;

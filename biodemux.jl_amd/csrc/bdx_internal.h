@@ -16,6 +16,7 @@
 #define BDX_MAX_COST 32767
 #define BDX_MAX_M 8192
 #define BDX_MAX_RATE 1.0e4
+#define BDX_WCAP 4       // column-window entries per read and pass handed from the filter to the exact kernel
 #define BDX_REG_ROWS 32  // barcodes up to this length run the register-resident exact DP
 
 struct BdxDevRange {
@@ -111,7 +112,9 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
                             const BdxSeedPlan *sp = nullptr);
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
-                             unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1, hipStream_t stream);
+                             unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1, hipStream_t stream,
+                             uint32_t *wins_out0 = nullptr, uint32_t *wins_out1 = nullptr, uint8_t *wcnt_out0 = nullptr,
+                             uint8_t *wcnt_out1 = nullptr);
 // max read length of a device-resident batch (one tiny kernel; result written to *d_out)
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
 
@@ -119,5 +122,7 @@ hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_o
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,
                               const long long *d_off, long long n_reads, const BdxDevOut &out,
                               unsigned long long *d_counts, const uint32_t *d_cand0,
-                              const uint32_t *d_cand1, hipStream_t stream);
+                              const uint32_t *d_cand1, hipStream_t stream, const uint32_t *d_wins0 = nullptr,
+                              const uint32_t *d_wins1 = nullptr, const uint8_t *d_wcnt0 = nullptr,
+                              const uint8_t *d_wcnt1 = nullptr);
 hipError_t bdx_generic_set_lds_limit(size_t bytes);

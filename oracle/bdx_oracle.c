@@ -152,12 +152,36 @@ static inline int64_t min3(int64_t a, int64_t b, int64_t c) { return imin(imin(a
 /* semiglobal_alignment_core, classification.jl:238-445.
  * q and r are passed 0-based from the caller; shifted to 1-based here.
  * DP/origin must hold at least m+1 entries (index 0 unused). */
+static orc_align_t semiglobal_core_cols(int64_t *DP, int64_t *origin, const uint8_t *q0, int64_t m,
+                                        const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                                        int64_t mismatch, int64_t indel, int32_t has_nindel,
+                                        int64_t nindel, int32_t output_mode, int32_t trim_side,
+                                        int64_t range_first, int64_t range_last, int64_t max_start_pos,
+                                        int64_t min_end_pos, int64_t normalization_length,
+                                        int64_t col_lo, int64_t col_hi);
+
 orc_align_t orc_semiglobal_core(int64_t *DP, int64_t *origin, const uint8_t *q0, int64_t m,
                                 const uint8_t *r0, int64_t n, double max_error, int64_t match,
                                 int64_t mismatch, int64_t indel, int32_t has_nindel,
                                 int64_t nindel, int32_t output_mode, int32_t trim_side,
                                 int64_t range_first, int64_t range_last, int64_t max_start_pos,
                                 int64_t min_end_pos, int64_t normalization_length) {
+    return semiglobal_core_cols(DP, origin, q0, m, r0, n, max_error, match, mismatch, indel, has_nindel, nindel,
+                                output_mode, trim_side, range_first, range_last, max_start_pos, min_end_pos,
+                                normalization_length, INT64_MIN, INT64_MAX);
+}
+
+/* The reference function, plus (test-only) col_lo/col_hi: when given, the column loop :287 runs over
+ * max(first, col_lo)..min(last, col_hi) instead of first..last — everything else untouched.  Used by
+ * orc_selftest_windowed_exact to check the HIP path's "restricted run" claim; the plain entry point
+ * above passes the whole range. */
+static orc_align_t semiglobal_core_cols(int64_t *DP, int64_t *origin, const uint8_t *q0, int64_t m,
+                                        const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                                        int64_t mismatch, int64_t indel, int32_t has_nindel,
+                                        int64_t nindel, int32_t output_mode, int32_t trim_side,
+                                        int64_t range_first, int64_t range_last, int64_t max_start_pos,
+                                        int64_t min_end_pos, int64_t normalization_length,
+                                        int64_t col_lo, int64_t col_hi) {
     const uint8_t *q = q0 - 1;
     const uint8_t *r = r0 - 1;
     const int is_traceback = output_mode == ORC_OUT_TRACEBACK; /* :275 */
@@ -191,6 +215,8 @@ orc_align_t orc_semiglobal_core(int64_t *DP, int64_t *origin, const uint8_t *q0,
     }
 
     int64_t lact = imin(allowed_error + 1, m); /* :286 */
+    if (col_lo > range_first) range_first = col_lo; /* test-only restriction, see above */
+    if (col_hi < range_last) range_last = col_hi;
     for (int64_t j = range_first; j <= range_last; j++) { /* :287 */
         int64_t previous_score_origin = j;
         int64_t fact, previous_score;
@@ -892,6 +918,117 @@ int64_t orc_selftest_known_class(uint64_t seed, int64_t iters, int64_t *first_ba
             if (bad == 0 && first_bad) {
                 first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = a.raw;
                 first_bad[4] = expect; first_bad[5] = ae;
+            }
+            bad++;
+        }
+    }
+    return bad;
+}
+
+
+/* ---- differential self-test supporting the "restricted exact run" of the HIP path ----
+ * Claim: let kb = floor(floor(max_error*norm) / cmin), cmin = min(mismatch, indel
+ * [, nindel]) >= 1, match >= 0, and let E = [e_lo, e_hi] be the first/last column j of the pass
+ * window with unit-cost semi-global distance U[m][j] <= kb (barcode N = wildcard under NScoring).
+ * Then running the reference's column loop only over  max(first, e_lo - 2(m+kb) - 1) .. min(last,
+ * e_hi)  returns the same (score, start, end) as the full run, for every output policy, trim side,
+ * range setting and (tightened) threshold <= max_error; with E empty the full run returns Inf. */
+static int64_t unit_cols(const uint8_t *q, int64_t m, const uint8_t *r, int64_t first, int64_t last, int wild,
+                         int64_t kb, int64_t *e_lo, int64_t *e_hi) {
+    int64_t *prev = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
+    int64_t found = 0;
+    for (int64_t i = 0; i <= m; i++) prev[i] = i;
+    for (int64_t j = first; j <= last; j++) {
+        cur[0] = 0;
+        for (int64_t i = 1; i <= m; i++) {
+            int eq = (q[i - 1] == r[j - 1]) || (wild && q[i - 1] == 'N');
+            int64_t a = prev[i] + 1, b = cur[i - 1] + 1, c = prev[i - 1] + !eq;
+            cur[i] = a < b ? (a < c ? a : c) : (b < c ? b : c);
+        }
+        if (cur[m] <= kb) {
+            if (!found) *e_lo = j;
+            *e_hi = j;
+            found = 1;
+        }
+        int64_t *t = prev;
+        prev = cur;
+        cur = t;
+    }
+    free(prev);
+    free(cur);
+    return found;
+}
+
+int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[6] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[260];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 2 + (int64_t)(st_next(&s) % 31);
+        int64_t n = (int64_t)(st_next(&s) % 250);
+        int has_n = (st_next(&s) % 4) == 0;
+        int64_t non_n = 0;
+        for (int64_t i = 0; i < m; i++) {
+            q[i] = (uint8_t)AL[st_next(&s) % ((has_n && (st_next(&s) % 6 == 0)) ? 5 : 4)];
+            non_n += q[i] != 'N';
+        }
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % ((st_next(&s) % 50) ? 4 : 5)];
+        int copies = (int)(st_next(&s) % 3); /* 0, 1 or 2 mutated copies (ties / repeated occurrences) */
+        for (int cpy = 0; cpy < copies && n > 0; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                uint8_t ch = q[i] == 'N' ? (uint8_t)AL[st_next(&s) % 4] : q[i];
+                if (u < 5) r[pos++] = (uint8_t)AL[st_next(&s) % 4];
+                else if (u < 8) continue;
+                else if (u < 11) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = ch; }
+                else r[pos++] = ch;
+            }
+        }
+        double rate = RATES[st_next(&s) % 8];
+        int64_t mismatch = 1 + (int64_t)(st_next(&s) % 3), indel = 1 + (int64_t)(st_next(&s) % 3);
+        int64_t match = (st_next(&s) % 8) == 0 ? 1 : 0;
+        int64_t nindel = 1 + (int64_t)(st_next(&s) % 2);
+        int64_t norm = has_n ? non_n : m;
+        int32_t mode = (int32_t)(st_next(&s) % 2);
+        int32_t trim = mode ? (int32_t)((int[]){0, 3, 5}[st_next(&s) % 3]) : 0;
+        /* ranges: whole read, a window, and sometimes binding start / end constraints */
+        int64_t first = 1, last = n, max_start = n, min_end = 1;
+        if (n > 0 && (st_next(&s) % 3) == 0) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        if (n > 0 && (st_next(&s) % 4) == 0) max_start = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+        if (n > 0 && (st_next(&s) % 4) == 0) min_end = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+        int64_t ae0 = (int64_t)floor(rate * (double)norm);
+        int64_t cmin = mismatch < indel ? mismatch : indel;
+        if (has_n && nindel < cmin) cmin = nindel;
+        int64_t kb = ae0 < 0 ? -1 : ae0 / cmin;
+        /* the threshold actually used may be tighter than the one kb was derived from */
+        double used = (st_next(&s) % 3) ? rate : rate * (double)(st_next(&s) % 100) / 100.0;
+        orc_align_t full = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, has_n, nindel, mode,
+                                                trim, first, last, max_start, min_end, norm, INT64_MIN, INT64_MAX);
+        int64_t e_lo = 0, e_hi = 0;
+        int64_t f = first < 1 ? 1 : first, l = last > n ? n : last;
+        int found = (n > 0 && l >= f && kb >= 0) ? (int)unit_cols(q, m, r, f, l, has_n, kb, &e_lo, &e_hi) : 0;
+        orc_align_t res;
+        if (!found) {
+            res.score = INFINITY;
+            res.raw = INF_INT;
+            res.start = -1;
+            res.end = -1;
+        } else {
+            res = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, has_n, nindel, mode, trim,
+                                       first, last, max_start, min_end, norm, e_lo - 2 * (m + kb) - 1, e_hi);
+        }
+        if (res.raw != full.raw || res.start != full.start || res.end != full.end) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = full.raw;
+                first_bad[4] = res.raw; first_bad[5] = full.start; first_bad[6] = res.start; first_bad[7] = mode * 10 + trim;
             }
             bad++;
         }

@@ -20,3 +20,13 @@ def test_unit_distance_sanity():
     assert d(u8(b"ACGT"), 4, u8(b"TTACGTTT"), 8) == 0
     assert d(u8(b"ACGT"), 4, u8(b"TTACTTT"), 7) == 1
     assert d(u8(b"AAAA"), 4, u8(b"CCCC"), 4) == 4
+
+
+def test_restricted_exact_run_equals_full_run():
+    """running the reference's column loop only over e_lo - 2(m+kb) - 1 .. e_hi
+    ([e_lo, e_hi] = first/last column with unit distance <= kb) returns the same (score, start, end)
+    as the full run — weighted costs, N-scoring, ScoreOnly and traceback, every trim side, column
+    windows, binding start/end ranges, tightened thresholds, repeated occurrences."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_windowed_exact(20260515, 300_000, fb)
+    assert bad == 0, f"first disagreement (iter, m, n, full.raw, res.raw, full.start, res.start, mode*10+trim): {list(fb)}"
