@@ -103,7 +103,13 @@ class FastqFile:
 
 def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: str, prefix1: str, prefix2: str,
                  classifier, batch_reads: int) -> None:
-    """Native counterpart of core._demux: index -> pack -> ONE C-ABI classify call -> in-order write."""
+    """Native counterpart of core._demux: index -> pack -> ONE C-ABI classify call -> in-order write,
+    as a three-stage pipeline (reader thread | classify on the calling thread | writer thread; the
+    native calls release the GIL).  Batches flow through bounded FIFO queues, so per-file order is
+    input order exactly as with the reference's single writer task (core.jl:139-148)."""
+    import queue
+    import threading
+
     L = _load()
     T = _threads()
     f1 = FastqFile(fastq1)
@@ -111,57 +117,103 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
     stride = max(1, len(config.bc_seqs2)) if config.is_dual else 1
     n_classes = 2 + len(config.bc_seqs) * stride
     do_trim = config.trim_side is not None or config.trim_side2 is not None
+    gz = int(bool(config.gzip_output))
+    q_in: "queue.Queue" = queue.Queue(maxsize=2)
+    q_out: "queue.Queue" = queue.Queue(maxsize=2)
+    errors = []
+
+    def reader():
+        try:
+            while True:
+                n1, off1, ln1 = f1.next_batch(batch_reads, T)
+                off2 = ln2 = None
+                if f2 is not None:
+                    n2, off2, ln2 = f2.next_batch(batch_reads, T)
+                    n = min(n1, n2)  # lock-step pairs: stop at the shorter file (core.jl:48)
+                    last = n1 != n2
+                else:
+                    n, last = n1, False
+                if n == 0:
+                    break
+                seq, so = f1.pack(off1, ln1, n, T)
+                q_in.put((n, off1, ln1, off2, ln2, seq, so))
+                if last:
+                    break
+        except BaseException as e:  # noqa: BLE001 - forwarded to the caller
+            errors.append(e)
+        finally:
+            q_in.put(None)
+
+    def paths(prefix, used):
+        arr = (C.c_char_p * n_classes)()
+        for c in used:
+            c = int(c)
+            if c == 0:
+                b1, b2 = 0, 0
+            elif c == 1:
+                b1, b2 = -1, 0
+            else:
+                b1, b2 = divmod(c - 2, stride)
+                b1, b2 = b1 + 1, (b2 + 1 if config.is_dual else 0)
+            arr[c] = os.path.join(output_directory, prefix + "." + filename_for(config, b1, b2)).encode()
+        return arr
+
+    def writer():
+        try:
+            while True:
+                item = q_out.get()
+                if item is None:
+                    break
+                n, off1, ln1, off2, ln2, cls, ks, ke = item
+                used = np.unique(cls)
+
+                def write(f, off, ln, prefix, trim):
+                    rc = L.bdx_fq_demux_write(f.h, off.ctypes.data, ln.ctypes.data, n, cls.ctypes.data, n_classes,
+                                              paths(prefix, used), ks.ctypes.data, ke.ctypes.data, int(trim), gz, T)
+                    if rc != 0:
+                        raise OSError(L.bdx_io_last_error().decode())
+
+                if config.classify_both and f2 is not None:  # core.jl:175-185
+                    write(f1, off1, ln1, prefix1, do_trim)
+                    write(f2, off2, ln2, prefix2, False)
+                elif f2 is not None:  # core.jl:186-190
+                    write(f2, off2, ln2, prefix2, False)
+                else:  # core.jl:191-196
+                    write(f1, off1, ln1, prefix1, do_trim)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            while q_out.get() is not None:  # keep draining so the producer never blocks
+                pass
+
+    tr = threading.Thread(target=reader, name="bdx-reader")
+    tw = threading.Thread(target=writer, name="bdx-writer")
+    tr.start()
+    tw.start()
     try:
         while True:
-            n1, off1, ln1 = f1.next_batch(batch_reads, T)
-            if f2 is not None:
-                n2, off2, ln2 = f2.next_batch(batch_reads, T)
-                n = min(n1, n2)  # lock-step pairs: stop at the shorter file (core.jl:48)
-            else:
-                n = n1
-            if n == 0:
+            item = q_in.get()
+            if item is None:
                 break
-            seq, so = f1.pack(off1, ln1, n, T)
+            if errors:
+                continue
+            n, off1, ln1, off2, ln2, seq, so = item
             out = classifier.classify(seq, so)  # <- the hot path: one C-ABI call per batch
             bc1, bc2 = out["bc1"], out["bc2"]
             cls = np.where(bc1 > 0, 2 + (bc1 - 1) * stride + np.maximum(bc2 - 1, 0), np.where(bc1 == 0, 0, 1))
             cls = np.ascontiguousarray(cls, dtype=np.int32)
-            used = np.unique(cls)
-
-            def paths(prefix):
-                arr = (C.c_char_p * n_classes)()
-                for c in used:
-                    c = int(c)
-                    if c == 0:
-                        b1, b2 = 0, 0
-                    elif c == 1:
-                        b1, b2 = -1, 0
-                    else:
-                        b1, b2 = divmod(c - 2, stride)
-                        b1, b2 = b1 + 1, (b2 + 1 if config.is_dual else 0)
-                    arr[c] = os.path.join(output_directory, prefix + "." + filename_for(config, b1, b2)).encode()
-                return arr
-
             ks = np.ascontiguousarray(out["keep_start"], dtype=np.int32)
             ke = np.ascontiguousarray(out["keep_end"], dtype=np.int32)
-            gz = int(bool(config.gzip_output))
-
-            def write(f, off, ln, prefix, trim):
-                rc = L.bdx_fq_demux_write(f.h, off.ctypes.data, ln.ctypes.data, n, cls.ctypes.data, n_classes,
-                                          paths(prefix), ks.ctypes.data, ke.ctypes.data, int(trim), gz, T)
-                if rc != 0:
-                    raise OSError(L.bdx_io_last_error().decode())
-
-            if config.classify_both and f2 is not None:  # core.jl:175-185
-                write(f1, off1, ln1, prefix1, do_trim)
-                write(f2, off2, ln2, prefix2, False)
-            elif f2 is not None:  # core.jl:186-190
-                write(f2, off2, ln2, prefix2, False)
-            else:  # core.jl:191-196
-                write(f1, off1, ln1, prefix1, do_trim)
-            if f2 is not None and n1 != n2:
-                break
+            q_out.put((n, off1, ln1, off2, ln2, cls, ks, ke))
+    except BaseException as e:  # noqa: BLE001
+        errors.append(e)
+        while q_in.get() is not None:
+            pass
     finally:
+        q_out.put(None)
+        tr.join()
+        tw.join()
         f1.close()
         if f2 is not None:
             f2.close()
+    if errors:
+        raise errors[0]
