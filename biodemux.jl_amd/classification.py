@@ -7,8 +7,8 @@ evaluated by the gfx950 kernel through the C-ABI (never on the CPU).
   hamming_align             classification.jl:557
   find_best_matching_bc     classification.jl:722
   determine_filename        classification.jl:871
-  DemuxStats / merge_stats  classification.jl:736-767 / reporting.jl:1-58 (scalar counters +
-                            sample_counts only; the histograms are out of scope)
+  DemuxStats / merge_stats  classification.jl:736-767 / reporting.jl:1-58 (scalar counters from the
+                            device; pos/len/score histograms accumulated on the host)
 
 Argument order and meaning follow the Julia signatures so the parity tests read like the
 reference's own unit tests.  ``ref_search_range`` is a ``(first, last)`` tuple or a Python
@@ -148,15 +148,36 @@ def determine_filename(seq: str, config: DemuxConfig, ws=None, *, device: int = 
     return filename_for(config, bc1, bc2), int(out["keep_start"][0]), int(out["keep_end"][0])
 
 
+def _round2(x):
+    """Julia's round(score, digits=2) (classification.jl:835): round-half-even of fl(x * 100), / 100."""
+    import numpy as np
+
+    return np.round(np.asarray(x, dtype=np.float64) * 100.0) / 100.0
+
+
 @dataclass
 class DemuxStats:
-    """Scalar part of classification.jl:736-744 (histograms :745-757 are out of scope)."""
+    """classification.jl:736-758.  The scalar counters and sample_counts come from the device
+    (C-ABI counter vector); the position / length / score histograms (filled at :827-865 for every
+    pass whose status is :match) are accumulated on the host from the per-pass outputs."""
 
     total_reads: int = 0
     matched_reads: int = 0
     unmatched_reads: int = 0
     ambiguous_reads: int = 0
     sample_counts: Dict[Tuple[int, int], int] = field(default_factory=dict)
+    bc1_pos_counts: Dict[int, int] = field(default_factory=dict)
+    bc1_len_counts: Dict[int, int] = field(default_factory=dict)
+    bc1_score_counts: Dict[float, int] = field(default_factory=dict)
+    bc1_per_bc_score_counts: Dict[int, Dict[float, int]] = field(default_factory=dict)
+    bc1_per_bc_pos_counts: Dict[int, Dict[int, int]] = field(default_factory=dict)
+    bc1_per_bc_len_counts: Dict[int, Dict[int, int]] = field(default_factory=dict)
+    bc2_pos_counts: Dict[int, int] = field(default_factory=dict)
+    bc2_len_counts: Dict[int, int] = field(default_factory=dict)
+    bc2_score_counts: Dict[float, int] = field(default_factory=dict)
+    bc2_per_bc_score_counts: Dict[int, Dict[float, int]] = field(default_factory=dict)
+    bc2_per_bc_pos_counts: Dict[int, Dict[int, int]] = field(default_factory=dict)
+    bc2_per_bc_len_counts: Dict[int, Dict[int, int]] = field(default_factory=dict)
 
     @classmethod
     def from_counts(cls, counts, n_bc1: int, n_bc2: int) -> "DemuxStats":
@@ -170,9 +191,43 @@ class DemuxStats:
                 s.sample_counts[(b1 + 1, b2 + 1 if n_bc2 else 0)] = c
         return s
 
+    def add_pass_outputs(self, out: dict, min_delta: float) -> None:
+        """Histogram update of match_barcode_pass (classification.jl:827-865) for one batch: a pass
+        contributes iff its status is :match (winner found and delta >= min_delta); pass 2 only ran
+        when pass 1 matched (then pass_bc of pass 2 is non-zero or the read went unknown)."""
+        import numpy as np
+
+        for p, tag in ((0, "bc1"), (1, "bc2")):
+            bc = out["pass_bc"][:, p]
+            ok = (bc > 0) & ~(out["pass_delta"][:, p] < min_delta)
+            if not ok.any():
+                continue
+            bc = bc[ok].astype(np.int64)
+            start = out["pass_start"][:, p][ok].astype(np.int64)
+            length = out["pass_end"][:, p][ok].astype(np.int64) - start + 1
+            score = _round2(out["pass_score"][:, p][ok])
+
+            def bump(d, keys, cast):
+                u, c = np.unique(keys, return_counts=True)
+                for k, n in zip(u, c):
+                    d[cast(k)] = d.get(cast(k), 0) + int(n)
+
+            bump(getattr(self, f"{tag}_pos_counts"), start, int)
+            bump(getattr(self, f"{tag}_len_counts"), length, int)
+            bump(getattr(self, f"{tag}_score_counts"), score, float)
+            for b in np.unique(bc):
+                m = bc == b
+                bump(getattr(self, f"{tag}_per_bc_pos_counts").setdefault(int(b), {}), start[m], int)
+                bump(getattr(self, f"{tag}_per_bc_len_counts").setdefault(int(b), {}), length[m], int)
+                bump(getattr(self, f"{tag}_per_bc_score_counts").setdefault(int(b), {}), score[m], float)
+
+
+_HIST_FIELDS = [f"{t}_{k}" for t in ("bc1", "bc2") for k in ("pos_counts", "len_counts", "score_counts")]
+_PER_BC_FIELDS = [f"{t}_per_bc_{k}" for t in ("bc1", "bc2") for k in ("score_counts", "pos_counts", "len_counts")]
+
 
 def merge_stats(stats_list: List[DemuxStats]) -> DemuxStats:
-    """reporting.jl:1-9: sum of the per-worker counters (across GPUs this is one RCCL
+    """reporting.jl:1-58: sum of the per-worker statistics (across GPUs the scalar part is one RCCL
     all-reduce of the counter vector, see dist.py)."""
     m = DemuxStats()
     for s in stats_list:
@@ -182,6 +237,16 @@ def merge_stats(stats_list: List[DemuxStats]) -> DemuxStats:
         m.ambiguous_reads += s.ambiguous_reads
         for k, v in s.sample_counts.items():
             m.sample_counts[k] = m.sample_counts.get(k, 0) + v
+        for f in _HIST_FIELDS:
+            d = getattr(m, f)
+            for k, v in getattr(s, f).items():
+                d[k] = d.get(k, 0) + v
+        for f in _PER_BC_FIELDS:
+            dm = getattr(m, f)
+            for b, dd in getattr(s, f).items():
+                t = dm.setdefault(b, {})
+                for k, v in dd.items():
+                    t[k] = t.get(k, 0) + v
     return m
 
 

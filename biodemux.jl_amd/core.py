@@ -80,7 +80,7 @@ def _log(msg: str):
 
 
 def _demux(fastq1: str, fastq2: Optional[str], config: DemuxConfig, output_directory: str, prefix1: str,
-           prefix2: str, classifier, batch_reads: int) -> None:
+           prefix2: str, classifier, batch_reads: int, on_batch=None) -> None:
     writer = _Writer(output_directory, config)
     do_trim = config.trim_side is not None or config.trim_side2 is not None  # core.jl:240
 
@@ -92,6 +92,8 @@ def _demux(fastq1: str, fastq2: Optional[str], config: DemuxConfig, output_direc
         off[1:] = np.cumsum([len(s) for s in seqs])
         blob = np.frombuffer(b"".join(seqs), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
         out = classifier.classify(blob, off)  # <- the hot path: one C-ABI call per batch
+        if on_batch is not None:
+            on_batch(out)
         bc1, bc2, ks, ke = out["bc1"], out["bc2"], out["keep_start"], out["keep_end"]
         for i, (h1, s1, p1, q1) in enumerate(r1):
             filename = filename_for(config, int(bc1[i]), int(bc2[i]))
@@ -204,19 +206,34 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
         o["barcode_start_range2"], o["barcode_end_range2"], o["trim_side"], o["trim_side2"], o["summary"],
         o["summary_format"], o["matching_algorithm"])
 
-    classifier = _classifier_factory(config) if _classifier_factory else HipClassifier(config, device=device)
+    # summary=true also wants the histograms of classification.jl:827-865: ask for the per-pass outputs
+    classifier = (_classifier_factory(config) if _classifier_factory
+                  else HipClassifier(config, device=device, want_pass=bool(config.summary)))
+    hist = DemuxStats() if config.summary else None
+
+    def on_batch(out):
+        if hist is not None and "pass_bc" in out:
+            hist.add_pass_outputs(out, float(config.min_delta))
+
     try:
         if _io not in ("auto", "native", "python"):
             raise ValueError("_io must be 'auto', 'native' or 'python'")
         use_native = _io == "native" or (_io == "auto" and nativeio.available())
         if use_native:
-            nativeio.demux_native(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads)
+            nativeio.demux_native(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads,
+                                  on_batch)
         else:
-            _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads)
+            _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads, on_batch)
         counts = np.asarray(classifier.counts)
     finally:
         classifier.close()
 
     if o["log"]:  # core.jl:484-491
         _log(f"Done: Finished in {_dt.datetime.now() - start_time}.")
-    return DemuxStats.from_counts(counts, len(config.bc_seqs), len(config.bc_seqs2) if config.is_dual else 0)
+    stats = DemuxStats.from_counts(counts, len(config.bc_seqs), len(config.bc_seqs2) if config.is_dual else 0)
+    if hist is not None:
+        for f in ("bc1", "bc2"):
+            for k in ("pos_counts", "len_counts", "score_counts", "per_bc_score_counts", "per_bc_pos_counts",
+                      "per_bc_len_counts"):
+                setattr(stats, f"{f}_{k}", getattr(hist, f"{f}_{k}"))
+    return stats

@@ -102,7 +102,7 @@ class FastqFile:
 
 
 def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: str, prefix1: str, prefix2: str,
-                 classifier, batch_reads: int) -> None:
+                 classifier, batch_reads: int, on_batch=None) -> None:
     """Native counterpart of core._demux: index -> pack -> ONE C-ABI classify call -> in-order write,
     as a three-stage pipeline (reader thread | classify on the calling thread | writer thread; the
     native calls release the GIL).  Batches flow through bounded FIFO queues, so per-file order is
@@ -198,6 +198,8 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 continue
             n, off1, ln1, off2, ln2, seq, so = item
             out = classifier.classify(seq, so)  # <- the hot path: one C-ABI call per batch
+            if on_batch is not None:
+                on_batch(out)
             bc1, bc2 = out["bc1"], out["bc2"]
             cls = np.where(bc1 > 0, 2 + (bc1 - 1) * stride + np.maximum(bc2 - 1, 0), np.where(bc1 == 0, 0, 1))
             cls = np.ascontiguousarray(cls, dtype=np.int32)

@@ -44,7 +44,7 @@ def make_config(overrides: dict) -> "bdx.DemuxConfig":
 
 
 def oracle_factory(cfg):
-    return orc.OracleClassifier(cfg, nthreads=1, want_pass=False)
+    return orc.OracleClassifier(cfg, nthreads=1, want_pass=bool(cfg.summary))
 
 
 def run_kat(vec, api: str):
@@ -303,6 +303,12 @@ def scenario_summary_distribution_reads(run, tmp):
                "@read4\nAAAT\n+\nIIII\n@read5\nAAA\n+\nIII\n")
     stats = run(fq, bc, os.path.join(tmp, "output_dist"), max_error_rate=0.3, summary=True, summary_format="json")
     assert stats.total_reads == 5 and stats.matched_reads == 5
+    # summary_distributions.jl:40-46: start positions 1, 2, 3 and lengths 3, 4 are present
+    assert set(stats.bc1_pos_counts) == {1, 2, 3} and sum(stats.bc1_pos_counts.values()) == 5
+    assert set(stats.bc1_len_counts) == {3, 4} and sum(stats.bc1_len_counts.values()) == 5
+    assert stats.bc1_pos_counts[2] == 1 and stats.bc1_pos_counts[3] == 1
+    assert set(stats.bc1_score_counts) == {0.0, 0.25} and stats.bc1_per_bc_pos_counts[1] == stats.bc1_pos_counts
+    assert stats.bc2_pos_counts == {}
 
 
 SCENARIOS_SMALL = [scenario_n_and_ranges, scenario_range_restrictions, scenario_dual, scenario_dual_trim,
