@@ -62,11 +62,14 @@ struct BitparArgs {
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
-    int dbg;  // timing experiments only (env BDX_DEBUG): 1 = skip stage 2, 2 = skip stage 1 sweep
+    int dbg;  // timing experiments only (env BDX_DEBUG), results are wrong when set: 1 skip stage 2, 2 skip
+              // sweeps, 4 skip hit resolve, 8 skip seed scan, 16 skip 2-bit packing, 32 skip transcode, 64 skip copy
 };
 
+// 3 waves per SIMD (12 per CU) is the residency the LDS footprint of the 64-read tile allows; the
+// bound keeps the register allocator at <= 168 VGPRs so that residency is actually reached.
 template <int BS, int R, bool SEED>
-__global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
+__global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     constexpr int SQCAP = 8 * R;  // capacity of the seed-hit queue
     constexpr int PQCAP = 4 * R;  // capacity of the sweep-record queue
     constexpr int RCAP = 8;       // merged sweep records per read
@@ -168,9 +171,16 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     // tiles of R consecutive reads (tile = blockIdx.x, + gridDim.x, ...).  Tiles are independent;
     // nothing is exchanged between workgroups, so no placement or ordering is assumed. ----
     const long long ntiles = (a.n_reads + R - 1) / R;
+    // the tile queue is read one tile ahead: the returning atomic's L2 round trip (1-3 us) overlaps
+    // the current tile's work instead of heading every tile (each workgroup over-fetches one index)
+    int next_tile = 0;
+    if (tid == 0) next_tile = atomicAdd(a.tile_counter, 1);
     for (;;) {
     __syncthreads();  // the previous tile's stage 2 is done with the per-tile LDS state
-    if (tid == 0) sqn[2] = atomicAdd(a.tile_counter, 1);  // dynamic tile queue (exit: queue drained)
+    if (tid == 0) {
+        sqn[2] = next_tile;  // dynamic tile queue (exit: queue drained)
+        next_tile = atomicAdd(a.tile_counter, 1);
+    }
     __syncthreads();
     const long long tile = sqn[2];
     if (tile >= ntiles) break;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     const int head = (int)(g0 - g0a);
     const long long need = slot ? (long long)nr * slot : (span1 - span0) + head;
     bool staged = slot ? true : (need + 16 <= (long long)a.stage_bytes);  // wave-uniform (whole workgroup)
-    if (!slot && staged) {
+    if (!slot && staged && !(a.dbg & 64)) {
         const int nvec = (int)((need + 15) >> 4);
         const u32x4 *src = (const u32x4 *)g0a;
         LDS u32x4 *dst = (LDS u32x4 *)rstage;
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
     // wlo_rel / whi_rel: optional column sub-window [lo, hi) relative to the read's first staged
     // base (seeded path); (0, 0xFFFF) = the whole pass window
     auto setup = [&](const bool valid, const int p, const int r, const int b, Sweep &w, const int wlo_rel = 0,
-                     const int whi_rel = 0xFFFF) {
+                     const int whi_rel = 0xFFFF) __attribute__((always_inline)) {
         w.ncol = 0;
         w.r = 0;
         w.b = 0;
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         w.ncol = jl - jf + 1;
         w.pq = (const LDS unsigned char *)((p ? peq1 : peq0) + b);
     };
-    auto step = [&](Sweep &w, const int j, const int sh) {
+    auto step = [&](Sweep &w, const int j, const int sh) __attribute__((always_inline)) {
         const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
         const uint32_t Xv = Eq | w.Mv;
         const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
         w.Mv = Ph & Xv;
         w.best = w.score < w.best ? w.score : w.best;
     };
-    auto finish = [&](const Sweep &w) {
+    auto finish = [&](const Sweep &w) __attribute__((always_inline)) {
         if (w.ncol > 0 && w.best <= (w.p ? kb1 : kb0)[w.b]) {
             const int cw = w.p ? cw1 : cw0;
             LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             }
         }
     };
-    auto sweep2 = [&](Sweep &A, Sweep &Bw) {
+    auto sweep2 = [&](Sweep &A, Sweep &Bw) __attribute__((always_inline)) {
         // both chains use the same symbol shift only when they belong to the same pass;
         // the shifts are per chain (uniform in the non-seeded path, per lane otherwise)
         const int shA = a.bshift[A.p], shB = a.bshift[Bw.p];
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
 
     if (staged) {
         // ---- transcode bytes -> symbol codes (4 per lane per step) ----
-        const int nvec4 = (int)((need + 3) >> 2);
+        const int nvec4 = (a.dbg & 32) ? 0 : (int)((need + 3) >> 2);
         for (int k = tid; k < nvec4; k += BS) {
             const uint32_t w = ((LDS uint32_t *)rstage)[k];
             const uint32_t c = (uint32_t)lut[w & 255] | ((uint32_t)lut[(w >> 8) & 255] << 8) |
@@ -406,48 +416,84 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             const uint32_t kmask = (q >= 16) ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u);
             const int G = a.seed_groups;  // 4-base groups per read (uniform upper bound)
             // 2-bit packing of every read, 4 bases per byte, aligned to the first staged base
-            for (int idx = tid; idx < nr * G; idx += BS) {
-                const int r = idx / G, g = idx - r * G;
-                const LDS unsigned char *c = codes + roff[r] + wlo[r] + 4 * g;
-                const uint32_t pk = (uint32_t)(c[0] & 3) | ((uint32_t)(c[1] & 3) << 2) | ((uint32_t)(c[2] & 3) << 4) |
-                                    ((uint32_t)(c[3] & 3) << 6);
-                spk[r * (G + 4) + g] = (unsigned char)pk;
-                // a read longer than the planned group count would leave its tail unscanned:
-                // sweep every barcode of it instead (lossless fallback)
-                if (g == 0 && wlen[r] > 4 * (G - 1)) sall[r] = 1;
+            {
+                const int dr = BS / G, dg = BS - dr * G;
+                int r = tid / G, g = tid - r * G;
+                const int total_items = (a.dbg & 16) ? 0 : nr * G;
+                for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
+                    const LDS unsigned char *c = codes + roff[r] + wlo[r] + 4 * g;
+                    const uint32_t pk = (uint32_t)(c[0] & 3) | ((uint32_t)(c[1] & 3) << 2) | ((uint32_t)(c[2] & 3) << 4) |
+                                        ((uint32_t)(c[3] & 3) << 6);
+                    spk[r * (G + 4) + g] = (unsigned char)pk;
+                    // a read longer than the planned group count would leave its tail unscanned:
+                    // sweep every barcode of it instead (lossless fallback)
+                    if (g == 0 && wlen[r] > 4 * (G - 1)) sall[r] = 1;
+                }
             }
             for (int idx = tid; idx < nr * 4; idx += BS) spk[(idx >> 2) * (G + 4) + G + (idx & 3)] = 0;
             __syncthreads();
             // scan: lane = (read, group of 4 start positions); key = 2q bits starting at the position
-            for (int idx = tid; idx < nr * G; idx += BS) {
-                const int r = idx / G, g = idx - r * G;
-                const int nread = rlen[r];
-                const int base = wlo[r];  // group g covers read positions base + 4g .. base + 4g + 3
-                int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
-                if (npass == 1) {
-                    lo = win[0 * R + r] - 1;
-                    hi = (sg ? win[1 * R + r] : nread) - q;
-                    if (win[1 * R + r] < win[0 * R + r]) hi = -1;
-                } else {
-                    lo = base;
-                    hi = base + wlen[r] - q;
-                }
-                if (hi > base + wlen[r] - q) hi = base + wlen[r] - q;  // never beyond the staged bases
-                if (base + 4 * g + 3 < lo || base + 4 * g > hi) continue;
-                const LDS unsigned char *pk = spk + r * (G + 4) + g;
-                const uint32_t w = (uint32_t)pk[0] | ((uint32_t)pk[1] << 8) | ((uint32_t)pk[2] << 16);
+            {
+                // (read, group) indices advance incrementally (no division per item); every lane keeps
+                // its up-to-4 hits of a trip in registers and the wave appends them to the hit queue with
+                // ONE LDS atomic (same-address atomics from 256 lanes serialise otherwise).
+                const int lane = tid & 63;
+                const int dr = BS / G, dg = BS - dr * G;
+                int r = tid / G, g = tid - r * G;
+                const int total_items = (a.dbg & 8) ? 0 : nr * G;
+                for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
+                    const int nread = rlen[r];
+                    const int base = wlo[r];  // group g covers read positions base + 4g .. base + 4g + 3
+                    int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
+                    if (npass == 1) {
+                        lo = win[0 * R + r] - 1;
+                        hi = (sg ? win[1 * R + r] : nread) - q;
+                        if (win[1 * R + r] < win[0 * R + r]) hi = -1;
+                    } else {
+                        lo = base;
+                        hi = base + wlen[r] - q;
+                    }
+                    if (hi > base + wlen[r] - q) hi = base + wlen[r] - q;  // never beyond the staged bases
+                    uint32_t keys[4];
+                    bool hit[4];
+                    const bool in_range = !(base + 4 * g + 3 < lo || base + 4 * g > hi);
+                    const LDS unsigned char *pk = spk + r * (G + 4) + g;
+                    const uint32_t w = (uint32_t)pk[0] | ((uint32_t)pk[1] << 8) | ((uint32_t)pk[2] << 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pos = base + 4 * g + i;
-                    const uint32_t key = (w >> (2 * i)) & kmask;
-                    const uint32_t hb = (key * 0x9E3779B1u) >> (32 - a.seed_bm_log2);  // hashed bitmap index
-                    if (pos >= lo && pos <= hi && ((sbm[hb >> 5] >> (hb & 31)) & 1u)) {
-                        const int k = __hip_atomic_fetch_add(&sqn[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (k < SQCAP) {
-                            shq[k] = ((uint32_t)(pos - base) << 16) | key;
-                            shr[k] = (unsigned char)r;
-                        } else {
-                            sall[r] = 1;  // hit queue full: sweep every barcode of this read instead
+                    for (int i = 0; i < 4; ++i) {
+                        const int pos = base + 4 * g + i;
+                        keys[i] = (w >> (2 * i)) & kmask;
+                        const uint32_t hb = (keys[i] * 0x9E3779B1u) >> (32 - a.seed_bm_log2);  // hashed bitmap index
+                        hit[i] = in_range && pos >= lo && pos <= hi && ((sbm[hb >> 5] >> (hb & 31)) & 1u);
+                    }
+                    // wave-aggregated append
+                    unsigned long long m[4];
+                    int tot = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        m[i] = __builtin_amdgcn_ballot_w64(hit[i]);
+                        tot += __builtin_popcountll(m[i]);
+                    }
+                    if (tot) {  // wave-uniform among the active lanes
+                        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                        const int leader = __builtin_ctzll(act);
+                        int basek = 0;
+                        if (lane == leader)
+                            basek = __hip_atomic_fetch_add(&sqn[0], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        basek = __shfl(basek, leader, 64);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (hit[i]) {
+                                const int k = basek + __builtin_popcountll(m[i] & below);
+                                if (k < SQCAP) {
+                                    shq[k] = ((uint32_t)(base + 4 * g + i - base) << 16) | keys[i];
+                                    shr[k] = (unsigned char)r;
+                                } else {
+                                    sall[r] = 1;  // hit queue full: sweep every barcode of this read instead
+                                }
+                            }
+                            basek += __builtin_popcountll(m[i]);
                         }
                     }
                 }
@@ -456,7 +502,7 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             // resolve: one lane per hit probes the hash table; every (pass, barcode) it finds is merged
             // into the read's small record table (CAS on the id, atomic min/max on the window)
             {
-                const int nh = sqn[0] < SQCAP ? sqn[0] : SQCAP;
+                const int nh = (a.dbg & 4) ? 0 : (sqn[0] < SQCAP ? sqn[0] : SQCAP);
                 const uint32_t hmask = (1u << a.seed_hash_log2) - 1u;
                 for (int k = tid; k < nh; k += BS) {
                     const uint32_t h = shq[k];
@@ -504,16 +550,28 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             }
             __syncthreads();
             // emit: every occupied record becomes one sweep
-            for (int idx = tid; idx < nr * RCAP; idx += BS) {
-                const uint32_t pb = srid[idx];
-                if (pb != 0u) {
-                    const int t = idx / RCAP;
-                    const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (kq < PQCAP) {
-                        spq[kq] = ((uint32_t)t << 16) | pb;
-                        spw[kq] = ((uint32_t)srlo[idx] << 16) | (uint32_t)srhi[idx];
-                    } else {
-                        sall[t] = 1;
+            for (int idx0 = 0; idx0 < nr * RCAP; idx0 += BS) {  // uniform trip count: wave-aggregated append
+                const int idx = idx0 + tid;
+                const uint32_t pb = idx < nr * RCAP ? srid[idx] : 0u;
+                const bool has = pb != 0u;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
+                if (mk) {
+                    const int lane = tid & 63;
+                    const int leader = __builtin_ctzll(mk);
+                    int basek = 0;
+                    if (lane == leader)
+                        basek = __hip_atomic_fetch_add(&sqn[1], (int)__builtin_popcountll(mk), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    basek = __shfl(basek, leader, 64);
+                    if (has) {
+                        const int t = idx / RCAP;
+                        const int kq = basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+                        if (kq < PQCAP) {
+                            spq[kq] = ((uint32_t)t << 16) | pb;
+                            spw[kq] = ((uint32_t)srlo[idx] << 16) | (uint32_t)srhi[idx];
+                        } else {
+                            sall[t] = 1;
+                        }
                     }
                 }
             }
@@ -657,14 +715,13 @@ __global__ __launch_bounds__(BS) void bdx_bitpar_kernel(const BitparArgs a) {
             const uint32_t *c1 = (const uint32_t *)(cand + R * cw0 + tid * cw1);
             Bytes<true> r{rstage + roff[tid]};
             Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            KnownPass kn[2];
-            for (int p = 0; p < 2; ++p) {
-                const int cnt = scnt[p * R + tid];
-                const LDS uint32_t *e = slots + (p * R + tid) * 4;
-                // more than four survivors (or a read outside the class): exact evaluation instead
-                kn[p] = KnownPass{p < npass && full[p * R + tid] && cnt <= 4, e[0], e[1], e[2], e[3], cnt};
-            }
-            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn[0], kn[1], ncode);
+            // more than four survivors (or a read outside the class): exact evaluation instead
+            const LDS uint32_t *e0 = slots + (0 * R + tid) * 4;
+            const LDS uint32_t *e1 = slots + (1 * R + tid) * 4;
+            const int cnt0 = scnt[0 * R + tid], cnt1 = scnt[1 * R + tid];
+            const KnownPass kn0{full[0 * R + tid] && cnt0 <= 4, e0[0], e0[1], e0[2], e0[3], cnt0};
+            const KnownPass kn1{npass > 1 && full[1 * R + tid] && cnt1 <= 4, e1[0], e1[1], e1[2], e1[3], cnt1};
+            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn0, kn1, ncode);
         } else {  // span larger than the staging area: unfiltered evaluation straight from HBM/L2
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
