@@ -314,13 +314,21 @@ int build_seed_tables(bdx_ctx *ctx) {
     const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
     if (expected * 3.0 > (double)total_bc) return BDX_OK;
     sp.q = q;
-    // hashed bitmap, <= 32768 bits (4 KiB): at ~300 keys that is < 1 % false hits per position, so
-    // the per-read hit lists rarely overflow (an overflow costs a whole-read sweep of every barcode)
-    sp.bm_log2 = 2 * q < 14 ? 2 * q : 14;
-    if (sp.bm_log2 < 5) sp.bm_log2 = 5;
+    // hashed bitmap with >= 48 bits per key (<= ~2 % false hits per position), at most the key space
+    // itself (then it is exact).  Too many false hits overflow the hit queue, and an overflow costs a
+    // whole-read sweep of every barcode.
+    sp.bm_log2 = 5;
+    while ((1u << sp.bm_log2) < pieces.size() * 48 && sp.bm_log2 < 2 * q) sp.bm_log2++;
+    // sweep records per read: the true barcode(s) plus the expected falsely seeded ones, generously
+    {
+        const double false_pairs = 150.0 * (double)pieces.size() / space;
+        sp.rcap = 8;
+        while (sp.rcap < 64 && (double)sp.rcap < 4.0 + 4.0 * false_pairs) sp.rcap *= 2;
+    }
     sp.bm_words = (1 << sp.bm_log2) / 32;
     sp.hash_log2 = 8;
     while ((1u << sp.hash_log2) < pieces.size() * 2) sp.hash_log2++;
+    sp.hash_in_lds = ((size_t)5 << sp.hash_log2) <= 8 * 1024;  // larger tables are probed in L2 (a few probes per read)
     std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
     std::vector<uint8_t> hash_ps((size_t)1 << sp.hash_log2, 0);
     const uint32_t hmask = (1u << sp.hash_log2) - 1;
@@ -328,7 +336,8 @@ int build_seed_tables(bdx_ctx *ctx) {
         const bdx_pass_t &p = c.pass[pc.pass];
         uint32_t key = 0;
         for (int i = 0; i < q; ++i) key |= (uint32_t)(code_of[p.bc_bytes[p.bc_off[pc.b] + pc.start + i]] & 3) << (2 * i);
-        const uint32_t hb = (key * 0x9E3779B1u) >> (32 - sp.bm_log2);
+        // same cheap fold as the kernel's scan (direct index when the bitmap spans the key space)
+        const uint32_t hb = sp.bm_log2 >= 2 * q ? key : ((key ^ (key >> sp.bm_log2)) & ((1u << sp.bm_log2) - 1u));
         bitmap[hb >> 5] |= 1u << (hb & 31);
         const uint32_t entry = (key << 16) | ((uint32_t)pc.pass << 15) | (uint32_t)(pc.b + 1);
         uint32_t slot = (key * 0x9E3779B1u) >> (32 - sp.hash_log2);

@@ -50,6 +50,8 @@ struct BitparArgs {
     int bshift[2];
     // q-gram seeding (SEED variant only)
     int seed_q, seed_groups, seed_hash_log2, seed_bm_words, seed_bm_log2;
+    int seed_rcap;         // sweep records per read (power of two, sized to the expected seeded barcodes)
+    int seed_hash_in_lds;  // 0: the hash table is probed in L2 (large barcode sets)
     int seed_n_always[2];
     const uint32_t *seed_bitmap;
     const uint32_t *seed_hash;
@@ -70,13 +72,14 @@ struct BitparArgs {
 // bound keeps the register allocator at <= 168 VGPRs so that residency is actually reached.
 template <int BS, int R, bool SEED>
 __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
-    constexpr int SQCAP = 8 * R;  // capacity of the seed-hit queue
-    constexpr int PQCAP = 4 * R;  // capacity of the sweep-record queue
-    constexpr int RCAP = 8;       // merged sweep records per read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
     const int tid = threadIdx.x;
+    const int RCAP = SEED ? a.seed_rcap : 8;
+    const int RCAP_LOG2 = 31 - __builtin_clz(RCAP);
+    const int SQCAP = (SEED && a.seed_rcap >= 16) ? 16 * R : 8 * R;  // capacity of the seed-hit queue
+    const int PQCAP = SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R;  // capacity of the sweep-record queue
     const int npass = cfg.is_dual ? 2 : 1;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS unsigned char *codes = rstage;
     // seeding work areas (SEED variant only)
     LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
-    LDS uint32_t *shash = (LDS uint32_t *)take(SEED ? ((size_t)4 << a.seed_hash_log2) : 0);
-    LDS unsigned char *spk = take(SEED ? (size_t)R * (a.seed_groups + 4) : 0);
-    LDS unsigned char *shps = take(SEED ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
+    LDS uint32_t *shash = (LDS uint32_t *)take(SEED && a.seed_hash_in_lds ? ((size_t)4 << a.seed_hash_log2) : 0);
+    LDS unsigned char *spk = take(SEED ? (size_t)(a.stage_bytes >> 2) + 16 : 0);  // flat 2-bit image of the staging area
+    LDS unsigned char *shps = take(SEED && a.seed_hash_in_lds ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
     LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);      // seed hits: position << 16 | key
     LDS unsigned char *shr = take(SEED ? (size_t)SQCAP : 0);                       // ... and their read
     LDS uint32_t *srid = (LDS uint32_t *)take(SEED ? (size_t)R * RCAP * 4 : 0);   // per-read sweep records: id
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *srhi = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
     LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // read << 16 | pass << 15 | barcode + 1
     LDS uint32_t *spw = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // window lo << 16 | hi
-    LDS int *sqn = (LDS int *)take(32);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow, [4] window-queue fill
+    LDS int *sqn = (LDS int *)take(32);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow, [4] window-queue fill, [5] some read needs the whole-read fallback
     LDS uint32_t *wq = (LDS uint32_t *)take((size_t)4 * R * 4);  // split mode: candidates to re-sweep with column tracking
     LDS int *wcl = (LDS int *)take((size_t)2 * R * 4);          // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
@@ -155,10 +158,11 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
     if (SEED) {
         for (int i = tid; i < a.seed_bm_words; i += BS) sbm[i] = a.seed_bitmap[i];
-        for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) {
-            shash[i] = a.seed_hash[i];
-            shps[i] = a.seed_hash_ps[i];
-        }
+        if (a.seed_hash_in_lds)
+            for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) {
+                shash[i] = a.seed_hash[i];
+                shps[i] = a.seed_hash_ps[i];
+            }
     }
     __syncthreads();
     const int bytes0 = (int)off0[B0];
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     if (tid == 0) {
         sqn[3] = 0;
         sqn[4] = 0;
+        sqn[5] = 0;
     }
     for (int i = tid; i < 2 * R; i += BS) wcl[i] = 0;
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
@@ -380,13 +385,16 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     };
 
     if (staged) {
-        // ---- transcode bytes -> symbol codes (4 per lane per step) ----
+        // ---- transcode bytes -> symbol codes (4 per lane per step); the seeded variant also packs the
+        // same four symbols to 2 bits each: one byte of the flat 2-bit image of the whole staging area
+        // (packed byte k holds staged bytes 4k .. 4k+3, whatever read they belong to) ----
         const int nvec4 = (a.dbg & 32) ? 0 : (int)((need + 3) >> 2);
         for (int k = tid; k < nvec4; k += BS) {
             const uint32_t w = ((LDS uint32_t *)rstage)[k];
             const uint32_t c = (uint32_t)lut[w & 255] | ((uint32_t)lut[(w >> 8) & 255] << 8) |
                                ((uint32_t)lut[(w >> 16) & 255] << 16) | ((uint32_t)lut[w >> 24] << 24);
             ((LDS uint32_t *)codes)[k] = c;
+            if (SEED) spk[k] = (unsigned char)((c & 3u) | ((c >> 6) & 0xCu) | ((c >> 12) & 0x30u) | ((c >> 18) & 0xC0u));
         }
         __syncthreads();
 
@@ -414,36 +422,23 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
             // downstream looks at.
             const int q = a.seed_q;
             const uint32_t kmask = (q >= 16) ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u);
-            const int G = a.seed_groups;  // 4-base groups per read (uniform upper bound)
-            // 2-bit packing of every read, 4 bases per byte, aligned to the first staged base
+            // scan: lane = (read, group of 8 consecutive bases of the flat 2-bit image); the group's 8 start
+            // positions share one 32-bit window (8 + 7 bases), every key is probed in the bitmap, and the
+            // hits of a wave are appended to the hit queue with one LDS atomic per round
             {
-                const int dr = BS / G, dg = BS - dr * G;
-                int r = tid / G, g = tid - r * G;
-                const int total_items = (a.dbg & 16) ? 0 : nr * G;
-                for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
-                    const LDS unsigned char *c = codes + roff[r] + wlo[r] + 4 * g;
-                    const uint32_t pk = (uint32_t)(c[0] & 3) | ((uint32_t)(c[1] & 3) << 2) | ((uint32_t)(c[2] & 3) << 4) |
-                                        ((uint32_t)(c[3] & 3) << 6);
-                    spk[r * (G + 4) + g] = (unsigned char)pk;
-                    // a read longer than the planned group count would leave its tail unscanned:
-                    // sweep every barcode of it instead (lossless fallback)
-                    if (g == 0 && wlen[r] > 4 * (G - 1)) sall[r] = 1;
-                }
-            }
-            for (int idx = tid; idx < nr * 4; idx += BS) spk[(idx >> 2) * (G + 4) + G + (idx & 3)] = 0;
-            __syncthreads();
-            // scan: lane = (read, group of 4 start positions); key = 2q bits starting at the position
-            {
-                // (read, group) indices advance incrementally (no division per item); every lane keeps
-                // its up-to-4 hits of a trip in registers and the wave appends them to the hit queue with
-                // ONE LDS atomic (same-address atomics from 256 lanes serialise otherwise).
+                const int G = a.seed_groups;  // 8-base groups per read (uniform upper bound)
                 const int lane = tid & 63;
                 const int dr = BS / G, dg = BS - dr * G;
                 int r = tid / G, g = tid - r * G;
                 const int total_items = (a.dbg & 8) ? 0 : nr * G;
+                const int bml = a.seed_bm_log2;
+                const uint32_t bmmask = (1u << bml) - 1u;
+                const bool bm_direct = bml >= 2 * q;
+                const LDS unsigned short *spk16 = (const LDS unsigned short *)spk;
                 for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
                     const int nread = rlen[r];
-                    const int base = wlo[r];  // group g covers read positions base + 4g .. base + 4g + 3
+                    const int base = wlo[r];
+                    const int ro = roff[r];
                     int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
                     if (npass == 1) {
                         lo = win[0 * R + r] - 1;
@@ -453,47 +448,46 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                         lo = base;
                         hi = base + wlen[r] - q;
                     }
+                    if (lo < base) lo = base;
                     if (hi > base + wlen[r] - q) hi = base + wlen[r] - q;  // never beyond the staged bases
-                    uint32_t keys[4];
-                    bool hit[4];
-                    const bool in_range = !(base + 4 * g + 3 < lo || base + 4 * g > hi);
-                    const LDS unsigned char *pk = spk + r * (G + 4) + g;
-                    const uint32_t w = (uint32_t)pk[0] | ((uint32_t)pk[1] << 8) | ((uint32_t)pk[2] << 16);
+                    // a read longer than the planned group count would leave its tail unscanned:
+                    // sweep every barcode of it instead (lossless fallback)
+                    if (g == 0 && wlen[r] + 7 > 8 * G) sall[r] = 1, sqn[5] = 1;
+                    const int F = ((ro + base) >> 3) + g;  // flat group: staged bytes 8F .. 8F+7
+                    const int pos0 = 8 * F - ro;           // read position (0-based) of the group's first base
+                    int i0 = lo - pos0, i1 = hi - pos0;    // valid start positions of this group: i0 <= i <= i1
+                    i0 = i0 < 0 ? 0 : i0;
+                    i1 = i1 > 7 ? 7 : i1;
+                    const uint32_t w = (uint32_t)spk16[F] | ((uint32_t)spk16[F + 1] << 16);
+                    uint32_t hits = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pos = base + 4 * g + i;
-                        keys[i] = (w >> (2 * i)) & kmask;
-                        const uint32_t hb = (keys[i] * 0x9E3779B1u) >> (32 - a.seed_bm_log2);  // hashed bitmap index
-                        hit[i] = in_range && pos >= lo && pos <= hi && ((sbm[hb >> 5] >> (hb & 31)) & 1u);
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t key = (w >> (2 * i)) & kmask;
+                        const uint32_t hb = bm_direct ? key : ((key ^ (key >> bml)) & bmmask);
+                        hits |= ((sbm[hb >> 5] >> (hb & 31)) & 1u) << i;
                     }
-                    // wave-aggregated append
-                    unsigned long long m[4];
-                    int tot = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        m[i] = __builtin_amdgcn_ballot_w64(hit[i]);
-                        tot += __builtin_popcountll(m[i]);
-                    }
-                    if (tot) {  // wave-uniform among the active lanes
-                        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-                        const int leader = __builtin_ctzll(act);
+                    hits = i0 <= i1 ? (hits & ((2u << i1) - (1u << i0))) : 0u;
+                    // rounds: every lane with a hit left appends its lowest one
+                    for (;;) {
+                        const bool has = hits != 0u;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+                        if (!m) break;
+                        const int leader = __builtin_ctzll(m);
                         int basek = 0;
                         if (lane == leader)
-                            basek = __hip_atomic_fetch_add(&sqn[0], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            basek = __hip_atomic_fetch_add(&sqn[0], (int)__builtin_popcountll(m), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                         basek = __shfl(basek, leader, 64);
-                        const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (hit[i]) {
-                                const int k = basek + __builtin_popcountll(m[i] & below);
-                                if (k < SQCAP) {
-                                    shq[k] = ((uint32_t)(base + 4 * g + i - base) << 16) | keys[i];
-                                    shr[k] = (unsigned char)r;
-                                } else {
-                                    sall[r] = 1;  // hit queue full: sweep every barcode of this read instead
-                                }
+                        if (has) {
+                            const int i = __builtin_ctz(hits);
+                            hits &= hits - 1u;
+                            const int k = basek + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                            if (k < SQCAP) {
+                                shq[k] = ((uint32_t)(pos0 + i - base) << 16) | ((w >> (2 * i)) & kmask);
+                                shr[k] = (unsigned char)r;
+                            } else {
+                                sall[r] = 1, sqn[5] = 1;  // hit queue full: sweep every barcode of this read instead
                             }
-                            basek += __builtin_popcountll(m[i]);
                         }
                     }
                 }
@@ -512,14 +506,14 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                     const int wl_r = wlen[t];
                     uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.seed_hash_log2);
                     for (;;) {
-                        const uint32_t e = shash[slot];
+                        const uint32_t e = a.seed_hash_in_lds ? shash[slot] : a.seed_hash[slot];
                         if (e == 0u) break;
                         if ((e >> 16) == key) {
                             const int p = (int)((e >> 15) & 1u);
                             const int b = (int)(e & 0x7FFFu) - 1;
                             const int kk = (p ? kb1 : kb0)[b];
                             const int mm = __builtin_popcount((p ? pv1 : pv0)[b]);
-                            const int diag = prel - (int)shps[slot];
+                            const int diag = prel - (int)(a.seed_hash_in_lds ? shps[slot] : a.seed_hash_ps[slot]);
                             int lo = diag - kk - 1, hi = diag + mm + kk + 1;  // [lo, hi) relative to the staged base
                             if (lo < 0) lo = 0;
                             if (hi > wl_r) hi = wl_r;
@@ -542,7 +536,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                                 }
                                 rs = (rs + 1) & (RCAP - 1);
                             }
-                            if (!placed) sall[t] = 1;  // more than RCAP distinct barcodes seeded in this read
+                            if (!placed) sall[t] = 1, sqn[5] = 1;  // more than RCAP distinct barcodes seeded in this read
                         }
                         slot = (slot + 1) & hmask;
                     }
@@ -564,13 +558,13 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                     basek = __shfl(basek, leader, 64);
                     if (has) {
-                        const int t = idx / RCAP;
+                        const int t = idx >> RCAP_LOG2;
                         const int kq = basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
                         if (kq < PQCAP) {
                             spq[kq] = ((uint32_t)t << 16) | pb;
                             spw[kq] = ((uint32_t)srlo[idx] << 16) | (uint32_t)srhi[idx];
                         } else {
-                            sall[t] = 1;
+                            sall[t] = 1, sqn[5] = 1;
                         }
                     }
                 }
@@ -586,11 +580,12 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                         spq[kq] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)(b + 1);
                         spw[kq] = 0x0000FFFFu;
                     } else {
-                        sall[r] = 1;
+                        sall[r] = 1, sqn[5] = 1;
                     }
                 }
             }
             __syncthreads();
+            const int any_sall = sqn[5];  // does any read of this tile need the whole-read fallback below?
             {
                 const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
                 for (int k = tid; k < np; k += 2 * BS) {
@@ -606,7 +601,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                 // reads whose lists overflowed: every barcode over the whole window, exactly once
                 for (int p = 0; p < npass; ++p) {
                     const int B = p ? B1 : B0;
-                    const int total = (a.dbg & 2) ? 0 : nr * B;
+                    const int total = ((a.dbg & 2) || !any_sall) ? 0 : nr * B;
                     for (int pair = tid; pair < total; pair += 2 * BS) {
                         Sweep A, Bw;
                         const int pb = pair + BS;
@@ -825,10 +820,10 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled) {
-        const int G = (bp.seed_span + 3) / 4 + 1;
-        o += al((size_t)sp->bm_words * 4) + al((size_t)4 << sp->hash_log2) + al((size_t)R * (G + 4));
-        o += al((size_t)1 << sp->hash_log2) + al((size_t)8 * R * 4) + al((size_t)8 * R) + 3 * al((size_t)R * 8 * 4);
-        o += 2 * al((size_t)4 * R * 4) + al((size_t)R);
+        o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 16);
+        if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
+        o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
+        o += 2 * al((size_t)(sp->rcap >= 16 ? 8 : 4) * R * 4) + al((size_t)R);
     }
     o += al(32) + al((size_t)4 * R * 4) + al((size_t)2 * R * 4);
     return o;
@@ -875,10 +870,12 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
     a.seed_q = sp.q;
-    a.seed_groups = (bp.seed_span + 3) / 4 + 1;
+    a.seed_groups = (bp.seed_span + 7 + 7) / 8;  // 8-base groups of the flat image that can overlap one read
     a.seed_hash_log2 = sp.hash_log2;
     a.seed_bm_words = sp.bm_words;
     a.seed_bm_log2 = sp.bm_log2;
+    a.seed_rcap = sp.rcap > 0 ? sp.rcap : 8;
+    a.seed_hash_in_lds = sp.hash_in_lds;
     a.seed_bitmap = sp.d_bitmap;
     a.seed_hash = sp.d_hash;
     a.seed_hash_ps = sp.d_hash_ps;

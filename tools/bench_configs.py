@@ -45,8 +45,23 @@ def run(name, cfg, seq, off, check=3000, outs=("bc1",), reps=3):
     print(f"{name:34s} {n / ms / 1e3:9.2f} M reads/s  {ms:9.3f} ms  [{path}, R={info['reads_per_block']}, lds={info['lds_bytes_per_block']}]  oracle-sample {'OK' if ok else 'MISMATCH'}  matched {float((exp['bc1'] > 0).mean()):.2f}", flush=True)
 
 
+def bscale(n):
+    """Throughput against the size of the barcode set (the seed tables and LDS plan scale with it)."""
+    C = bdx.DemuxConfig
+    for B in (24, 96, 384, 768, 1536):
+        bcs = synth.make_barcodes(B, 24, seed=B)
+        seq, off, _ = synth.make_reads(bcs, n, 150)
+        base = dict(bc_seqs=bcs, bc_lengths_no_N=[24] * B, ids=[str(i) for i in range(B)])
+        run(f"B={B} rate0.1", C(**base, max_error_rate=0.1), seq, off, check=1500)
+        run(f"B={B} rate0.2", C(**base, max_error_rate=0.2), seq, off, check=1500)
+        run(f"B={B} rate0.1 trim5", C(**base, max_error_rate=0.1, trim_side=5), seq, off, check=1500,
+            outs=("bc1", "keep_start", "keep_end"))
+
+
 def main():
     n = int(os.environ.get("N", "2000000"))
+    if os.environ.get("BSCALE"):
+        return bscale(n)
     bcs = synth.make_barcodes(96, 24)
     seq, off, _ = synth.make_reads(bcs, n, 150)
     base = dict(bc_seqs=bcs, bc_lengths_no_N=[24] * 96, ids=[str(i) for i in range(96)])
