@@ -63,6 +63,7 @@ struct bdx_ctx {
     // candidate masks (filtered paths)
     DevBuf d_cand[2];
     DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel
+    DevBuf d_exc;                 // known-score mode: reads handed over to the exact kernel
     std::string err;
     std::string path;
     int64_t launches = 0;
@@ -148,7 +149,6 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     BdxBitparPlan &bp = ctx->bplan;
     bp = BdxBitparPlan{};
     if (c.filter == BDX_FILTER_OFF) return BDX_OK;
-    if (ctx->plan.bc_stage_bytes == 0) return BDX_OK;  // the fused kernel keeps all barcodes in LDS
     const int npass = c.is_dual ? 2 : 1;
     // cost domain: every edit operation must cost >= 1 and a match >= 0
     int cmin = 1;
@@ -677,6 +677,7 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->bp_tables.release();
     ctx->seed_tables.release();
     ctx->d_maxlen.release();
+    ctx->d_exc.release();
     ctx->d_seq.release();
     ctx->d_off.release();
     ctx->d_out_i32.release();
@@ -734,41 +735,53 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     }
     if (filtered) {
         ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->bplan.d_tile_counter, 0, sizeof(int), ctx->stream));
-        // Configs whose passes all sit in the known-score class finish inside the fused kernel.
-        // Otherwise (trimming / summary / weighted costs / N-scoring / Hamming / exact) the fused
-        // kernel only filters and the exact DP runs at full width in the generic kernel.
+        // The fused kernel filters; the exact DP runs at full width in the generic kernel:
+        //  * split (trimming / summary / weighted costs / N-scoring / Hamming / exact): every read's
+        //    candidate mask (+ column windows) goes through HBM, the generic kernel gives every verdict;
+        //  * known-score configs: the fused kernel also gives the verdict of (nearly) every read by
+        //    replaying the reducer; the few it cannot settle are listed and evaluated by the generic
+        //    kernel in list mode.
         const int npass = ctx->dev.is_dual ? 2 : 1;
         bool split = false;
         for (int k = 0; k < npass; ++k) split |= !ctx->bplan.known_ok[k];
-        if (getenv("BDX_NO_SPLIT")) split = false;
+        if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
-        if (split) {
-            const bool windows = ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !getenv("BDX_NO_WINDOWS");
-            for (int k = 0; k < npass; ++k) {
-                HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
-                if (windows) {
-                    HIP_TRY(ctx, ctx->d_wins[k].ensure((size_t)n_reads * BDX_WCAP * 3 * 4 + 64));
-                    HIP_TRY(ctx, ctx->d_wcnt[k].ensure((size_t)n_reads + 64));
-                }
-            }
-            c0 = (uint32_t *)ctx->d_cand[0].p;
-            c1 = npass > 1 ? (uint32_t *)ctx->d_cand[1].p : c0;
+        const bool windows = split && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !getenv("BDX_NO_WINDOWS");
+        for (int k = 0; k < npass; ++k) {
+            HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
             if (windows) {
-                w0 = (uint32_t *)ctx->d_wins[0].p;
-                n0 = (uint8_t *)ctx->d_wcnt[0].p;
-                w1 = npass > 1 ? (uint32_t *)ctx->d_wins[1].p : w0;
-                n1 = npass > 1 ? (uint8_t *)ctx->d_wcnt[1].p : n0;
+                HIP_TRY(ctx, ctx->d_wins[k].ensure((size_t)n_reads * BDX_WCAP * 3 * 4 + 64));
+                HIP_TRY(ctx, ctx->d_wcnt[k].ensure((size_t)n_reads + 64));
             }
         }
+        c0 = (uint32_t *)ctx->d_cand[0].p;
+        c1 = npass > 1 ? (uint32_t *)ctx->d_cand[1].p : c0;
+        if (windows) {
+            w0 = (uint32_t *)ctx->d_wins[0].p;
+            n0 = (uint8_t *)ctx->d_wcnt[0].p;
+            w1 = npass > 1 ? (uint32_t *)ctx->d_wins[1].p : w0;
+            n1 = npass > 1 ? (uint8_t *)ctx->d_wcnt[1].p : n0;
+        }
+        uint32_t *exc_list = nullptr;
+        unsigned int *exc_count = (unsigned int *)((char *)ctx->d_maxlen.p + 128);
+        if (!split) {
+            HIP_TRY(ctx, ctx->d_exc.ensure((size_t)n_reads * 4 + 64));
+            exc_list = (uint32_t *)ctx->d_exc.p;
+        }
+        // one memset clears the tile queue head (+64) and the hand-over count (+128)
+        HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_maxlen.p + 64, 0, 128, ctx->stream));
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
-                                       n1));
+                                       n1, split ? 1 : 0, exc_list, exc_count));
         if (split)
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
                                             npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr));
+        else
+            HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                            ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
+                                            nullptr, exc_list, exc_count));
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
         ctx->path = ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify";
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;

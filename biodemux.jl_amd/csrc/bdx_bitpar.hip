@@ -37,9 +37,7 @@ struct BitparArgs {
     long long n_reads;
     BdxDevOut out;
     unsigned long long *counts;
-    int dp_rows;
     int stage_bytes;     // capacity of EACH of the two staging areas (raw bytes, codes)
-    int bc_stage_bytes;
     int hist_entries;
     const uint8_t *lut;  // 256 bytes: byte -> symbol code
     const uint32_t *peq[2];
@@ -59,7 +57,10 @@ struct BitparArgs {
     const uint16_t *seed_always[2];
     uint32_t *wins_out[2];  // split mode: [n_reads][BDX_WCAP][3] = {barcode, first column, last column} of the exact run
     uint8_t *wcnt_out[2];   // split mode: entries valid per read (255 = none: whole window)
-    uint32_t *cand_out[2];  // split mode: candidate masks go to HBM, stage 2 runs in the generic kernel
+    uint32_t *cand_out[2];  // candidate masks in HBM for the reads the exact kernel evaluates (split: all of them)
+    int split;              // 1: this kernel only filters, every read's verdict comes from the exact kernel
+    uint32_t *exc_list;     // known-score mode: reads handed to the exact kernel after all (see stage 2)
+    unsigned int *exc_count;
     int *tile_counter;  // zeroed before every launch: dynamic tile queue
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
@@ -68,10 +69,11 @@ struct BitparArgs {
               // sweeps, 4 skip hit resolve, 8 skip seed scan, 16 skip 2-bit packing, 32 skip transcode, 64 skip copy
 };
 
-// 3 waves per SIMD (12 per CU) is the residency the LDS footprint of the 64-read tile allows; the
-// bound keeps the register allocator at <= 168 VGPRs so that residency is actually reached.
+// The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
+// VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
+// are short and barrier-separated, so throughput follows the number of resident waves closely.
 template <int BS, int R, bool SEED>
-__global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
+__global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -92,13 +94,6 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
         o = (o + bytes + 15) & ~(size_t)15;
         return p;
     };
-    LDS int *DPbase = (LDS int *)take((size_t)a.dp_rows * R * 4);
-    LDS int *OGbase = (LDS int *)take(cfg.any_traceback ? (size_t)a.dp_rows * R * 4 : 0);
-    LDS uint32_t *off0 = (LDS uint32_t *)take((size_t)(B0 + 1) * 4);
-    LDS uint32_t *off1 = (LDS uint32_t *)take((size_t)(B1 + 1) * 4);
-    LDS int *nn0 = (LDS int *)take((size_t)B0 * 4);
-    LDS int *nn1 = (LDS int *)take((size_t)B1 * 4);
-    LDS unsigned char *bcs = take((size_t)a.bc_stage_bytes);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
     LDS unsigned char *lut = take(256);
     LDS uint32_t *peq0 = (LDS uint32_t *)take((size_t)a.ncodes * a.bpad[0] * 4);
@@ -130,25 +125,23 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *srid = (LDS uint32_t *)take(SEED ? (size_t)R * RCAP * 4 : 0);   // per-read sweep records: id
     LDS int *srlo = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window start (min)
     LDS int *srhi = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
-    LDS uint32_t *spq = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // read << 16 | pass << 15 | barcode + 1
-    LDS uint32_t *spw = (LDS uint32_t *)take(SEED ? (size_t)PQCAP * 4 : 0);  // window lo << 16 | hi
+    // the sweep-record queue reuses the hit queue (dead once the hits are resolved; SQCAP = 2 * PQCAP)
+    LDS uint32_t *spq = shq;          // read << 16 | pass << 15 | barcode + 1
+    LDS uint32_t *spw = shq + PQCAP;  // window lo << 16 | hi
     LDS int *sqn = (LDS int *)take(32);  // [0] hits, [1] pairs, [2] current tile, [3] slot overflow, [4] window-queue fill, [5] some read needs the whole-read fallback
-    LDS uint32_t *wq = (LDS uint32_t *)take((size_t)4 * R * 4);  // split mode: candidates to re-sweep with column tracking
-    LDS int *wcl = (LDS int *)take((size_t)2 * R * 4);          // split mode: window entries written per read and pass
+    // split mode never enters the known-score class, so its work areas reuse that class's slots / counters
+    LDS uint32_t *wq = slots;  // split mode: candidates to re-sweep with column tracking (4 R entries)
+    LDS int *wcl = scnt;       // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
 
     // ---- tables -> LDS ----
-    for (int i = tid; i <= B0; i += BS) off0[i] = cfg.pass[0].bc_off[i];
     for (int i = tid; i < B0; i += BS) {
-        nn0[i] = cfg.pass[0].bc_len_no_N[i];
         pv0[i] = a.pvinit[0][i];
         kb0[i] = a.kb[0][i];
     }
     for (int i = tid; i < a.ncodes * a.bpad[0]; i += BS) peq0[i] = a.peq[0][i];
     if (cfg.is_dual) {
-        for (int i = tid; i <= B1; i += BS) off1[i] = cfg.pass[1].bc_off[i];
         for (int i = tid; i < B1; i += BS) {
-            nn1[i] = cfg.pass[1].bc_len_no_N[i];
             pv1[i] = a.pvinit[1][i];
             kb1[i] = a.kb[1][i];
         }
@@ -165,11 +158,10 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
             }
     }
     __syncthreads();
-    const int bytes0 = (int)off0[B0];
-    const int bytes1 = cfg.is_dual ? (int)off1[B1] : 0;
-    for (int i = tid; i < bytes0; i += BS) bcs[i] = lut[cfg.pass[0].bc_bytes[i]];  // barcodes as codes too
-    for (int i = tid; i < bytes1; i += BS) bcs[bytes0 + i] = lut[cfg.pass[1].bc_bytes[i]];
     const int ncode = a.ncode;
+    // kernel-argument arrays indexed by a per-lane pass number would be fetched with vector loads from
+    // the argument segment: select between two scalars instead
+    const int bsh0 = a.bshift[0], bsh1 = a.bshift[1];
 
     // ---- persistent workgroup: the tables above are loaded once, then the workgroup walks
     // tiles of R consecutive reads (tile = blockIdx.x, + gridDim.x, ...).  Tiles are independent;
@@ -204,7 +196,6 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
         sqn[4] = 0;
         sqn[5] = 0;
     }
-    for (int i = tid; i < 2 * R; i += BS) wcl[i] = 0;
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
     const long long r0 = tile * R;
     long long r1 = r0 + R;
@@ -226,7 +217,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     bool staged = slot ? true : (need + 16 <= (long long)a.stage_bytes);  // wave-uniform (whole workgroup)
     if (!slot && staged && !(a.dbg & 64)) {
         const int nvec = (int)((need + 15) >> 4);
-        const u32x4 *src = (const u32x4 *)g0a;
+        const GlobalVec16 src = (GlobalVec16)g0a;
         LDS u32x4 *dst = (LDS u32x4 *)rstage;
         for (int k = tid; k < nvec; k += BS) dst[k] = __builtin_nontemporal_load(src + k);
     }
@@ -281,7 +272,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int hd = roff[r] - r * slot + wlo[r];
                 if (16 * k < wlen[r] + hd) {
                     const uintptr_t src = ((uintptr_t)(a.seq + a.off[r0 + r] + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
-                    *(LDS u32x4 *)(rstage + r * slot + 16 * k) = __builtin_nontemporal_load((const u32x4 *)src);
+                    *(LDS u32x4 *)(rstage + r * slot + 16 * k) = __builtin_nontemporal_load((GlobalVec16)src);
                 }
             }
         }
@@ -370,7 +361,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     auto sweep2 = [&](Sweep &A, Sweep &Bw) __attribute__((always_inline)) {
         // both chains use the same symbol shift only when they belong to the same pass;
         // the shifts are per chain (uniform in the non-seeded path, per lane otherwise)
-        const int shA = a.bshift[A.p], shB = a.bshift[Bw.p];
+        const int shA = A.p ? bsh1 : bsh0, shB = Bw.p ? bsh1 : bsh0;
         const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
         int j = 0;
 #pragma unroll 4
@@ -619,7 +610,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
         __syncthreads();
     }
 
-    if (a.cand_out[0]) {
+    if (a.split) {
         // split mode: hand the candidate masks to the full-width exact kernel (bdx_generic_kernel,
         // 256 reads per workgroup).  Tiles that could not be staged pass every barcode.
         for (int p = 0; p < npass; ++p) {
@@ -661,7 +652,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                     setup(true, p, r, b, A);
                     const int kbv = (p ? kb1 : kb0)[b];
                     const int mm = A.score;  // barcode length before the first column
-                    const int sh = a.bshift[p];
+                    const int sh = p ? bsh1 : bsh0;
                     const int jf_abs = (int)(A.c - (codes + roff[r])) + 1;
                     int e_lo = 0, e_hi = -1;
                     for (int j = 0; j < A.ncol; ++j) {
@@ -674,7 +665,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
                     if (e_hi >= 0) {
                         const int kk = __hip_atomic_fetch_add(&wcl[p * R + r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (kk < BDX_WCAP) {
-                            uint32_t *dst = a.wins_out[p] + ((r0 + r) * BDX_WCAP + kk) * 3;
+                            uint32_t *dst = (p ? a.wins_out[1] : a.wins_out[0]) + ((r0 + r) * BDX_WCAP + kk) * 3;
                             dst[0] = (uint32_t)b;
                             dst[1] = (uint32_t)(e_lo - 2 * (mm + kbv) - 1);
                             dst[2] = (uint32_t)e_hi;
@@ -694,34 +685,40 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
         continue;
     }
 
-    // ---- stage 2: exact evaluation, one lane per read ----
+    // ---- stage 2 (configs whose passes all sit in the known-score class): the verdict of a read
+    // with at most four survivors per pass is a replay of the reducer on their unit distances
+    // (DESIGN.md §3.1).  The other reads — more survivors, a range that binds, or a tile that did not
+    // fit the staging area — are handed to the exact kernel through a list in HBM together with
+    // their candidate masks; this kernel holds no DP state at all. ----
     const bool active = tid < nr;
     const long long ridx = r0 + tid;
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
+    bool done = false;
     if (active && !(a.dbg & 1)) {
-        const long long ro = a.off[ridx];
-        const long long rn = a.off[ridx + 1] - ro;
-        const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
-        LDS int *DP = DPbase + tid;
-        LDS int *OG = OGbase + tid;
-        if (staged) {
-            const uint32_t *c0 = (const uint32_t *)(cand + tid * cw0);
-            const uint32_t *c1 = (const uint32_t *)(cand + R * cw0 + tid * cw1);
-            Bytes<true> r{rstage + roff[tid]};
-            Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            // more than four survivors (or a read outside the class): exact evaluation instead
+        const int cnt0 = scnt[0 * R + tid], cnt1 = scnt[1 * R + tid];
+        bool known = staged && full[0 * R + tid] && cnt0 <= 4;
+        if (npass > 1) known = known && full[1 * R + tid] && cnt1 <= 4;
+        if (known) {
             const LDS uint32_t *e0 = slots + (0 * R + tid) * 4;
             const LDS uint32_t *e1 = slots + (1 * R + tid) * 4;
-            const int cnt0 = scnt[0 * R + tid], cnt1 = scnt[1 * R + tid];
-            const KnownPass kn0{full[0 * R + tid] && cnt0 <= 4, e0[0], e0[1], e0[2], e0[3], cnt0};
-            const KnownPass kn1{npass > 1 && full[1 * R + tid] && cnt1 <= 4, e1[0], e1[1], e1[2], e1[3], cnt1};
-            classify_one<true>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, c0, c1, v, p1, p2, kn0, kn1, ncode);
-        } else {  // span larger than the staging area: unfiltered evaluation straight from HBM/L2
-            Bytes<false> r{a.seq + ro};
-            Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
-            classify_one<false>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, R, nullptr, nullptr, v, p1, p2);
+            const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt0};
+            const KnownPass kn1{true, e1[0], e1[1], e1[2], e1[3], cnt1};
+            const auto m0 = [&](const int b) { return (int)__builtin_popcount(pv0[b]); };
+            const auto m1 = [&](const int b) { return (int)__builtin_popcount(pv1[b]); };
+            classify_known(cfg, m0, m1, rlen[tid], kn0, kn1, v, p1, p2);
+            done = true;
+        } else {
+            for (int p = 0; p < npass; ++p) {
+                const int cw = p ? cw1 : cw0;
+                const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0) + tid * cw;
+                uint32_t *dst = (p ? a.cand_out[1] : a.cand_out[0]) + ridx * cw;
+                for (int w = 0; w < cw; ++w) dst[w] = staged ? cnd[w] : 0xFFFFFFFFu;
+            }
+            a.exc_list[atomicAdd(a.exc_count, 1u)] = (uint32_t)ridx;
         }
+    }
+    if (done) {
         if (a.out.bc1) a.out.bc1[ridx] = v.bc1;
         if (a.out.bc2) a.out.bc2[ridx] = v.bc2;
         if (a.out.keep_start) a.out.keep_start[ridx] = v.keep_start;
@@ -753,7 +750,7 @@ __global__ __launch_bounds__(BS, 3) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 
     // ---- DemuxStats scalar counters (accumulated in LDS across this workgroup's tiles) ----
-    if (a.counts && active) {
+    if (a.counts && done) {
         int slot = -1;
         if (v.bc1 > 0) slot = 4 + (v.bc1 - 1) * cfg.counts_stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
         const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
@@ -810,10 +807,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     const int B0 = cfg.pass[0].n_barcodes, B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
     const int cw0 = cfg.pass[0].cand_words, cw1 = cfg.is_dual ? cfg.pass[1].cand_words : 0;
     size_t o = 0;
-    o += al((size_t)gp.dp_rows_fused * R * 4);
-    o += al(cfg.any_traceback ? (size_t)gp.dp_rows_fused * R * 4 : 0);
-    o += al((size_t)(B0 + 1) * 4) + al((size_t)(B1 + 1) * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4);
-    o += al((size_t)gp.bc_stage_bytes) + al((size_t)gp.hist_entries * 4) + al(256);
+    o += al((size_t)gp.hist_entries * 4) + al(256);
     o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 3 * al((size_t)R * 4) + al((size_t)R * 16);
@@ -823,9 +817,9 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 16);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
         o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
-        o += 2 * al((size_t)(sp->rcap >= 16 ? 8 : 4) * R * 4) + al((size_t)R);
+        o += al((size_t)R);
     }
-    o += al(32) + al((size_t)4 * R * 4) + al((size_t)2 * R * 4);
+    o += al(32);
     return o;
 }
 
@@ -833,7 +827,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1,
                              hipStream_t stream, uint32_t *wins_out0, uint32_t *wins_out1, uint8_t *wcnt_out0,
-                             uint8_t *wcnt_out1) {
+                             uint8_t *wcnt_out1, int split, uint32_t *exc_list, unsigned int *exc_count) {
     if (n_reads <= 0) return hipSuccess;
     BitparArgs a;
     a.cfg = cfg;
@@ -842,9 +836,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.n_reads = n_reads;
     a.out = out;
     a.counts = d_counts;
-    a.dp_rows = gp.dp_rows_fused;
     a.stage_bytes = bp.stage_bytes;
-    a.bc_stage_bytes = gp.bc_stage_bytes;
     a.hist_entries = gp.hist_entries;
     a.lut = bp.d_lut;
     for (int k = 0; k < 2; ++k) {
@@ -859,6 +851,9 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.dbg = 0;
     a.slot_bytes = bp.slot_bytes;
     a.ncode = bp.ncode_N;
+    a.split = split;
+    a.exc_list = exc_list;
+    a.exc_count = exc_count;
     a.cand_out[0] = cand_out0;
     a.cand_out[1] = cand_out1;
     a.wins_out[0] = wins_out0;

@@ -5,6 +5,9 @@
 
 #define LDS __attribute__((address_space(3)))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// pointers rebuilt from integer arithmetic lose their address space and would compile to flat_load (which
+// also counts on lgkmcnt and so stalls every LDS wait): name the global address space explicitly
+typedef const u32x4 __attribute__((address_space(1))) *GlobalVec16;
 
 namespace {
 
@@ -562,7 +565,8 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 // unit-cost semi-global distance delivered by the bit-vector sweep.  `entries` holds up to four
 // (barcode << 8 | d) words of this read in arbitrary order; they are replayed in ascending
 // barcode (= file) order through the very same reducer.
-__device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const LDS uint32_t *bc_off,
+template <class MLen>
+__device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const MLen mlen,
                                                   const uint32_t e0, const uint32_t e1, const uint32_t e2,
                                                   const uint32_t e3, const int count) {
     Reducer red;
@@ -580,7 +584,7 @@ __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const LD
         const uint32_t e = pick - 1u;
         const int b = (int)(e >> 8);
         const int d = (int)(e & 255u);
-        const int m = (int)bc_off[b + 1] - (int)bc_off[b];
+        const int m = mlen(b);  // barcode length
         const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
         AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};
         const double score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :155-160
@@ -615,14 +619,16 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
     // determine_filename, classification.jl:871-938
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-    p1 = kn0.use ? run_pass_known(cfg, off0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
+    const auto m0 = [&](const int b) { return (int)off0[b + 1] - (int)off0[b]; };
+    const auto m1 = [&](const int b) { return (int)off1[b + 1] - (int)off1[b]; };
+    p1 = kn0.use ? run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
                  : run_pass<STAGED, REGM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode, went0, wcount0);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
-        p2 = kn1.use ? run_pass_known(cfg, off1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
+        p2 = kn1.use ? run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
                      : run_pass<STAGED, REGM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode, went1, wcount1);
         if (p2.status != 1) {
             v.bc1 = p2.status;
@@ -655,5 +661,37 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
     }
 }
 
+
+// determine_filename (classification.jl:871-938) for a read whose passes all sit in the known-score
+// class: both passes are reducer replays, nothing is aligned, nothing is trimmed (ScoreOnly configs
+// have no trim side; the keep range is the whole read as in :907-908, :932-935).
+template <class MLen0, class MLen1>
+__device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0 m0, const MLen1 m1, const int n,
+                                               const KnownPass kn0, const KnownPass kn1, Verdict &v, PassOut &p1,
+                                               PassOut &p2) {
+    v = Verdict{0, 0, -1, -1};
+    p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
+    p1 = run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
+    if (p1.status != 1) {  // :879-883
+        v.bc1 = p1.status;
+        return;
+    }
+    if (cfg.is_dual) {  // :887-895
+        p2 = run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
+        if (p2.status != 1) {
+            v.bc1 = p2.status;
+            return;
+        }
+        v.bc2 = p2.bc;
+    }
+    v.bc1 = p1.bc;
+    if (n < 1) {  // :932-935 (keep_start 1 > keep_end n)
+        v.keep_start = 1;
+        v.keep_end = 0;
+    } else {
+        v.keep_start = 1;
+        v.keep_end = n;
+    }
+}
 
 }  // namespace

@@ -38,6 +38,8 @@ struct GenericArgs {
     const uint8_t *wcnt[2];   // [n_reads] entries valid (255: none -> whole window)
     int dp_rows;
     int stage_bytes;    // capacity of the read staging area (0: never stage)
+    const uint32_t *list;             // list mode: the reads to evaluate (indices into the batch) ...
+    const unsigned int *list_count;  // ... and how many (device-resident; the grid strides over them)
     int bc_stage_bytes; // bytes of the barcode staging area (both passes; 0: barcodes not staged)
     int hist_entries;
 };
@@ -95,27 +97,42 @@ __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
         for (int i = tid; i < bytes1; i += BS) bcs[bytes0 + i] = cfg.pass[1].bc_bytes[i];
     }
 
-    // this workgroup's reads: [r0, r1)
-    const long long r0 = (long long)blockIdx.x * BS;
-    long long r1 = r0 + BS;
-    if (r1 > a.n_reads) r1 = a.n_reads;
-    const long long span0 = a.off[r0];
-    const long long span1 = a.off[r1];
-    const uintptr_t g0 = (uintptr_t)(a.seq + span0);
-    const uintptr_t g0a = g0 & ~(uintptr_t)15;
-    const int head = (int)(g0 - g0a);
-    const long long need = (span1 - span0) + head;
-    const bool staged = bc_staged && a.stage_bytes > 0 && need + 16 <= (long long)a.stage_bytes;
-    if (staged) {  // coalesced 16-B copy of the contiguous span, each HBM byte fetched once
-        const int nvec = (int)((need + 15) >> 4);
-        const u32x4 *src = (const u32x4 *)g0a;
-        LDS u32x4 *dst = (LDS u32x4 *)rstage;
-        for (int k = tid; k < nvec; k += BS) dst[k] = __builtin_nontemporal_load(src + k);
+    // Two ways to walk the batch:
+    //  * dense (a.list == nullptr): workgroup b evaluates reads [b*BS, (b+1)*BS), staged as one span;
+    //  * list: the reads named by a.list[0 .. *a.list_count) (the fused filter kernel's hand-overs) —
+    //    scattered, so they are read straight from HBM/L2; the grid strides over the list.
+    const bool listed = a.list != nullptr;
+    long long total = a.n_reads;
+    if (listed) {
+        const long long c = (long long)*a.list_count;
+        total = c < a.n_reads ? c : a.n_reads;
     }
-    __syncthreads();
+    for (long long base = (long long)blockIdx.x * BS; base < total; base += listed ? (long long)gridDim.x * BS : total) {
+    const long long r0 = base;
+    long long r1 = r0 + BS;
+    if (r1 > total) r1 = total;
+    long long span0 = 0;
+    int head = 0;
+    bool staged = false;
+    if (!listed) {
+        span0 = a.off[r0];
+        const long long span1 = a.off[r1];
+        const uintptr_t g0 = (uintptr_t)(a.seq + span0);
+        const uintptr_t g0a = g0 & ~(uintptr_t)15;
+        head = (int)(g0 - g0a);
+        const long long need = (span1 - span0) + head;
+        staged = bc_staged && a.stage_bytes > 0 && need + 16 <= (long long)a.stage_bytes;
+        if (staged) {  // coalesced 16-B copy of the contiguous span, each HBM byte fetched once
+            const int nvec = (int)((need + 15) >> 4);
+            const GlobalVec16 src = (GlobalVec16)g0a;
+            LDS u32x4 *dst = (LDS u32x4 *)rstage;
+            for (int k = tid; k < nvec; k += BS) dst[k] = __builtin_nontemporal_load(src + k);
+        }
+        __syncthreads();
+    }
 
-    const long long ridx = r0 + tid;
-    const bool active = ridx < r1;
+    const bool active = r0 + tid < r1;
+    const long long ridx = listed ? (active ? (long long)a.list[r0 + tid] : 0) : r0 + tid;
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     if (active) {
@@ -190,12 +207,13 @@ __global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
                 if (slot >= 0) atomicAdd(&a.counts[slot], 1ULL);
             }
         }
-        if (a.hist_entries > 0) {
-            __syncthreads();
-            for (int i = tid; i < a.hist_entries; i += BS) {
-                const int h = hist[i];
-                if (h) atomicAdd(&a.counts[i], (unsigned long long)h);
-            }
+    }
+    }  // dense: one trip; list: grid stride
+    if (a.counts && a.hist_entries > 0) {
+        __syncthreads();
+        for (int i = tid; i < a.hist_entries; i += BS) {
+            const int h = hist[i];
+            if (h) atomicAdd(&a.counts[i], (unsigned long long)h);
         }
     }
 }
@@ -248,7 +266,8 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               const long long *d_off, long long n_reads, const BdxDevOut &out,
                               unsigned long long *d_counts, const uint32_t *d_cand0, const uint32_t *d_cand1,
                               hipStream_t stream, const uint32_t *d_wins0, const uint32_t *d_wins1,
-                              const uint8_t *d_wcnt0, const uint8_t *d_wcnt1) {
+                              const uint8_t *d_wcnt0, const uint8_t *d_wcnt1, const uint32_t *d_list,
+                              const unsigned int *d_list_count) {
     if (n_reads <= 0) return hipSuccess;
     GenericArgs a;
     a.cfg = cfg;
@@ -263,12 +282,15 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     a.wins[1] = d_wins1;
     a.wcnt[0] = d_wcnt0;
     a.wcnt[1] = d_wcnt1;
+    a.list = d_list;
+    a.list_count = d_list_count;
     a.dp_rows = plan.dp_rows;
     a.stage_bytes = plan.stage_bytes;
     a.bc_stage_bytes = plan.bc_stage_bytes;
     a.hist_entries = plan.hist_entries;
-    const long long blocks = (n_reads + plan.threads - 1) / plan.threads;
+    long long blocks = (n_reads + plan.threads - 1) / plan.threads;
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    if (d_list && blocks > 1024) blocks = 1024;  // list mode: the hand-overs are few; the grid strides
     const dim3 grid((unsigned)blocks), block((unsigned)plan.threads);
     if (plan.reg_rows == 24 && plan.threads == 256) {
         hipLaunchKernelGGL((bdx_generic_kernel<256, 24>), grid, block, plan.lds_bytes, stream, a);

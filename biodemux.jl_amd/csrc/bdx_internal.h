@@ -115,8 +115,8 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
 hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, const BdxBitparPlan &bp,
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1, hipStream_t stream,
-                             uint32_t *wins_out0 = nullptr, uint32_t *wins_out1 = nullptr, uint8_t *wcnt_out0 = nullptr,
-                             uint8_t *wcnt_out1 = nullptr);
+                             uint32_t *wins_out0, uint32_t *wins_out1, uint8_t *wcnt_out0, uint8_t *wcnt_out1, int split,
+                             uint32_t *exc_list, unsigned int *exc_count);
 // max read length of a device-resident batch (one tiny kernel; result written to *d_out)
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
 
@@ -126,5 +126,6 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               unsigned long long *d_counts, const uint32_t *d_cand0,
                               const uint32_t *d_cand1, hipStream_t stream, const uint32_t *d_wins0 = nullptr,
                               const uint32_t *d_wins1 = nullptr, const uint8_t *d_wcnt0 = nullptr,
-                              const uint8_t *d_wcnt1 = nullptr);
+                              const uint8_t *d_wcnt1 = nullptr, const uint32_t *d_list = nullptr,
+                              const unsigned int *d_list_count = nullptr);
 hipError_t bdx_generic_set_lds_limit(size_t bytes);

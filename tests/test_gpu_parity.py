@@ -263,6 +263,22 @@ def test_seed_queue_overflow_low_complexity():
     assert (exp["bc1"] != 0).mean() > 0.3
 
 
+def test_known_class_handover_many_survivors():
+    """A family of near-identical barcodes leaves more than four survivors per read: the fused
+    kernel cannot replay the reducer for such reads and hands them (with their candidate masks) to
+    the exact kernel's list mode.  Results must not depend on which kernel gave the verdict."""
+    base = synth.make_barcodes(1, 24, seed=77)[0]
+    fam = [base]
+    for i in range(9):  # one substitution each, at different positions
+        j = 2 * i + 1
+        fam.append(base[:j] + ("A" if base[j] != "A" else "C") + base[j + 1:])
+    bcs = fam + synth.make_barcodes(22, 24, seed=78)
+    seq, off, _ = synth.make_reads(bcs, 20000, 150, seed=79)
+    for kw in (dict(), dict(min_delta=0.05), dict(max_error_rate=0.13)):
+        exp = _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path="qgram+bitpar+verify")
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
 @pytest.mark.parametrize("hint", [40, 150, 400])
 def test_seed_ragged_reads_and_wrong_hint(hint):
     """A read-length hint that is too small (tiles not staged / tails beyond the planned group
