@@ -94,6 +94,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         o = (o + bytes + 15) & ~(size_t)15;
         return p;
     };
+    // the seed bitmap sits at LDS offset 0: its byte probes then need no base address arithmetic
+    LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
     LDS unsigned char *lut = take(256);
     LDS uint32_t *peq0 = (LDS uint32_t *)take((size_t)a.ncodes * a.bpad[0] * 4);
@@ -116,7 +118,6 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS unsigned char *rstage = take((size_t)a.stage_bytes + 16);
     LDS unsigned char *codes = rstage;
     // seeding work areas (SEED variant only)
-    LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
     LDS uint32_t *shash = (LDS uint32_t *)take(SEED && a.seed_hash_in_lds ? ((size_t)4 << a.seed_hash_log2) : 0);
     LDS unsigned char *spk = take(SEED ? (size_t)(a.stage_bytes >> 2) + 16 : 0);  // flat 2-bit image of the staging area
     LDS unsigned char *shps = take(SEED && a.seed_hash_in_lds ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
@@ -451,11 +452,24 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     i1 = i1 > 7 ? 7 : i1;
                     const uint32_t w = (uint32_t)spk16[F] | ((uint32_t)spk16[F + 1] << 16);
                     uint32_t hits = 0;
+                    // the bitmap starts at LDS address 0 (first region of the carve-up, the kernel has no static
+                    // LDS): a byte's address is its index, no base register and no add per probe
+                    const auto probe = [](const uint32_t hb) __attribute__((always_inline)) {
+                        return (uint32_t) * (const LDS unsigned char *)(uintptr_t)(hb >> 3);
+                    };
+                    if (bm_direct) {  // workgroup-uniform: the bitmap spans the key space
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const uint32_t key = (w >> (2 * i)) & kmask;
-                        const uint32_t hb = bm_direct ? key : ((key ^ (key >> bml)) & bmmask);
-                        hits |= ((sbm[hb >> 5] >> (hb & 31)) & 1u) << i;
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t hb = __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
+                            hits |= __builtin_amdgcn_ubfe(probe(hb), hb & 7u, 1) << i;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t key = __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
+                            const uint32_t hb = (key ^ (key >> bml)) & bmmask;
+                            hits |= __builtin_amdgcn_ubfe(probe(hb), hb & 7u, 1) << i;
+                        }
                     }
                     hits = i0 <= i1 ? (hits & ((2u << i1) - (1u << i0))) : 0u;
                     // rounds: every lane with a hit left appends its lowest one
