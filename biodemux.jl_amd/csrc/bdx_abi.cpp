@@ -377,11 +377,15 @@ int build_seed_tables(bdx_ctx *ctx) {
 
 // Geometry of the fused kernel for a given typical read length: the largest R whose LDS
 // footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
-bool size_bitpar(bdx_ctx *ctx, int read_len) {
+bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     BdxBitparPlan &bp = ctx->bplan;
     if (!bp.enabled) return false;
     if (read_len < 1) read_len = 1;
-    if (bp.read_len_hint == read_len && bp.reads_per_block > 0) return true;
+    // small batches: keep >= ~1024 tiles in flight (4 per CU) before growing the tile
+    int r_cap = 256;
+    while (r_cap > 16 && n_reads / r_cap < 1024) r_cap >>= 1;
+    if (bp.read_len_hint == read_len && bp.r_cap == r_cap && bp.reads_per_block > 0) return true;
+    bp.r_cap = r_cap;
     int forced = 0;
     if (const char *e = getenv("BDX_BITPAR_R")) forced = atoi(e);
     // Pick the R that keeps the most waves resident per CU (the sweep is latency-bound):
@@ -434,6 +438,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
         if (forced && R != forced) continue;
+        if (!forced && R > r_cap) continue;
         if (!forced && !ctx->splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
         size_t st = slot_mode ? (size_t)R * (size_t)slot : (size_t)R * (size_t)read_len + 64;
         st = (st + 15) & ~(size_t)15;
@@ -466,7 +471,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len) {
         // the seed tables do not fit next to everything else (very many barcodes): keep the
         // sweep filter, drop the seeds, and plan again
         ctx->splan.enabled = 0;
-        return size_bitpar(ctx, read_len);
+        return size_bitpar(ctx, read_len, n_reads);
     }
     bp.reads_per_block = 0;
     bp.read_len_hint = 0;
@@ -731,7 +736,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             len = host_len;
         }
-        filtered = size_bitpar(ctx, len);
+        filtered = size_bitpar(ctx, len, n_reads);
     }
     if (filtered) {
         ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *wq = slots;  // split mode: candidates to re-sweep with column tracking (4 R entries)
     LDS int *wcl = scnt;       // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
+    LDS uint32_t *slh = (LDS uint32_t *)take(SEED ? (size_t)R * 4 : 0);  // per read: first | (last + 1) << 16 seed start, relative to the first staged base
+    LDS int *srw = (LDS int *)take(SEED ? (size_t)R * 4 : 0);            // per read: stage offset of its first staged base
 
     // ---- tables -> LDS ----
     for (int i = tid; i < B0; i += BS) {
@@ -176,6 +178,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     __syncthreads();  // the previous tile's stage 2 is done with the per-tile LDS state
     if (tid == 0) {
         sqn[2] = next_tile;  // dynamic tile queue (exit: queue drained)
+        // per-tile flags that other lanes SET before the next barrier are cleared here, one barrier earlier
+        sqn[3] = 0;
+        sqn[4] = 0;
+        sqn[5] = 0;
         next_tile = atomicAdd(a.tile_counter, 1);
     }
     __syncthreads();
@@ -191,11 +197,6 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             srhi[i] = 0;
         }
         if (tid < 2) sqn[tid] = 0;
-    }
-    if (tid == 0) {
-        sqn[3] = 0;
-        sqn[4] = 0;
-        sqn[5] = 0;
     }
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
     const long long r0 = tile * R;
@@ -229,11 +230,16 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
         rlen[t] = n;
         int ulo = 0x7FFFFFFF, uhi = 0;
+        int f_p0 = 1, l_p0 = 0;
         for (int p = 0; p < npass; ++p) {
             PassWindow w;
             const bool ok = pass_window(cfg.pass[p], n, w);
             int f = ok ? (w.first > 1 ? w.first : 1) : 1;
             int l = ok ? (w.last < n ? w.last : n) : 0;
+            if (p == 0) {
+                f_p0 = f;
+                l_p0 = l;
+            }
             win[(p * 2 + 0) * R + t] = f;
             win[(p * 2 + 1) * R + t] = l;
             if (l >= f) {
@@ -261,6 +267,34 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             roff[t] = head + (int)(ro - span0);
             wlo[t] = 0;
             wlen[t] = n;
+        }
+        if (SEED) {
+            // seed scan parameters of this read: the 0-based start positions [lo, hi] that may begin a
+            // seed, relative to the first staged base
+            const int q = a.seed_q;
+            const int base = slot ? ulo : 0, wl = slot ? uhi - ulo : n;
+            int lo, hi;
+            if (npass == 1) {
+                lo = f_p0 - 1;
+                hi = (sgm ? l_p0 : n) - q;
+                if (l_p0 < f_p0) hi = -1;
+            } else {
+                lo = base;
+                hi = base + wl - q;
+            }
+            if (lo < base) lo = base;
+            if (hi > base + wl - q) hi = base + wl - q;  // never beyond the staged bases
+            int lor = lo - base, hir = hi - base;
+            if (hir < lor || hir < 0 || lor > 0xFFFF) {
+                lor = 1;
+                hir = 0;
+            }
+            if (hir > 0xFFFE) hir = 0xFFFE;  // (positions are 16-bit throughout the seeded path)
+            slh[t] = (uint32_t)lor | ((uint32_t)(hir + 1) << 16);
+            srw[t] = roff[t] + base;
+            // a read longer than the planned group count would leave its tail unscanned:
+            // sweep every barcode of it instead (lossless fallback)
+            if (wl + 7 > 8 * a.seed_groups || wl > 0xFFF0) sall[t] = 1, sqn[5] = 1;
         }
     }
     __syncthreads();
@@ -413,10 +447,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // whole-window minimum whenever the latter is <= kb — the only case anything
             // downstream looks at.
             const int q = a.seed_q;
-            const uint32_t kmask = (q >= 16) ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u);
             // scan: lane = (read, group of 8 consecutive bases of the flat 2-bit image); the group's 8 start
-            // positions share one 32-bit window (8 + 7 bases), every key is probed in the bitmap, and the
-            // hits of a wave are appended to the hit queue with one LDS atomic per round
+            // positions share one 32-bit window (8 + 7 bases), every key is probed in the bitmap.  The
+            // hit counts of a wave are prefix-summed with four ballots (counts are <= 8), one lane
+            // reserves the wave's range of the hit queue, every lane then writes its own hits.
             {
                 const int G = a.seed_groups;  // 8-base groups per read (uniform upper bound)
                 const int lane = tid & 63;
@@ -427,36 +461,21 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const uint32_t bmmask = (1u << bml) - 1u;
                 const bool bm_direct = bml >= 2 * q;
                 const LDS unsigned short *spk16 = (const LDS unsigned short *)spk;
+                // the bitmap starts at LDS address 0 (first region of the carve-up, the kernel has no static
+                // LDS): a byte's address is its index, no base register and no add per probe
+                const auto probe = [](const uint32_t hb) __attribute__((always_inline)) {
+                    return (uint32_t) * (const LDS unsigned char *)(uintptr_t)(hb >> 3);
+                };
                 for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
-                    const int nread = rlen[r];
-                    const int base = wlo[r];
-                    const int ro = roff[r];
-                    int lo, hi;  // 0-based start positions [lo, hi] that may begin a seed
-                    if (npass == 1) {
-                        lo = win[0 * R + r] - 1;
-                        hi = (sg ? win[1 * R + r] : nread) - q;
-                        if (win[1 * R + r] < win[0 * R + r]) hi = -1;
-                    } else {
-                        lo = base;
-                        hi = base + wlen[r] - q;
-                    }
-                    if (lo < base) lo = base;
-                    if (hi > base + wlen[r] - q) hi = base + wlen[r] - q;  // never beyond the staged bases
-                    // a read longer than the planned group count would leave its tail unscanned:
-                    // sweep every barcode of it instead (lossless fallback)
-                    if (g == 0 && wlen[r] + 7 > 8 * G) sall[r] = 1, sqn[5] = 1;
-                    const int F = ((ro + base) >> 3) + g;  // flat group: staged bytes 8F .. 8F+7
-                    const int pos0 = 8 * F - ro;           // read position (0-based) of the group's first base
-                    int i0 = lo - pos0, i1 = hi - pos0;    // valid start positions of this group: i0 <= i <= i1
+                    const int rw = srw[r];
+                    const uint32_t lh = slh[r];
+                    const int F = (rw >> 3) + g;  // flat group: staged bytes 8F .. 8F+7
+                    const int p0 = 8 * F - rw;    // position of the group's first base relative to the first staged base
+                    int i0 = (int)(lh & 0xFFFFu) - p0, i1 = (int)(lh >> 16) - 1 - p0;  // valid starts: i0 <= i <= i1
                     i0 = i0 < 0 ? 0 : i0;
                     i1 = i1 > 7 ? 7 : i1;
                     const uint32_t w = (uint32_t)spk16[F] | ((uint32_t)spk16[F + 1] << 16);
                     uint32_t hits = 0;
-                    // the bitmap starts at LDS address 0 (first region of the carve-up, the kernel has no static
-                    // LDS): a byte's address is its index, no base register and no add per probe
-                    const auto probe = [](const uint32_t hb) __attribute__((always_inline)) {
-                        return (uint32_t) * (const LDS unsigned char *)(uintptr_t)(hb >> 3);
-                    };
                     if (bm_direct) {  // workgroup-uniform: the bitmap spans the key space
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
@@ -472,27 +491,31 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         }
                     }
                     hits = i0 <= i1 ? (hits & ((2u << i1) - (1u << i0))) : 0u;
-                    // rounds: every lane with a hit left appends its lowest one
-                    for (;;) {
-                        const bool has = hits != 0u;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-                        if (!m) break;
-                        const int leader = __builtin_ctzll(m);
+                    // exclusive prefix sum of the per-lane hit counts over the wave, bit plane by bit plane
+                    const uint32_t cnt = (uint32_t)__builtin_popcount(hits);
+                    int pre = 0, tot = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64((cnt >> k) & 1u);
+                        pre += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
+                        tot += (int)__builtin_popcountll(m) << k;
+                    }
+                    if (tot) {  // wave-uniform
                         int basek = 0;
-                        if (lane == leader)
-                            basek = __hip_atomic_fetch_add(&sqn[0], (int)__builtin_popcountll(m), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                        basek = __shfl(basek, leader, 64);
-                        if (has) {
+                        if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                            basek = __hip_atomic_fetch_add(&sqn[0], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        basek = __builtin_amdgcn_readfirstlane(basek);
+                        int k = basek + pre;
+                        while (hits) {
                             const int i = __builtin_ctz(hits);
                             hits &= hits - 1u;
-                            const int k = basek + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
                             if (k < SQCAP) {
-                                shq[k] = ((uint32_t)(pos0 + i - base) << 16) | ((w >> (2 * i)) & kmask);
+                                shq[k] = ((uint32_t)(p0 + i) << 16) | __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
                                 shr[k] = (unsigned char)r;
                             } else {
                                 sall[r] = 1, sqn[5] = 1;  // hit queue full: sweep every barcode of this read instead
                             }
+                            ++k;
                         }
                     }
                 }
@@ -831,7 +854,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 16);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
         o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
-        o += al((size_t)R);
+        o += al((size_t)R) + 2 * al((size_t)R * 4);
     }
     o += al(32);
     return o;

@@ -79,6 +79,7 @@ struct BdxBitparPlan {
     int reads_per_block;   // R: 256 / 128 / 64 / 32 / 16
     int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
     int read_len_hint;     // the read length the geometry was planned for
+    int r_cap;             // ... and the tile-size cap the batch size implied
     int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
     int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
