@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS unsigned char *codes = rstage;
     // seeding work areas (SEED variant only)
     LDS uint32_t *shash = (LDS uint32_t *)take(SEED && a.seed_hash_in_lds ? ((size_t)4 << a.seed_hash_log2) : 0);
-    LDS unsigned char *spk = take(SEED ? (size_t)(a.stage_bytes >> 2) + 16 : 0);  // flat 2-bit image of the staging area
+    LDS unsigned char *spk = take(SEED ? (size_t)(a.stage_bytes >> 2) + 32 : 0);  // flat 2-bit image of the staging area
     LDS unsigned char *shps = take(SEED && a.seed_hash_in_lds ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
     LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);      // seed hits: position << 16 | key
     LDS unsigned char *shr = take(SEED ? (size_t)SQCAP : 0);                       // ... and their read
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             srw[t] = roff[t] + base;
             // a read longer than the planned group count would leave its tail unscanned:
             // sweep every barcode of it instead (lossless fallback)
-            if (wl + 7 > 8 * a.seed_groups || wl > 0xFFF0) sall[t] = 1, sqn[5] = 1;
+            if (wl + 15 > 16 * a.seed_groups || wl > 0xFFF0) sall[t] = 1, sqn[5] = 1;
         }
     }
     __syncthreads();
@@ -447,12 +447,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // whole-window minimum whenever the latter is <= kb — the only case anything
             // downstream looks at.
             const int q = a.seed_q;
-            // scan: lane = (read, group of 8 consecutive bases of the flat 2-bit image); the group's 8 start
-            // positions share one 32-bit window (8 + 7 bases), every key is probed in the bitmap.  The
-            // hit counts of a wave are prefix-summed with four ballots (counts are <= 8), one lane
+            // scan: lane = (read, group of 16 consecutive bases of the flat 2-bit image); the group's 16
+            // start positions share one 64-bit window (16 + 7 bases), every key is probed in the bitmap.  The
+            // hit counts of a wave are prefix-summed with four ballots (counts are <= 16), one lane
             // reserves the wave's range of the hit queue, every lane then writes its own hits.
             {
-                const int G = a.seed_groups;  // 8-base groups per read (uniform upper bound)
+                const int G = a.seed_groups;  // 16-base groups per read (uniform upper bound)
                 const int lane = tid & 63;
                 const int dr = BS / G, dg = BS - dr * G;
                 int r = tid / G, g = tid - r * G;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int bml = a.seed_bm_log2;
                 const uint32_t bmmask = (1u << bml) - 1u;
                 const bool bm_direct = bml >= 2 * q;
-                const LDS unsigned short *spk16 = (const LDS unsigned short *)spk;
+                const LDS uint32_t *spk32 = (const LDS uint32_t *)spk;
                 // the bitmap starts at LDS address 0 (first region of the carve-up, the kernel has no static
                 // LDS): a byte's address is its index, no base register and no add per probe
                 const auto probe = [](const uint32_t hb) __attribute__((always_inline)) {
@@ -469,23 +469,25 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
                     const int rw = srw[r];
                     const uint32_t lh = slh[r];
-                    const int F = (rw >> 3) + g;  // flat group: staged bytes 8F .. 8F+7
-                    const int p0 = 8 * F - rw;    // position of the group's first base relative to the first staged base
+                    const int F = (rw >> 4) + g;  // flat group: staged bytes 16F .. 16F+15
+                    const int p0 = 16 * F - rw;   // position of the group's first base relative to the first staged base
                     int i0 = (int)(lh & 0xFFFFu) - p0, i1 = (int)(lh >> 16) - 1 - p0;  // valid starts: i0 <= i <= i1
                     i0 = i0 < 0 ? 0 : i0;
-                    i1 = i1 > 7 ? 7 : i1;
-                    const uint32_t w = (uint32_t)spk16[F] | ((uint32_t)spk16[F + 1] << 16);
+                    i1 = i1 > 15 ? 15 : i1;
+                    const uint32_t w0 = spk32[F], w1 = spk32[F + 1];  // bases 0..15 and 16..31 of the group's window
                     uint32_t hits = 0;
                     if (bm_direct) {  // workgroup-uniform: the bitmap spans the key space
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const uint32_t hb = __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
+                        for (int i = 0; i < 16; ++i) {
+                            const uint32_t hb = (i <= 8 ? __builtin_amdgcn_ubfe(w0, 2 * i, 2 * q)  /* q <= 8: the key lies inside w0 */
+                                                             : __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, 2 * i), 0, 2 * q));
                             hits |= __builtin_amdgcn_ubfe(probe(hb), hb & 7u, 1) << i;
                         }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const uint32_t key = __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
+                        for (int i = 0; i < 16; ++i) {
+                            const uint32_t key = (i <= 8 ? __builtin_amdgcn_ubfe(w0, 2 * i, 2 * q)  /* q <= 8: the key lies inside w0 */
+                                                             : __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, 2 * i), 0, 2 * q));
                             const uint32_t hb = (key ^ (key >> bml)) & bmmask;
                             hits |= __builtin_amdgcn_ubfe(probe(hb), hb & 7u, 1) << i;
                         }
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     const uint32_t cnt = (uint32_t)__builtin_popcount(hits);
                     int pre = 0, tot = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 5; ++k) {
                         const unsigned long long m = __builtin_amdgcn_ballot_w64((cnt >> k) & 1u);
                         pre += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << k;
                         tot += (int)__builtin_popcountll(m) << k;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                             const int i = __builtin_ctz(hits);
                             hits &= hits - 1u;
                             if (k < SQCAP) {
-                                shq[k] = ((uint32_t)(p0 + i) << 16) | __builtin_amdgcn_ubfe(w, 2 * i, 2 * q);
+                                shq[k] = ((uint32_t)(p0 + i) << 16) | __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, 2 * i), 0, 2 * q);
                                 shr[k] = (unsigned char)r;
                             } else {
                                 sall[r] = 1, sqn[5] = 1;  // hit queue full: sweep every barcode of this read instead
@@ -851,7 +853,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled) {
-        o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 16);
+        o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 32);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
         o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
@@ -902,7 +904,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.known_ok[1] = bp.known_ok[1];
     if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
     a.seed_q = sp.q;
-    a.seed_groups = (bp.seed_span + 7 + 7) / 8;  // 8-base groups of the flat image that can overlap one read
+    a.seed_groups = (bp.seed_span + 15 + 15) / 16;  // 16-base groups of the flat image that can overlap one read
     a.seed_hash_log2 = sp.hash_log2;
     a.seed_bm_words = sp.bm_words;
     a.seed_bm_log2 = sp.bm_log2;
