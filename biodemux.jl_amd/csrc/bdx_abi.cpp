@@ -375,6 +375,114 @@ int build_seed_tables(bdx_ctx *ctx) {
     return BDX_OK;
 }
 
+// ---- two-intact-pieces ("diagonal") seeding for budgets where single pieces are too short -----
+// With kb operations allowed, kb+2 disjoint pieces of the barcode leave at least TWO untouched; they
+// occur in the read on diagonals (read position - barcode offset) that differ by at most kb (the
+// indels between them), and the alignment starts within kb of either diagonal.  The kernel keeps,
+// per read, an inverted index of its 4-mers (256 keys x position bits) and tests every (read,
+// barcode) pair with a handful of word operations per piece; only pairs with two such pieces are
+// swept, over the columns [d_min - kb - 1, d_max + m + kb + 1).  Lossless for the same reason as the
+// single-piece seeds: it only skips pairs whose unit distance exceeds kb.
+int build_diag_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxSeedPlan &sp = ctx->splan;
+    if (sp.enabled || !ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || getenv("BDX_NO_SEED") || getenv("BDX_NO_DIAG"))
+        return BDX_OK;
+    const int npass = c.is_dual ? 2 : 1;
+    int cmin = 1;
+    if (c.algorithm == BDX_ALG_SEMIGLOBAL) {
+        cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
+        if (c.has_nindel && c.nindel < cmin) cmin = c.nindel;
+    }
+    const bool n_wild = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) || c.algorithm == BDX_ALG_HAMMING;
+    int code_of[256];
+    for (int i = 0; i < 256; ++i) code_of[i] = -1;
+    int K = 0;
+    for (int k = 0; k < npass; ++k)
+        for (uint32_t i = 0; i < c.pass[k].bc_off[c.pass[k].n_barcodes]; ++i) {
+            const uint8_t ch = c.pass[k].bc_bytes[i];
+            if (code_of[ch] < 0) code_of[ch] = K++;
+        }
+    std::vector<uint32_t> meta[2], keys[2];
+    std::vector<uint16_t> always[2];
+    int total_bc = 0, kmax = 0;
+    double flagged = 0.0;  // expected falsely flagged pairs per read of ~150 bases
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        if (p.n_barcodes > 32767) return BDX_OK;
+        total_bc += p.n_barcodes;
+        meta[k].assign((size_t)p.n_barcodes, 0u);
+        keys[k].assign((size_t)p.n_barcodes * 2, 0u);
+        for (int b = 0; b < p.n_barcodes; ++b) {
+            const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+            long long ae;
+            if (c.algorithm == BDX_ALG_EXACT) ae = 0;
+            else if (c.algorithm == BDX_ALG_HAMMING) ae = (long long)std::floor(c.max_error_rate * (double)m);
+            else ae = (long long)std::floor(c.max_error_rate * (double)(c.has_nindel ? p.bc_len_no_N[b] : m));
+            if (ae < 0) continue;  // can never be recorded: neither seeded nor swept (meta 0 and not in `always`)
+            const long long kb = ae / cmin;
+            bool wild = false;
+            for (int i = 0; i < m; ++i) wild |= n_wild && p.bc_bytes[p.bc_off[b] + i] == 'N';
+            const long long P = kb + 2;
+            const long long L = m / P;
+            if (wild || L < 4 || P > 8 || kb > 6 || (P - 1) * L > 28) {
+                always[k].push_back((uint16_t)b);
+                continue;
+            }
+            if (kb > kmax) kmax = (int)kb;
+            meta[k][b] = (uint32_t)P | ((uint32_t)L << 8);
+            uint64_t kk = 0;
+            for (long long t = 0; t < P; ++t) {
+                uint32_t key = 0;
+                for (int i = 0; i < 4; ++i) key |= (uint32_t)(code_of[p.bc_bytes[p.bc_off[b] + t * L + i]] & 3) << (2 * i);
+                kk |= (uint64_t)key << (8 * t);
+            }
+            keys[k][2 * b] = (uint32_t)kk;
+            keys[k][2 * b + 1] = (uint32_t)(kk >> 32);
+            const double hits = 147.0 / 256.0;  // occurrences of one 4-mer in the read
+            flagged += (double)(P * (P - 1) / 2) * hits * hits * (double)(2 * kb + 1) / (150.0 + m);
+        }
+    }
+    const size_t n_always = always[0].size() + always[1].size();
+    if (n_always == (size_t)total_bc) return BDX_OK;
+    if (n_always * 4 > (size_t)total_bc) return BDX_OK;
+    // worth it only if clearly fewer pairs are swept (a flagged pair costs ~ a quarter of a whole-read sweep)
+    if ((flagged + (double)n_always) * 2.0 > (double)total_bc) return BDX_OK;
+    size_t bytes = 0;
+    size_t o_meta[2], o_keys[2], o_always[2];
+    for (int k = 0; k < 2; ++k) {
+        o_meta[k] = bytes;
+        bytes += (meta[k].size() * 4 + 15) & ~(size_t)15;
+        o_keys[k] = bytes;
+        bytes += (keys[k].size() * 4 + 15) & ~(size_t)15;
+        o_always[k] = bytes;
+        bytes += (always[k].size() * 2 + 15) & ~(size_t)15;
+    }
+    bytes += 16;
+    std::vector<uint8_t> blob(bytes, 0);
+    for (int k = 0; k < 2; ++k) {
+        if (!meta[k].empty()) memcpy(blob.data() + o_meta[k], meta[k].data(), meta[k].size() * 4);
+        if (!keys[k].empty()) memcpy(blob.data() + o_keys[k], keys[k].data(), keys[k].size() * 4);
+        if (!always[k].empty()) memcpy(blob.data() + o_always[k], always[k].data(), always[k].size() * 2);
+    }
+    HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
+    sp = BdxSeedPlan{};
+    for (int k = 0; k < 2; ++k) {
+        sp.d_dmeta[k] = (const uint32_t *)(base + o_meta[k]);
+        sp.d_dkeys[k] = (const uint32_t *)(base + o_keys[k]);
+        sp.n_always[k] = (int)always[k].size();
+        sp.d_always[k] = (const uint16_t *)(base + o_always[k]);
+    }
+    sp.q = 4;
+    sp.diag = 1;
+    sp.diag_kmax = kmax;
+    sp.rcap = 8;
+    sp.enabled = 1;
+    return BDX_OK;
+}
+
 // Geometry of the fused kernel for a given typical read length: the largest R whose LDS
 // footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
 bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
@@ -434,9 +542,12 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     const int slot = slot_mode ? ((wmax + 15 + 16 + 15) & ~15) : 0;
     bp.slot_bytes = slot;
     bp.seed_span = slot_mode ? wmax : read_len;
-    const int tries[5] = {256, 128, 64, 32, 16};
+    if (ctx->splan.enabled && ctx->splan.diag && bp.seed_span > 152) ctx->splan.enabled = 0;  // index holds 160 positions
+    const bool diag = ctx->splan.enabled && ctx->splan.diag;
+    const int tries[7] = {256, 128, 64, 32, 16, 8, 4};
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
+        if (diag ? R > 16 : R < 16) continue;  // the diagonal variant keeps 5 KiB of index per read: small tiles
         if (forced && R != forced) continue;
         if (!forced && R > r_cap) continue;
         if (!forced && !ctx->splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
@@ -453,7 +564,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         // workgroups (12 waves) share a CU — larger tiles fill the 256 lanes of the sparse
         // sweep / exact stages better.  Rank: >= 3 resident (largest R wins), then 2, then 1.
         const int rank = blocks >= 3 ? 3 : blocks;
-        if (R == 16 && best_R) continue;
+        if (!diag && R == 16 && best_R) continue;
         if (rank > best_blocks) {
             best_blocks = rank;
             best_R = R;
@@ -641,7 +752,9 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = build_seed_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
-    ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify") : "generic";
+    rc = build_diag_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
+    ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
     ctx->filter_used = ctx->bplan.enabled ? (ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
     if (ctx->bplan.enabled) {
         if (ctx->d_maxlen.ensure(256) != hipSuccess) {
@@ -787,8 +900,16 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
                                             nullptr, exc_list, exc_count));
+        if (const char *e = getenv("BDX_DEBUG"))
+            if (atoi(e) & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
+                unsigned int st[4] = {0, 0, 0, 0};
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipMemcpy(st, exc_count, sizeof(st), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[bdx] handed over %u reads; %u windowed sweeps, %u columns, %u tiles with a fallback read (of %lld reads)\n",
+                        st[0], st[1], st[2], st[3], (long long)n_reads);
+            }
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
-        ctx->path = ctx->splan.enabled ? "qgram+bitpar+verify" : "bitpar+verify";
+        ctx->path = ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,

@@ -48,6 +48,9 @@ struct BitparArgs {
     int bshift[2];
     // q-gram seeding (SEED variant only)
     int seed_q, seed_groups, seed_hash_log2, seed_bm_words, seed_bm_log2;
+    const uint32_t *dmeta[2];  // DIAG variant: per barcode pieces | piece length << 8 (0: not seeded)
+    const uint32_t *dkeys[2];  //   ... and the 8-bit keys of its pieces (2 words)
+    int diag_kmax;
     int seed_rcap;         // sweep records per read (power of two, sized to the expected seeded barcodes)
     int seed_hash_in_lds;  // 0: the hash table is probed in L2 (large barcode sets)
     int seed_n_always[2];
@@ -72,8 +75,11 @@ struct BitparArgs {
 // The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
 // VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
 // are short and barrier-separated, so throughput follows the number of resident waves closely.
-template <int BS, int R, bool SEED>
+template <int BS, int R, bool SEED, bool DIAG>
 __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
+    static_assert(!DIAG || SEED, "the diagonal variant is a seeded variant");
+    constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
+    constexpr int NW = 5;                 // DIAG: position words per 4-mer key (reads of <= 160 staged bases)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const int RCAP = SEED ? a.seed_rcap : 8;
     const int RCAP_LOG2 = 31 - __builtin_clz(RCAP);
     const int SQCAP = (SEED && a.seed_rcap >= 16) ? 16 * R : 8 * R;  // capacity of the seed-hit queue
-    const int PQCAP = SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R;  // capacity of the sweep-record queue
+    const int PQCAP = DIAG ? 64 * R : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
     const int npass = cfg.is_dual ? 2 : 1;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         return p;
     };
     // the seed bitmap sits at LDS offset 0: its byte probes then need no base address arithmetic
-    LDS uint32_t *sbm = (LDS uint32_t *)take(SEED ? (size_t)a.seed_bm_words * 4 : 0);
+    LDS uint32_t *sbm = (LDS uint32_t *)take(HASH ? (size_t)a.seed_bm_words * 4 : 0);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
     LDS unsigned char *lut = take(256);
     LDS uint32_t *peq0 = (LDS uint32_t *)take((size_t)a.ncodes * a.bpad[0] * 4);
@@ -118,14 +124,14 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS unsigned char *rstage = take((size_t)a.stage_bytes + 16);
     LDS unsigned char *codes = rstage;
     // seeding work areas (SEED variant only)
-    LDS uint32_t *shash = (LDS uint32_t *)take(SEED && a.seed_hash_in_lds ? ((size_t)4 << a.seed_hash_log2) : 0);
+    LDS uint32_t *shash = (LDS uint32_t *)take(HASH && a.seed_hash_in_lds ? ((size_t)4 << a.seed_hash_log2) : 0);
     LDS unsigned char *spk = take(SEED ? (size_t)(a.stage_bytes >> 2) + 32 : 0);  // flat 2-bit image of the staging area
-    LDS unsigned char *shps = take(SEED && a.seed_hash_in_lds ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
-    LDS uint32_t *shq = (LDS uint32_t *)take(SEED ? (size_t)SQCAP * 4 : 0);      // seed hits: position << 16 | key
-    LDS unsigned char *shr = take(SEED ? (size_t)SQCAP : 0);                       // ... and their read
-    LDS uint32_t *srid = (LDS uint32_t *)take(SEED ? (size_t)R * RCAP * 4 : 0);   // per-read sweep records: id
-    LDS int *srlo = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window start (min)
-    LDS int *srhi = (LDS int *)take(SEED ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
+    LDS unsigned char *shps = take(HASH && a.seed_hash_in_lds ? ((size_t)1 << a.seed_hash_log2) : 0);  // piece start of each hash entry
+    LDS uint32_t *shq = (LDS uint32_t *)take(HASH ? (size_t)SQCAP * 4 : (DIAG ? (size_t)2 * PQCAP * 4 : 0));      // seed hits: position << 16 | key
+    LDS unsigned char *shr = take(HASH ? (size_t)SQCAP : 0);                       // ... and their read
+    LDS uint32_t *srid = (LDS uint32_t *)take(HASH ? (size_t)R * RCAP * 4 : 0);   // per-read sweep records: id
+    LDS int *srlo = (LDS int *)take(HASH ? (size_t)R * RCAP * 4 : 0);             //   window start (min)
+    LDS int *srhi = (LDS int *)take(HASH ? (size_t)R * RCAP * 4 : 0);             //   window end (max)
     // the sweep-record queue reuses the hit queue (dead once the hits are resolved; SQCAP = 2 * PQCAP)
     LDS uint32_t *spq = shq;          // read << 16 | pass << 15 | barcode + 1
     LDS uint32_t *spw = shq + PQCAP;  // window lo << 16 | hi
@@ -136,6 +142,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
     LDS uint32_t *slh = (LDS uint32_t *)take(SEED ? (size_t)R * 4 : 0);  // per read: first | (last + 1) << 16 seed start, relative to the first staged base
     LDS int *srw = (LDS int *)take(SEED ? (size_t)R * 4 : 0);            // per read: stage offset of its first staged base
+    // DIAG variant: per-read inverted index of 4-mers (bit p of occ[r][key][.] <=> the 4-mer at staged position p is key)
+    LDS uint32_t *occ = (LDS uint32_t *)take(DIAG ? (size_t)R * 256 * NW * 4 : 0);
+    LDS uint32_t *dm0 = (LDS uint32_t *)take(DIAG ? (size_t)B0 * 4 : 0);
+    LDS uint32_t *dm1 = (LDS uint32_t *)take(DIAG ? (size_t)B1 * 4 : 0);
+    LDS uint32_t *dk0 = (LDS uint32_t *)take(DIAG ? (size_t)B0 * 8 : 0);
+    LDS uint32_t *dk1 = (LDS uint32_t *)take(DIAG ? (size_t)B1 * 8 : 0);
 
     // ---- tables -> LDS ----
     for (int i = tid; i < B0; i += BS) {
@@ -152,7 +164,13 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
     for (int i = tid; i < 256; i += BS) lut[i] = a.lut[i];
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
-    if (SEED) {
+    if (DIAG) {
+        for (int i = tid; i < B0; i += BS) dm0[i] = a.dmeta[0][i];
+        for (int i = tid; i < 2 * B0; i += BS) dk0[i] = a.dkeys[0][i];
+        for (int i = tid; i < B1; i += BS) dm1[i] = a.dmeta[1][i];
+        for (int i = tid; i < 2 * B1; i += BS) dk1[i] = a.dkeys[1][i];
+    }
+    if (HASH) {
         for (int i = tid; i < a.seed_bm_words; i += BS) sbm[i] = a.seed_bitmap[i];
         if (a.seed_hash_in_lds)
             for (int i = tid; i < (1 << a.seed_hash_log2); i += BS) {
@@ -191,10 +209,15 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
     if (SEED) {
         for (int i = tid; i < R; i += BS) sall[i] = 0;
-        for (int i = tid; i < R * RCAP; i += BS) {
-            srid[i] = 0u;
-            srlo[i] = 0x7FFFFFFF;
-            srhi[i] = 0;
+        if (HASH)
+            for (int i = tid; i < R * RCAP; i += BS) {
+                srid[i] = 0u;
+                srlo[i] = 0x7FFFFFFF;
+                srhi[i] = 0;
+            }
+        if (DIAG) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < R * 256 * NW / 4; i += BS) ((LDS u32x4 *)occ)[i] = z;
         }
         if (tid < 2) sqn[tid] = 0;
     }
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             srw[t] = roff[t] + base;
             // a read longer than the planned group count would leave its tail unscanned:
             // sweep every barcode of it instead (lossless fallback)
-            if (wl + 15 > 16 * a.seed_groups || wl > 0xFFF0) sall[t] = 1, sqn[5] = 1;
+            if (wl + 15 > 16 * a.seed_groups || wl > 0xFFF0 || (DIAG && wl > 32 * NW - 8)) sall[t] = 1, sqn[5] = 1;
         }
     }
     __syncthreads();
@@ -404,7 +427,9 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             step(A, j, shA);
             step(Bw, j, shB);
         }
+#pragma unroll 4
         for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
+#pragma unroll 4
         for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
         finish(A);
         finish(Bw);
@@ -447,6 +472,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // whole-window minimum whenever the latter is <= kb — the only case anything
             // downstream looks at.
             const int q = a.seed_q;
+            if constexpr (HASH) {
             // scan: lane = (read, group of 16 consecutive bases of the flat 2-bit image); the group's 16
             // start positions share one 64-bit window (16 + 7 bases), every key is probed in the bitmap.  The
             // hit counts of a wave are prefix-summed with four ballots (counts are <= 16), one lane
@@ -599,6 +625,133 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     }
                 }
             }
+            } else {
+            // ---- two-intact-pieces ("diagonal") variant (see build_diag_tables): budgets too large for a
+            // selective single piece.  1) inverted index of the read's 4-mers; 2) lane = (read, barcode):
+            // the position bits of each of the barcode's kb+2 piece keys are shifted onto diagonals
+            // (bit 32 + position - piece offset); a pair is a candidate iff two DIFFERENT pieces hit
+            // diagonals at most kb apart; 3) candidates are swept over [d_min - kb - 1, d_max + m + kb + 1).
+            {
+                const int G = a.seed_groups;
+                const int dr = BS / G, dg = BS - dr * G;
+                int r = tid / G, g = tid - r * G;
+                const int total_items = (a.dbg & 8) ? 0 : nr * G;
+                const LDS uint32_t *spk32 = (const LDS uint32_t *)spk;
+                for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
+                    const int rw = srw[r];
+                    const uint32_t lh = slh[r];
+                    const int F = (rw >> 4) + g;
+                    const int p0 = 16 * F - rw;
+                    int i0 = (int)(lh & 0xFFFFu) - p0, i1 = (int)(lh >> 16) - 1 - p0;
+                    i0 = i0 < 0 ? 0 : i0;
+                    i1 = i1 > 15 ? 15 : i1;
+                    if (sall[r] || i0 > i1) continue;
+                    const uint32_t w0 = spk32[F], w1 = spk32[F + 1];
+                    LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
+                    for (int i = i0; i <= i1; ++i) {
+                        const uint32_t key = __builtin_amdgcn_alignbit(w1, w0, 2 * i) & 255u;
+                        const int pos = p0 + i;  // 0 .. 32 NW - 1 (longer reads were flagged for the fallback)
+                        __hip_atomic_fetch_or(&oc[key * NW + (pos >> 5)], 1u << (pos & 31), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int p = 0; p < npass; ++p) {
+                const int B = p ? B1 : B0;
+                const LDS uint32_t *dm = p ? dm1 : dm0;
+                const LDS uint32_t *dk = p ? dk1 : dk0;
+                const int total = (a.dbg & 4) ? 0 : nr * B;
+                for (int pair0 = 0; pair0 < total; pair0 += BS) {  // uniform trip count: wave-aggregated append
+                    const int pair = pair0 + tid;
+                    const bool in = pair < total;
+                    const int r = in ? pair / B : 0, b = in ? pair - r * B : 0;
+                    const uint32_t meta = in ? dm[b] : 0u;
+                    uint32_t Cm[NW + 1];
+                    bool cand_pair = false;
+                    int kk = 0, mm = 0;
+                    if (meta != 0u && !sall[r]) {
+                        const int P = (int)(meta & 255u), L = (int)(meta >> 8);
+                        const uint32_t k0 = dk[2 * b], k1 = dk[2 * b + 1];
+                        kk = (p ? kb1 : kb0)[b];
+                        mm = __builtin_popcount((p ? pv1 : pv0)[b]);
+                        const LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
+                        uint32_t U[NW + 1], FU[NW + 1];
+#pragma unroll
+                        for (int w = 0; w <= NW; ++w) U[w] = FU[w] = Cm[w] = 0u;
+                        for (int t = 0; t < P; ++t) {
+                            const uint32_t key = (t < 4 ? k0 >> (8 * t) : k1 >> (8 * (t - 4))) & 255u;
+                            const int o = t * L;  // piece offset, <= 28
+                            uint32_t in_[NW];
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) in_[w] = oc[key * NW + w];
+                            // D: bit 32 + position - o  (({in[w], in[w-1]} >> o) as one 64-bit funnel per word)
+                            uint32_t D[NW + 1], FD[NW + 1], Y[NW + 1];
+#pragma unroll
+                            for (int w = 0; w <= NW; ++w)
+                                D[w] = __builtin_amdgcn_alignbit(w < NW ? in_[w] : 0u, w > 0 ? in_[w - 1] : 0u, o);
+                            // FD = D | D << 1 | ... | D << kk  (one-sided smear)
+#pragma unroll
+                            for (int w = 0; w <= NW; ++w) FD[w] = Y[w] = D[w];
+                            for (int sft = 1; sft <= a.diag_kmax; ++sft) {
+#pragma unroll
+                                for (int w = NW; w >= 0; --w) Y[w] = __builtin_amdgcn_alignbit(Y[w], w > 0 ? Y[w - 1] : 0u, 31);
+                                if (sft <= kk) {
+#pragma unroll
+                                    for (int w = 0; w <= NW; ++w) FD[w] |= Y[w];
+                                }
+                            }
+                            // this piece at d, an earlier piece within [d - kk, d]  or  within [d, d + kk]
+#pragma unroll
+                            for (int w = 0; w <= NW; ++w) {
+                                Cm[w] |= (FU[w] & D[w]) | (U[w] & FD[w]);
+                                U[w] |= D[w];
+                                FU[w] |= FD[w];
+                            }
+                        }
+                        uint32_t any = 0;
+#pragma unroll
+                        for (int w = 0; w <= NW; ++w) any |= Cm[w];
+                        cand_pair = any != 0u;
+                    }
+                    if (cand_pair) {
+                        // one sweep per CLUSTER of candidate diagonals (bits closer than 2 kk + 2 share a window):
+                        // far-apart candidates of one pair must not be merged into one long window — the
+                        // longest window of a wave sets that wave's sweep time
+                        const int wl_r = wlen[r];
+                        const int gap = 2 * kk + 2;
+                        int c_lo = -1, c_hi = -1;
+                        auto flush = [&]() __attribute__((always_inline)) {
+                            int lo = c_lo - 32 - kk - 1, hi = c_hi - 32 + mm + kk + 1;  // [lo, hi) relative to the staged base
+                            if (lo < 0) lo = 0;
+                            if (hi > wl_r) hi = wl_r;
+                            const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (kq < PQCAP) {
+                                spq[kq] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)(b + 1);
+                                spw[kq] = ((uint32_t)lo << 16) | (uint32_t)hi;
+                            } else {
+                                sall[r] = 1, sqn[5] = 1;
+                            }
+                        };
+#pragma unroll
+                        for (int w = 0; w <= NW; ++w) {
+                            uint32_t bits = Cm[w];
+                            while (bits) {
+                                const int g = 32 * w + __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                if (c_lo >= 0 && g - c_hi > gap) {
+                                    flush();
+                                    c_lo = g;
+                                }
+                                if (c_lo < 0) c_lo = g;
+                                c_hi = g;
+                            }
+                        }
+                        flush();
+                    }
+                }
+            }
+            }
             // barcodes that are swept unconditionally (wildcards, pieces shorter than 5): whole window
             for (int p = 0; p < npass; ++p) {
                 const int na = a.seed_n_always[p];
@@ -615,7 +768,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 }
             }
             __syncthreads();
-            const int any_sall = sqn[5];  // does any read of this tile need the whole-read fallback below?
+            const int any_sall = sqn[5];
+            if ((a.dbg & 128) && tid == 0 && any_sall) atomicAdd(a.exc_count + 3, 1u);  // does any read of this tile need the whole-read fallback below?
             {
                 const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
                 for (int k = tid; k < np; k += 2 * BS) {
@@ -626,6 +780,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     const int ra = (int)(ea >> 16), rb = (int)(eb >> 16);
                     setup(!sall[ra], (int)((ea >> 15) & 1u), ra, (int)(ea & 0x7FFFu) - 1, A, (int)(wa >> 16), (int)(wa & 0xFFFFu));
                     setup(hb && !sall[rb], (int)((eb >> 15) & 1u), rb, (int)(eb & 0x7FFFu) - 1, Bw, (int)(wb >> 16), (int)(wb & 0xFFFFu));
+                    if (a.dbg & 128) {  // statistics for tuning (results stay correct): sweeps and swept columns
+                        atomicAdd(a.exc_count + 1, 1u + (hb ? 1u : 0u));
+                        atomicAdd(a.exc_count + 2, (unsigned)(A.ncol + Bw.ncol));
+                    }
                     sweep2(A, Bw);
                 }
                 // reads whose lists overflowed: every barcode over the whole window, exactly once
@@ -814,11 +972,11 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 }
 
-template <int BS, int R, bool SEED>
+template <int BS, int R, bool SEED, bool DIAG = false>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED>,
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -833,7 +991,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     if (const char *e = getenv("BDX_GRID")) blocks = atoll(e);
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
+    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -852,7 +1010,11 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 3 * al((size_t)R * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
-    if (sp && sp->enabled) {
+    if (sp && sp->enabled && sp->diag) {
+        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * 64 * R * 4);
+        o += al((size_t)R) + 2 * al((size_t)R * 4);
+        o += al((size_t)R * 256 * 5 * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
+    } else if (sp && sp->enabled) {
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 32);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
         o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
@@ -909,6 +1071,11 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_bm_words = sp.bm_words;
     a.seed_bm_log2 = sp.bm_log2;
     a.seed_rcap = sp.rcap > 0 ? sp.rcap : 8;
+    a.diag_kmax = sp.diag_kmax;
+    for (int k = 0; k < 2; ++k) {
+        a.dmeta[k] = sp.d_dmeta[k];
+        a.dkeys[k] = sp.d_dkeys[k];
+    }
     a.seed_hash_in_lds = sp.hash_in_lds;
     a.seed_bitmap = sp.d_bitmap;
     a.seed_hash = sp.d_hash;
@@ -919,6 +1086,18 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     }
     const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp, &sp);
     const bool seed = sp.enabled != 0;
+    if (seed && sp.diag) {
+        switch (bp.reads_per_block) {
+            case 16:
+                return launch_one<256, 16, true, true>(a, lds, n_reads, stream);
+            case 8:
+                return launch_one<256, 8, true, true>(a, lds, n_reads, stream);
+            case 4:
+                return launch_one<256, 4, true, true>(a, lds, n_reads, stream);
+            default:
+                return hipErrorInvalidValue;
+        }
+    }
 #define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream) : launch_one<256, RR, false>(a, lds, n_reads, stream)
     switch (bp.reads_per_block) {
         case 256:

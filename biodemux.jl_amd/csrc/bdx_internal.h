@@ -108,6 +108,11 @@ struct BdxSeedPlan {
     const uint32_t *d_hash;
     const uint8_t *d_hash_ps;      // piece start offset (bases) of every hash entry
     const uint16_t *d_always[2];
+    // two-intact-pieces ("diagonal") variant for budgets too large for single seeds (see bdx_bitpar.hip)
+    int diag;                      // 1: q = 4 inverted index per read + per-pair diagonal test instead of bitmap / hash
+    int diag_kmax;                 // largest operation budget among the seeded barcodes
+    const uint32_t *d_dmeta[2];    // per barcode: pieces | piece length << 8 (0 = swept unconditionally)
+    const uint32_t *d_dkeys[2];    // per barcode: 2 words, 8 bits per piece key (first 4 bases of the piece)
 };
 
 // Implemented in bdx_bitpar.hip.
