@@ -323,8 +323,9 @@ def test_diag_c2_shape(kw):
 
 
 def test_diag_variable_lengths_and_dual():
-    """Per-barcode budgets and piece lengths differ (16..32 nt); second pass on the same read."""
-    lens = np.random.Generator(np.random.PCG64(43)).integers(20, 33, size=40)
+    """Per-barcode budgets and piece counts differ (24 nt: 6 pieces, 28 / 29 nt: 7, 32 nt: 8; a few of 26 nt
+    whose pieces would be too short are swept unconditionally); second pass on the same read."""
+    lens = np.random.Generator(np.random.PCG64(43)).choice([24, 28, 29, 32, 24, 28, 32, 26, 24, 29], size=40)
     b1 = synth.make_barcodes(40, 24, seed=43, lengths=lens)
     b2 = synth.make_barcodes(12, 24, seed=44)
     seq, off, _ = synth.make_reads(b1, 15000, 150, seed=45, plant_lo=0, plant_hi=60, second=(b2, 90, 126))
