@@ -448,6 +448,15 @@ int build_diag_tables(bdx_ctx *ctx) {
     if (n_always * 4 > (size_t)total_bc) return BDX_OK;
     // worth it only if clearly fewer pairs are swept (a flagged pair costs ~ a quarter of a whole-read sweep)
     if ((flagged + (double)n_always) * 2.0 > (double)total_bc) return BDX_OK;
+    // ... and only for enough barcodes: the index forces 4..8-read tiles, whose per-tile latency costs about
+    // as much as sweeping ~50 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.0235 us/pair
+    // against 0.054 us/pair of the plain sweep)
+    if (total_bc < 64) return BDX_OK;
+    // ... and only when this kernel gives the verdicts itself: in split mode the small tiles cost more than
+    // the skipped sweeps save (measured: 127 vs 140 M reads/s with trimming at B = 96)
+    for (int k = 0; k < npass; ++k)
+        if (!ctx->bplan.known_ok[k]) return BDX_OK;
+    sp.diag_qcap = (int)((flagged + (double)n_always) * 1.6) + 16;  // sweep-queue entries per read
     size_t bytes = 0;
     size_t o_meta[2], o_keys[2], o_always[2];
     for (int k = 0; k < 2; ++k) {
@@ -468,7 +477,9 @@ int build_diag_tables(bdx_ctx *ctx) {
     HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
     HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
+    const int qcap = sp.diag_qcap;
     sp = BdxSeedPlan{};
+    sp.diag_qcap = qcap;
     for (int k = 0; k < 2; ++k) {
         sp.d_dmeta[k] = (const uint32_t *)(base + o_meta[k]);
         sp.d_dkeys[k] = (const uint32_t *)(base + o_keys[k]);
@@ -570,6 +581,11 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
             best_R = R;
             best_stage = (int)st;
         }
+    }
+    if (best_R && diag && best_blocks < 2) {
+        // the index leaves room for one workgroup per CU only (very many barcodes): the plain sweep is faster
+        ctx->splan.enabled = 0;
+        return size_bitpar(ctx, read_len, n_reads);
     }
     if (best_R) {
         bp.reads_per_block = best_R;

@@ -50,7 +50,7 @@ struct BitparArgs {
     int seed_q, seed_groups, seed_hash_log2, seed_bm_words, seed_bm_log2;
     const uint32_t *dmeta[2];  // DIAG variant: per barcode pieces | piece length << 8 (0: not seeded)
     const uint32_t *dkeys[2];  //   ... and the 8-bit keys of its pieces (2 words)
-    int diag_kmax;
+    int diag_kmax, diag_qcap;
     int seed_rcap;         // sweep records per read (power of two, sized to the expected seeded barcodes)
     int seed_hash_in_lds;  // 0: the hash table is probed in L2 (large barcode sets)
     int seed_n_always[2];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const int RCAP = SEED ? a.seed_rcap : 8;
     const int RCAP_LOG2 = 31 - __builtin_clz(RCAP);
     const int SQCAP = (SEED && a.seed_rcap >= 16) ? 16 * R : 8 * R;  // capacity of the seed-hit queue
-    const int PQCAP = DIAG ? 64 * R : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
+    const int PQCAP = DIAG ? a.diag_qcap * R : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
     const int npass = cfg.is_dual ? 2 : 1;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -1011,7 +1011,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
-        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * 64 * R * 4);
+        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (sp->diag_qcap > 0 ? sp->diag_qcap : 64) * R * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
         o += al((size_t)R * 256 * 5 * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
     } else if (sp && sp->enabled) {
@@ -1072,6 +1072,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_bm_log2 = sp.bm_log2;
     a.seed_rcap = sp.rcap > 0 ? sp.rcap : 8;
     a.diag_kmax = sp.diag_kmax;
+    a.diag_qcap = sp.diag_qcap > 0 ? sp.diag_qcap : 64;
     for (int k = 0; k < 2; ++k) {
         a.dmeta[k] = sp.d_dmeta[k];
         a.dkeys[k] = sp.d_dkeys[k];

@@ -111,6 +111,7 @@ struct BdxSeedPlan {
     // two-intact-pieces ("diagonal") variant for budgets too large for single seeds (see bdx_bitpar.hip)
     int diag;                      // 1: q = 4 inverted index per read + per-pair diagonal test instead of bitmap / hash
     int diag_kmax;                 // largest operation budget among the seeded barcodes
+    int diag_qcap;                 // sweep-queue entries to provide per read
     const uint32_t *d_dmeta[2];    // per barcode: pieces | piece length << 8 (0 = swept unconditionally)
     const uint32_t *d_dkeys[2];    // per barcode: 2 words, 8 bits per piece key (first 4 bases of the piece)
 };
