@@ -1,0 +1,87 @@
+"""The two-intact-pieces ("diagonal") filter of csrc/bdx_bitpar.hip, restated with Python integers and
+checked against the oracle's plain unit-cost semi-global distance (CPU only).
+
+Claim: a barcode of length m aligned with at most kb edit operations leaves at least
+two of its kb+2 disjoint pieces untouched; they occur in the read on diagonals (read position -
+barcode offset) at most kb apart, and the alignment lies inside [d - kb - 1, d + m + kb + 1) for either
+diagonal d.  So (1) every pair with unit distance <= kb is flagged, and (2) the distance over the
+flagged window equals the distance over the whole read.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bdx_oracle as orc  # noqa: E402
+from biodemux_jl_amd import synth  # noqa: E402
+
+
+def _unit_distance():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libbdx_oracle.so"))
+    u8p = C.POINTER(C.c_uint8)
+    lib.orc_unit_distance.restype = C.c_int64
+    lib.orc_unit_distance.argtypes = [u8p, C.c_int64, u8p, C.c_int64]
+
+    def ud(q: bytes, r: bytes) -> int:
+        if not r:
+            return len(q)
+        qa, ra = np.frombuffer(q, dtype=np.uint8), np.frombuffer(r, dtype=np.uint8)
+        return int(lib.orc_unit_distance(qa.ctypes.data_as(u8p), len(qa), ra.ctypes.data_as(u8p), len(ra)))
+
+    return ud
+
+
+@pytest.mark.parametrize("m,kb,n_reads", [(24, 4, 500), (24, 3, 250), (28, 5, 250), (32, 6, 250), (16, 2, 250), (25, 4, 250)])
+def test_two_intact_pieces_filter_is_lossless(m, kb, n_reads):
+    orc.OracleClassifier  # the shared library is built by the package's build step
+    ud = _unit_distance()
+    P = kb + 2
+    L = m // P
+    assert L >= 4
+    bcs = synth.make_barcodes(40, m, seed=100 + m + kb, min_hamming=max(2, m // 4))
+    # heavier damage than the bench generator so that distances around kb are common
+    seq, off, _ = synth.make_reads(bcs, n_reads, 150, seed=200 + m + kb, sub=0.06, ins=0.03, dele=0.03)
+    flagged = missed = window_bad = near = 0
+    for i in range(n_reads):
+        r = bytes(seq[off[i]:off[i + 1]])
+        n = len(r)
+        occ = {}
+        for p in range(n - 3):
+            occ[r[p:p + 4]] = occ.get(r[p:p + 4], 0) | (1 << p)
+        for b in bcs:
+            bb = b.encode()
+            U = FU = Cm = 0
+            for t in range(P):
+                o = t * L
+                D = occ.get(bb[o:o + 4], 0) << (32 - o)
+                FD = 0
+                for s in range(kb + 1):
+                    FD |= D << s
+                Cm |= (FU & D) | (U & FD)
+                U |= D
+                FU |= FD
+            d_full = ud(bb, r)
+            near += d_full <= kb
+            if not Cm:
+                missed += d_full <= kb
+                continue
+            flagged += 1
+            # clusters of candidate diagonals closer than 2 kb + 2, one window each (as the kernel does)
+            bits = [g for g in range(Cm.bit_length()) if (Cm >> g) & 1]
+            clusters, lo, hi = [], bits[0], bits[0]
+            for g in bits[1:]:
+                if g - hi > 2 * kb + 2:
+                    clusters.append((lo, hi))
+                    lo = g
+                hi = g
+            clusters.append((lo, hi))
+            best = min(ud(bb, r[max(0, a - 32 - kb - 1):min(n, e - 32 + m + kb + 1)]) for a, e in clusters)
+            if d_full <= kb and best != d_full:
+                window_bad += 1
+    assert near > 20, "the generator must produce pairs within the budget"
+    assert missed == 0 and window_bad == 0, (missed, window_bad, flagged)
