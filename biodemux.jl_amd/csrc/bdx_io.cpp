@@ -19,6 +19,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -31,9 +35,22 @@ extern "C" {
 
 struct bdx_fq_file {
     const uint8_t *data = nullptr;
-    int64_t size = 0;
+    int64_t size = 0;  // plain files: file size; .gz: bytes inflated so far once `state` != 0
     bool mapped = false;
-    std::vector<uint8_t> owned;  // inflated .gz contents
+    // .gz input: a background thread inflates into an address range reserved up
+    // front (MAP_NORESERVE, so pages cost memory only once written) while the index / pack / classify /
+    // write stages already work on the records that are there.  `avail` only grows; bytes below it
+    // are final.
+    bool streaming = false;
+    size_t reserve = 0;
+    std::thread inflater;
+    std::atomic<int64_t> avail{0};
+    std::atomic<int> state{0};    // 0 inflating, 1 complete, -1 failed
+    std::atomic<bool> cancel{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string err;
+    double avg_record = 330.0;    // bytes per record, learned from the batches indexed so far
 };
 
 static thread_local std::string g_io_err;
@@ -55,25 +72,48 @@ int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
             return -1;
         }
         gzbuffer(g, 1 << 20);
-        std::vector<uint8_t> &o = f->owned;
-        o.resize(1 << 22);
-        size_t used = 0;
-        for (;;) {
-            if (o.size() - used < (1 << 20)) o.resize(o.size() * 2);
-            int got = gzread(g, o.data() + used, (unsigned)std::min<size_t>(o.size() - used, 1u << 30));
-            if (got < 0) {
-                g_io_err = "gzread failed on " + p;
-                gzclose(g);
-                delete f;
-                return -1;
-            }
-            if (got == 0) break;
-            used += (size_t)got;
+        struct stat st;
+        const int64_t csize = stat(path, &st) == 0 ? (int64_t)st.st_size : 0;
+        // FASTQ deflates 3..10x; reserve 64x the compressed size (at least 1 GiB) of address space
+        f->reserve = (size_t)std::min<int64_t>(std::max<int64_t>(csize * 64, (int64_t)1 << 30), (int64_t)1 << 40);
+        void *m = mmap(nullptr, f->reserve, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) {
+            g_io_err = "cannot reserve address space for " + p;
+            gzclose(g);
+            delete f;
+            return -1;
         }
-        gzclose(g);
-        o.resize(used);
-        f->data = o.data();
-        f->size = (int64_t)used;
+        f->data = (const uint8_t *)m;
+        f->streaming = true;
+        f->inflater = std::thread([f, g, p]() {
+            uint8_t *dst = (uint8_t *)f->data;
+            size_t used = 0;
+            int st = 1;
+            while (!f->cancel.load(std::memory_order_relaxed)) {
+                if (f->reserve - used < (1u << 22)) {
+                    f->err = "inflated size of " + p + " exceeds 64x its compressed size";
+                    st = -1;
+                    break;
+                }
+                const int got = gzread(g, dst + used, 1u << 22);
+                if (got < 0) {
+                    f->err = "gzread failed on " + p;
+                    st = -1;
+                    break;
+                }
+                if (got == 0) break;
+                used += (size_t)got;
+                f->avail.store((int64_t)used, std::memory_order_release);
+                f->cv.notify_all();
+            }
+            gzclose(g);
+            {
+                std::lock_guard<std::mutex> lk(f->mu);
+                f->size = (int64_t)used;
+                f->state.store(st, std::memory_order_release);
+            }
+            f->cv.notify_all();
+        });
     } else {
         int fd = open(path, O_RDONLY);
         if (fd < 0) {
@@ -109,21 +149,55 @@ int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
 
 void bdx_fq_close(bdx_fq_file *f) {
     if (!f) return;
-    if (f->mapped && f->data) munmap((void *)f->data, (size_t)f->size);
+    if (f->streaming) {
+        f->cancel.store(true);
+        if (f->inflater.joinable()) f->inflater.join();
+        if (f->data) munmap((void *)f->data, f->reserve);
+    } else if (f->mapped && f->data) {
+        munmap((void *)f->data, (size_t)f->size);
+    }
     delete f;
 }
 
+// Blocks until at least `target` bytes are there or the stream has ended; returns the bytes available
+// and whether that is the whole file (*final).  Plain files: immediately.
+static int64_t wait_available(bdx_fq_file *f, int64_t target, bool *final, bool *failed) {
+    *failed = false;
+    if (!f->streaming) {
+        *final = true;
+        return f->size;
+    }
+    std::unique_lock<std::mutex> lk(f->mu);
+    f->cv.wait_for(lk, std::chrono::milliseconds(50), [&]() { return f->state.load() != 0 || f->avail.load() >= target; });
+    while (f->state.load() == 0 && f->avail.load() < target) f->cv.wait_for(lk, std::chrono::milliseconds(50));
+    const int st = f->state.load(std::memory_order_acquire);
+    *final = st != 0;
+    *failed = st < 0;
+    return st != 0 ? f->size : f->avail.load(std::memory_order_acquire);
+}
+
 const uint8_t *bdx_fq_data(const bdx_fq_file *f) { return f->data; }
-int64_t bdx_fq_size(const bdx_fq_file *f) { return f->size; }
+// Total size (for .gz: blocks until the stream is completely inflated).
+int64_t bdx_fq_size(bdx_fq_file *f) {
+    bool fin, bad;
+    int64_t s = wait_available(f, INT64_MAX, &fin, &bad);
+    return bad ? -1 : s;
+}
+// The records below `upto` have been written out: give their pages back (streamed .gz only).
+void bdx_fq_release(bdx_fq_file *f, int64_t upto) {
+    if (!f->streaming || upto <= 0) return;
+    const int64_t page = 1 << 12;
+    const int64_t n = (upto / page) * page;
+    if (n > 0) madvise((void *)f->data, (size_t)n, MADV_DONTNEED);
+}
 
 // Line index of the bytes [start, size): fills line_off[k] / line_len[k] for up to 4*max_reads
 // lines (len excludes "\n" and a preceding "\r").  Returns the number of RECORDS (a trailing
 // partial record counts; its missing lines get offset = size, len = 0) and stores the cursor
 // after the last consumed line in *next.  nthreads chunks scan for '\n' in parallel.
-int64_t bdx_fq_index(const bdx_fq_file *f, int64_t start, int64_t max_reads, int64_t *line_off,
-                     int32_t *line_len, int64_t *next, int32_t nthreads) {
-    const uint8_t *d = f->data;
-    const int64_t size = f->size;
+// `final` == false (streamed input, more bytes will follow): only complete records are returned.
+static int64_t index_range(const uint8_t *d, const int64_t size, const bool final, int64_t start, int64_t max_reads,
+                           int64_t *line_off, int32_t *line_len, int64_t *next, int32_t nthreads) {
     if (start >= size || max_reads <= 0) {
         *next = start;
         return 0;
@@ -160,6 +234,7 @@ int64_t bdx_fq_index(const bdx_fq_file *f, int64_t start, int64_t max_reads, int
     }
     (void)lo;
     int64_t nlines = std::min<int64_t>((int64_t)nl.size(), want);
+    if (!final) nlines -= nlines % 4;  // the rest of a record may still be on its way
     int64_t cur = start;
     for (int64_t k = 0; k < nlines; ++k) {
         int64_t e = nl[k];
@@ -170,7 +245,7 @@ int64_t bdx_fq_index(const bdx_fq_file *f, int64_t start, int64_t max_reads, int
         cur = e + 1;
     }
     // data not terminated by '\n': the rest is one more line (readline at EOF)
-    if (nlines < want && scanned_to >= size && cur < size) {
+    if (final && nlines < want && scanned_to >= size && cur < size) {
         int64_t len = size - cur;
         line_off[nlines] = cur;
         if (len > 0 && d[size - 1] == '\r') len -= 1;
@@ -185,6 +260,27 @@ int64_t bdx_fq_index(const bdx_fq_file *f, int64_t start, int64_t max_reads, int
     }
     *next = cur;
     return nrec;
+}
+
+int64_t bdx_fq_index(bdx_fq_file *f, int64_t start, int64_t max_reads, int64_t *line_off, int32_t *line_len,
+                     int64_t *next, int32_t nthreads) {
+    if (!f->streaming) return index_range(f->data, f->size, true, start, max_reads, line_off, line_len, next, nthreads);
+    double want_bytes = (double)max_reads * f->avg_record * 1.02 + 4096.0;
+    for (;;) {
+        bool fin, bad;
+        const int64_t have = wait_available(f, start + (int64_t)want_bytes, &fin, &bad);
+        if (bad) {
+            g_io_err = f->err;
+            *next = start;
+            return -1;
+        }
+        const int64_t n = index_range(f->data, have, fin, start, max_reads, line_off, line_len, next, nthreads);
+        if (n >= max_reads || fin) {
+            if (n > 0) f->avg_record = (double)(*next - start) / (double)n;
+            return n;
+        }
+        want_bytes = want_bytes * 1.25 + 65536.0;  // records longer than estimated: wait for more
+    }
 }
 
 // Packs the sequence lines (line 1 of every record) into the C-ABI chunk layout:

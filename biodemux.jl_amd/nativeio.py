@@ -46,6 +46,8 @@ def _load():
         L.bdx_fq_size.argtypes = [vp]
         L.bdx_fq_index.restype = C.c_int64
         L.bdx_fq_index.argtypes = [vp, C.c_int64, C.c_int64, vp, vp, C.POINTER(C.c_int64), C.c_int32]
+        L.bdx_fq_release.restype = None
+        L.bdx_fq_release.argtypes = [vp, C.c_int64]
         L.bdx_fq_seq_bytes.restype = C.c_int64
         L.bdx_fq_seq_bytes.argtypes = [vp, C.c_int64]
         L.bdx_fq_pack.restype = None
@@ -76,7 +78,15 @@ class FastqFile:
             raise OSError(self.L.bdx_io_last_error().decode())
         self.h = h
         self.cursor = 0
-        self.size = int(self.L.bdx_fq_size(h))
+
+    @property
+    def size(self) -> int:
+        """Total bytes (a .gz input is inflated in the background: this waits for the end of the stream)."""
+        return int(self.L.bdx_fq_size(self.h))
+
+    def release(self, upto: int) -> None:
+        """Records below byte `upto` are written out: a streamed .gz input gives their pages back."""
+        self.L.bdx_fq_release(self.h, int(upto))
 
     def next_batch(self, max_reads: int, nthreads: int):
         """-> (n_records, line_off int64[4n], line_len int32[4n]) from the cursor on."""
@@ -85,6 +95,8 @@ class FastqFile:
         nxt = C.c_int64(0)
         n = int(self.L.bdx_fq_index(self.h, self.cursor, max_reads, off.ctypes.data, ln.ctypes.data, C.byref(nxt),
                                     nthreads))
+        if n < 0:
+            raise OSError(self.L.bdx_io_last_error().decode())
         self.cursor = int(nxt.value)
         return n, off, ln
 
@@ -136,7 +148,7 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 if n == 0:
                     break
                 seq, so = f1.pack(off1, ln1, n, T)
-                q_in.put((n, off1, ln1, off2, ln2, seq, so))
+                q_in.put((n, off1, ln1, off2, ln2, seq, so, f1.cursor, f2.cursor if f2 is not None else 0))
                 if last:
                     break
         except BaseException as e:  # noqa: BLE001 - forwarded to the caller
@@ -164,7 +176,7 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 item = q_out.get()
                 if item is None:
                     break
-                n, off1, ln1, off2, ln2, cls, ks, ke = item
+                n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2 = item
                 used = np.unique(cls)
 
                 def write(f, off, ln, prefix, trim):
@@ -180,6 +192,9 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                     write(f2, off2, ln2, prefix2, False)
                 else:  # core.jl:191-196
                     write(f1, off1, ln1, prefix1, do_trim)
+                f1.release(cur1)  # this batch and everything before it is on disk
+                if f2 is not None:
+                    f2.release(cur2)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
             while q_out.get() is not None:  # keep draining so the producer never blocks
@@ -196,7 +211,7 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 break
             if errors:
                 continue
-            n, off1, ln1, off2, ln2, seq, so = item
+            n, off1, ln1, off2, ln2, seq, so, cur1, cur2 = item
             out = classifier.classify(seq, so)  # <- the hot path: one C-ABI call per batch
             if on_batch is not None:
                 on_batch(out)
@@ -205,7 +220,7 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
             cls = np.ascontiguousarray(cls, dtype=np.int32)
             ks = np.ascontiguousarray(out["keep_start"], dtype=np.int32)
             ke = np.ascontiguousarray(out["keep_end"], dtype=np.int32)
-            q_out.put((n, off1, ln1, off2, ln2, cls, ks, ke))
+            q_out.put((n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2))
     except BaseException as e:  # noqa: BLE001
         errors.append(e)
         while q_in.get() is not None:

@@ -77,3 +77,46 @@ def test_native_paired_lockstep_and_classify_both(tmp_path):
         run_py(f1, f2, str(bc), str(tmp_path / f"py{both}"), **kw)
         run_nat(f1, f2, str(bc), str(tmp_path / f"nat{both}"), **kw)
         _same_tree(str(tmp_path / f"py{both}"), str(tmp_path / f"nat{both}"))
+
+
+@pytest.mark.parametrize("case", ["gz_small_batches", "gz_truncated_record", "gz_no_final_newline", "gz_out"])
+def test_streamed_gzip_input(tmp_path, case):
+    """.gz inputs are inflated by a background thread while batches are already indexed, classified
+    and written: batch boundaries must not depend on how far the inflater is,
+    released pages must never be read again, the tail rules are those of plain files."""
+    bcs = synth.make_barcodes(6, 12, seed=7, min_hamming=4)
+    seq, off, _ = synth.make_ragged_reads(bcs, 3000, 0, 120, seed=7)
+    seqs = [seq[off[i]:off[i + 1]].tobytes() for i in range(3000)]
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    tail = {"gz_truncated_record": b"@last\nACGTAC", "gz_no_final_newline": b"@x\nACGT\n+\nIIII"}.get(case, b"")
+    fq = str(tmp_path / "reads.fastq.gz")
+    _fastq(fq, seqs, tail=tail, gz=True)
+    kw = dict(max_error_rate=0.2, trim_side=3, _batch_reads=211)
+    if case == "gz_out":
+        kw["gzip_output"] = True
+    run_py(fq, str(bc), str(tmp_path / "py"), **kw)
+    run_nat(fq, str(bc), str(tmp_path / "nat"), **kw)
+    _same_tree(str(tmp_path / "py"), str(tmp_path / "nat"))
+
+
+def test_streamed_gzip_pairs_and_errors(tmp_path):
+    bcs = synth.make_barcodes(5, 12, seed=8, min_hamming=4)
+    seq, off, _ = synth.make_reads(bcs, 900, 60, seed=8)
+    s1 = [seq[off[i]:off[i + 1]].tobytes() for i in range(900)]
+    s2 = [b"TTGCA" * 9 for _ in range(900)]
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    f1, f2 = str(tmp_path / "y_R1.fastq.gz"), str(tmp_path / "y_R2.fastq.gz")
+    _fastq(f1, s1, gz=True)
+    _fastq(f2, s2, gz=True)
+    kw = dict(classify_both=True, _batch_reads=100)
+    run_py(f1, f2, str(bc), str(tmp_path / "py"), **kw)
+    run_nat(f1, f2, str(bc), str(tmp_path / "nat"), **kw)
+    _same_tree(str(tmp_path / "py"), str(tmp_path / "nat"))
+    # a corrupt stream is reported, not silently truncated
+    blob = open(f1, "rb").read()
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(blob[:len(blob) // 2] + b"\x00" * 64 + blob[len(blob) // 2 + 64:])
+    with pytest.raises(OSError):
+        run_nat(bad, str(bc), str(tmp_path / "bad_out"), _batch_reads=100)

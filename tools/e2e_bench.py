@@ -28,11 +28,24 @@ bc = os.path.join(root, "barcodes.csv")
 open(bc, "w").write("ID,Full_seq,Full_annotation\n" + "".join(f"bc{i + 1:03d},{b},{'B' * 24}\n" for i, b in enumerate(bcs)))
 print(f"wrote {os.path.getsize(fq) / 1e9:.2f} GB FASTQ ({n} reads) in {time.time() - t:.1f} s -> {root}", flush=True)
 del rec
+gz = bool(os.environ.get("GZ"))  # GZ=1: .fastq.gz in (streamed inflate), gzip out
+extra = {}
+if gz:
+    import subprocess
+    t = time.time()
+    subprocess.check_call(["gzip", "-1", "-k", fq])
+    print(f"gzip -1: {os.path.getsize(fq + '.gz') / 1e9:.2f} GB in {time.time() - t:.1f} s", flush=True)
+    t = time.time()
+    subprocess.check_call("gzip -dc %s.gz > /dev/null" % fq, shell=True)
+    print(f"gzip -dc alone (the serial floor of a single gzip stream): {time.time() - t:.2f} s", flush=True)
+    os.remove(fq)
+    fq = fq + ".gz"
+    extra = dict(gzip_output=True)
 for io in ("native",):
     for rep in range(2):
         out = os.path.join(root, f"out_{io}_{rep}")
         t = time.perf_counter()
-        st = bdx.execute_demultiplexing(fq, bc, out, max_error_rate=0.1, _io=io)
+        st = bdx.execute_demultiplexing(fq, bc, out, max_error_rate=0.1, _io=io, **extra)
         dt = time.perf_counter() - t
         nfiles = len(os.listdir(out))
         print(f"io={io} run {rep}: {dt:.2f} s -> {n / dt / 1e6:.2f} M reads/s end-to-end ({os.path.getsize(fq) / dt / 1e9:.2f} GB/s of FASTQ), "
