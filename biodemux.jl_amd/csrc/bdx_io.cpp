@@ -384,46 +384,87 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
             });
         for (auto &t : th) t.join();
     }
-    // pass 3: append each class buffer to its file (parallel over files)
+    // pass 3: append each class buffer to its file.  gzip output: every 4 MiB piece of every class is
+    // deflated as a gzip member of its own by whichever thread is free (members concatenate to a valid
+    // .gz; one big class — `unknown` — would otherwise serialise the whole batch behind one zlib stream),
+    // then the members of a file are appended in order.
     std::vector<int> todo;
     for (int c = 0; c < n_classes; ++c)
         if (csize[c] > 0) todo.push_back(c);
     std::vector<int> fail((size_t)todo.size(), 0);
+    std::vector<char> is_gz(todo.size(), 0);
+    struct Member {
+        size_t k, off, len;
+        std::vector<uint8_t> out;
+        int bad = 0;
+    };
+    std::vector<Member> members;
+    for (size_t k = 0; k < todo.size(); ++k) {
+        std::string low(class_paths[todo[k]]);
+        std::transform(low.begin(), low.end(), low.begin(), ::tolower);
+        is_gz[k] = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
+        if (is_gz[k]) {
+            const size_t total = bufs[todo[k]].size(), piece = (size_t)1 << 22;
+            for (size_t off = 0; off < total; off += piece) {
+                Member mb;
+                mb.k = k;
+                mb.off = off;
+                mb.len = std::min(piece, total - off);
+                members.push_back(std::move(mb));
+            }
+        }
+    }
+    if (!members.empty()) {
+        std::atomic<size_t> nextm{0};
+        const int T = std::max(1, std::min<int>(nthreads, (int)members.size()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&]() {
+                for (;;) {
+                    const size_t i = nextm.fetch_add(1);
+                    if (i >= members.size()) break;
+                    Member &mb = members[i];
+                    z_stream zs;
+                    memset(&zs, 0, sizeof(zs));
+                    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                        mb.bad = 1;
+                        continue;
+                    }
+                    mb.out.resize(deflateBound(&zs, (uLong)mb.len) + 64);
+                    zs.next_in = (Bytef *)(bufs[todo[mb.k]].data() + mb.off);
+                    zs.avail_in = (uInt)mb.len;
+                    zs.next_out = mb.out.data();
+                    zs.avail_out = (uInt)mb.out.size();
+                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mb.bad = 1;
+                    mb.out.resize(mb.out.size() - zs.avail_out);
+                    deflateEnd(&zs);
+                }
+            });
+        for (auto &t : th) t.join();
+    }
     {
+        // members of one file are consecutive in `members`
+        std::vector<size_t> first(todo.size() + 1, members.size());
+        for (size_t i = members.size(); i-- > 0;) first[members[i].k] = i;
         const int T = std::max(1, std::min<int>(nthreads, (int)todo.size()));
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
             th.emplace_back([&, t]() {
                 for (size_t k = (size_t)t; k < todo.size(); k += (size_t)T) {
                     const int c = todo[k];
-                    std::string p(class_paths[c]), low(p);
-                    std::transform(low.begin(), low.end(), low.begin(), ::tolower);
-                    const bool gz = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
-                    if (gz) {
-                        gzFile g = gzopen(p.c_str(), "ab");
-                        if (!g) {
-                            fail[k] = 1;
-                            continue;
-                        }
-                        size_t off = 0;
-                        while (off < bufs[c].size()) {
-                            const unsigned chunk = (unsigned)std::min<size_t>(bufs[c].size() - off, 1u << 30);
-                            if (gzwrite(g, bufs[c].data() + off, chunk) <= 0) {
-                                fail[k] = 1;
-                                break;
-                            }
-                            off += chunk;
-                        }
-                        gzclose(g);
-                    } else {
-                        FILE *fp = fopen(p.c_str(), "ab");
-                        if (!fp) {
-                            fail[k] = 1;
-                            continue;
-                        }
-                        if (fwrite(bufs[c].data(), 1, bufs[c].size(), fp) != bufs[c].size()) fail[k] = 1;
-                        fclose(fp);
+                    FILE *fp = fopen(class_paths[c], "ab");
+                    if (!fp) {
+                        fail[k] = 1;
+                        continue;
                     }
+                    if (is_gz[k]) {
+                        for (size_t i = first[k]; i < members.size() && members[i].k == k; ++i)
+                            if (members[i].bad || fwrite(members[i].out.data(), 1, members[i].out.size(), fp) != members[i].out.size())
+                                fail[k] = 1;
+                    } else if (fwrite(bufs[c].data(), 1, bufs[c].size(), fp) != bufs[c].size()) {
+                        fail[k] = 1;
+                    }
+                    if (fclose(fp) != 0) fail[k] = 1;
                 }
             });
         for (auto &t : th) t.join();
