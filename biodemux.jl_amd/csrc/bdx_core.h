@@ -203,8 +203,21 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
     int lact = (ae + 1 < m) ? ae + 1 : m;  // :286
     if (jlo > first) first = jlo;  // restricted run, DESIGN.md §3.2
     if (jhi < last) last = jhi;
-    for (int j = first; j <= last; ++j) {  // :287
-        int prev_o = j;                    // :288
+    // The lanes of a wave walk their columns END-ALIGNED: all lanes reach their last column in the same
+    // trip (lanes with fewer columns start later).  Each lane still visits first..last in order, so its
+    // result is untouched; but a restricted run ends at the alignment's end column, so the
+    // lanes now sit on (nearly) the same rows at the same time and the row blocks below can be skipped
+    // for the whole wave.  Wave maximum of the column counts by bisection on ballots (safe under divergence).
+    int T = 0;
+    {
+        const int len = last - first + 1;
+        for (int bit = 30; bit >= 0; --bit)
+            if (__builtin_amdgcn_ballot_w64(len >= (T | (1 << bit)))) T |= 1 << bit;
+    }
+    for (int t = 0; t < T; ++t) {
+        const int j = last - (T - 1 - t);  // :287
+        if (j < first) continue;
+        int prev_o = j;  // :288
         int fact, prev;
         if (j + band >= 1) {  // :289-295
             fact = j + band;
@@ -219,35 +232,52 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
         const int seed = prev;
         int diag = 0;    // row-0 value (:215 "i == 1 ? 0")
         int diag_o = j;  // row-0 origin (:308)
+        // The reference visits rows fact..lact only (:300); here the rows are static registers, so they are
+        // walked in blocks of RB and a block is executed only if SOME lane of the wave has a row of
+        // [fact-1, lact] in it (fact-1: the band seed).  For the other lanes the block's code is a no-op
+        // (DP, OG, prev unchanged; diag leaves the block as the old value of its last row) — exactly what
+        // the skip branch does.  In restricted runs all lanes of a wave sit at about the
+        // same distance from their window start, so most blocks are skipped.
+        constexpr int RB = 4;
 #pragma unroll
-        for (int i = 1; i <= M; ++i) {
-            const int old = DP[i];
-            const int old_o = OG[i];
-            const bool inb = (i >= fact) && (i <= lact);
-            const int qi = (int)((QP[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu);
-            const bool isN = NS && (qi == c.ncode);
-            const int cost = isN ? c.nindel : c.indel;
-            const int ins = (i == m) ? BDX_INF32 : old + cost;
-            const int del = prev + cost;
-            const int sub = diag + ((qi == rj || isN) ? c.match : c.mismatch);
-            int cur_o = prev_o;
-            if (TB) {  // :310-321
-                int best = del;
-                if (sub < best) {
-                    best = sub;
-                    cur_o = diag_o;
+        for (int bs = 1; bs <= M; bs += RB) {
+            const int be = bs + RB - 1 < M ? bs + RB - 1 : M;
+            const bool lane_on = (bs <= lact) && (be >= fact - 1);
+            if (__builtin_amdgcn_ballot_w64(lane_on)) {
+#pragma unroll
+                for (int i = bs; i <= be; ++i) {
+                    const int old = DP[i];
+                    const int old_o = OG[i];
+                    const bool inb = (i >= fact) && (i <= lact);
+                    const int qi = (int)((QP[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu);
+                    const bool isN = NS && (qi == c.ncode);
+                    const int cost = isN ? c.nindel : c.indel;
+                    const int ins = (i == m) ? BDX_INF32 : old + cost;
+                    const int del = prev + cost;
+                    const int sub = diag + ((qi == rj || isN) ? c.match : c.mismatch);
+                    int cur_o = prev_o;
+                    if (TB) {  // :310-321
+                        int best = del;
+                        if (sub < best) {
+                            best = sub;
+                            cur_o = diag_o;
+                        }
+                        if (ins < best) cur_o = old_o;
+                    }
+                    const int t = del < sub ? del : sub;
+                    const int nv = ins < t ? ins : t;
+                    const bool seedrow = (i == fact - 1);  // :326-331 (fact != 1 is implied by i >= 1)
+                    DP[i] = inb ? nv : (seedrow ? seed : old);
+                    if (TB) OG[i] = inb ? cur_o : (seedrow ? j : old_o);
+                    prev = inb ? nv : prev;
+                    if (TB) prev_o = inb ? cur_o : prev_o;
+                    diag = old;
+                    diag_o = old_o;
                 }
-                if (ins < best) cur_o = old_o;
+            } else {
+                diag = DP[be];
+                diag_o = OG[be];
             }
-            const int t = del < sub ? del : sub;
-            const int nv = ins < t ? ins : t;
-            const bool seedrow = (i == fact - 1);  // :326-331 (fact != 1 is implied by i >= 1)
-            DP[i] = inb ? nv : (seedrow ? seed : old);
-            if (TB) OG[i] = inb ? cur_o : (seedrow ? j : old_o);
-            prev = inb ? nv : prev;
-            if (TB) prev_o = inb ? cur_o : prev_o;
-            diag = old;
-            diag_o = old_o;
         }
 
         if (lact == m && prev <= ae) {  // :417

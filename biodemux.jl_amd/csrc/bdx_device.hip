@@ -50,7 +50,7 @@ struct GenericArgs {
 // REGM > 0: the exact DP of SimpleScoring barcodes up to REGM rows runs register-resident
 // (sg_core_reg); the kernel then needs no DP/origin columns in LDS.
 template <int BS, int REGM>
-__global__ __launch_bounds__(BS) void bdx_generic_kernel(const GenericArgs a) {
+__global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(const GenericArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
