@@ -11,3 +11,8 @@ _spec = _ilu.spec_from_file_location(__name__, _os.path.join(_dir, "__init__.py"
 _mod = _ilu.module_from_spec(_spec)
 _sys.modules[__name__] = _mod
 _spec.loader.exec_module(_mod)
+
+if __name__ == "__main__":  # python biodemux_jl_amd.py <fastq1> <barcode_file> <output_directory> [options] (cli.jl)
+    from biodemux_jl_amd.cli import main as _main
+
+    _sys.exit(_main())
