@@ -425,3 +425,12 @@ def test_long_reads_dual_windows():
                             ref_search_range2=H.bdx.parse_dynamic_range("end-120:end"))
     exp = _all_filters_agree(cfg, seq, off)
     assert (exp["bc1"] > 0).mean() > 0.4
+
+
+def test_cli_directory_mode_on_the_gpu(tmp_path):
+    """The command line front end ends in the HIP hot path: demo1 (24 files, directory mode) byte-exact."""
+    from biodemux_jl_amd import cli
+    out = str(tmp_path / "out")
+    rc = cli.main([os.path.join(H.REF, "FASTQ_files", "demo1_R1"), os.path.join(H.REF, "reference_files", "demo1.tsv"), out])
+    assert rc == 0
+    assert H.check_output_files(out, os.path.join(H.REF, "results", "demo1_R1")) > 0
