@@ -198,8 +198,10 @@ int32_t bdx_reset_counts(bdx_ctx *ctx);
 void *bdx_counts_device_ptr(bdx_ctx *ctx);
 int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts);
 
-/* Introspection for bench/tests: name of the kernel path a classify call will take
- * ("generic", "qgram+verify", "bitpar+verify", ...), and numbers of the last launch. */
+/* Introspection for bench/tests: name of the kernel path a classify call will take, and numbers of the
+ * last launch.  "generic": exact kernel only; "bitpar+verify": bit-vector sweep of every pair, then the exact
+ * stage; "qgram+bitpar+verify": single-piece q-gram seeds in front of the sweep; "qgram2+bitpar+verify":
+ * two-intact-pieces ("diagonal") seeds in front of the sweep.  All paths give identical results. */
 const char *bdx_kernel_path(const bdx_ctx *ctx);
 
 typedef struct {
