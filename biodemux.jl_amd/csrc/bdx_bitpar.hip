@@ -627,10 +627,17 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             }
             } else {
             // ---- two-intact-pieces ("diagonal") variant (see build_diag_tables): budgets too large for a
-            // selective single piece.  1) inverted index of the read's 4-mers; 2) lane = (read, barcode):
-            // the position bits of each of the barcode's kb+2 piece keys are shifted onto diagonals
-            // (bit 32 + position - piece offset); a pair is a candidate iff two DIFFERENT pieces hit
-            // diagonals at most kb apart; 3) candidates are swept over [d_min - kb - 1, d_max + m + kb + 1).
+            // selective single piece.
+            //  1) inverted index of the read's 4-mers, every occurrence smeared over h = ceil(kmax / 2)
+            //     positions to either side (index bit p + h + s, s = -h..h, for a 4-mer at position p);
+            //  2) lane = (read, barcode): the bits of each of the barcode's kb+2 piece keys are shifted onto
+            //     diagonals (bit 32 + h + position - piece offset); two DIFFERENT pieces on diagonals at most
+            //     kb <= 2h apart have smeared bits in common, so a pair is a candidate iff the AND of one piece's
+            //     bits with the union of the earlier pieces' bits is non-zero (exact for even kb = 2h, a
+            //     superset otherwise): two loads, one funnel shift and two logic ops per piece and word;
+            //  3) a common bit b is within h of both diagonals and the alignment starts within kb of either:
+            //     candidates are swept over [b_min - h - kb - 1, b_max + h + m + kb + 1).
+            const int hsm = (a.diag_kmax + 1) >> 1;
             {
                 const int G = a.seed_groups;
                 const int dr = BS / G, dg = BS - dr * G;
@@ -650,9 +657,15 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
                     for (int i = i0; i <= i1; ++i) {
                         const uint32_t key = __builtin_amdgcn_alignbit(w1, w0, 2 * i) & 255u;
-                        const int pos = p0 + i;  // 0 .. 32 NW - 1 (longer reads were flagged for the fallback)
-                        __hip_atomic_fetch_or(&oc[key * NW + (pos >> 5)], 1u << (pos & 31), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int lo = p0 + i, hi = lo + 2 * hsm;  // bits [pos, pos + 2h]: <= 32 NW - 1 (reads <= 32 NW - 8 bases)
+                        const int wlo_ = lo >> 5, whi_ = hi >> 5;
+                        const uint32_t mlo = 0xFFFFFFFFu << (lo & 31), mhi = 0xFFFFFFFFu >> (31 - (hi & 31));
+                        if (wlo_ == whi_) {
+                            __hip_atomic_fetch_or(&oc[key * NW + wlo_], mlo & mhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            __hip_atomic_fetch_or(&oc[key * NW + wlo_], mlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&oc[key * NW + whi_], mhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
             }
@@ -676,37 +689,21 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         kk = (p ? kb1 : kb0)[b];
                         mm = __builtin_popcount((p ? pv1 : pv0)[b]);
                         const LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
-                        uint32_t U[NW + 1], FU[NW + 1];
+                        uint32_t SU[NW + 1];
 #pragma unroll
-                        for (int w = 0; w <= NW; ++w) U[w] = FU[w] = Cm[w] = 0u;
+                        for (int w = 0; w <= NW; ++w) SU[w] = Cm[w] = 0u;
                         for (int t = 0; t < P; ++t) {
                             const uint32_t key = (t < 4 ? k0 >> (8 * t) : k1 >> (8 * (t - 4))) & 255u;
                             const int o = t * L;  // piece offset, <= 28
                             uint32_t in_[NW];
 #pragma unroll
                             for (int w = 0; w < NW; ++w) in_[w] = oc[key * NW + w];
-                            // D: bit 32 + position - o  (({in[w], in[w-1]} >> o) as one 64-bit funnel per word)
-                            uint32_t D[NW + 1], FD[NW + 1], Y[NW + 1];
-#pragma unroll
-                            for (int w = 0; w <= NW; ++w)
-                                D[w] = __builtin_amdgcn_alignbit(w < NW ? in_[w] : 0u, w > 0 ? in_[w - 1] : 0u, o);
-                            // FD = D | D << 1 | ... | D << kk  (one-sided smear)
-#pragma unroll
-                            for (int w = 0; w <= NW; ++w) FD[w] = Y[w] = D[w];
-                            for (int sft = 1; sft <= a.diag_kmax; ++sft) {
-#pragma unroll
-                                for (int w = NW; w >= 0; --w) Y[w] = __builtin_amdgcn_alignbit(Y[w], w > 0 ? Y[w - 1] : 0u, 31);
-                                if (sft <= kk) {
-#pragma unroll
-                                    for (int w = 0; w <= NW; ++w) FD[w] |= Y[w];
-                                }
-                            }
-                            // this piece at d, an earlier piece within [d - kk, d]  or  within [d, d + kk]
+                            // S: bit 32 + index bit - o  (({in[w], in[w-1]} >> o) as one 64-bit funnel per word)
 #pragma unroll
                             for (int w = 0; w <= NW; ++w) {
-                                Cm[w] |= (FU[w] & D[w]) | (U[w] & FD[w]);
-                                U[w] |= D[w];
-                                FU[w] |= FD[w];
+                                const uint32_t S = __builtin_amdgcn_alignbit(w < NW ? in_[w] : 0u, w > 0 ? in_[w - 1] : 0u, o);
+                                Cm[w] |= SU[w] & S;
+                                SU[w] |= S;
                             }
                         }
                         uint32_t any = 0;
@@ -722,7 +719,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         const int gap = 2 * kk + 2;
                         int c_lo = -1, c_hi = -1;
                         auto flush = [&]() __attribute__((always_inline)) {
-                            int lo = c_lo - 32 - kk - 1, hi = c_hi - 32 + mm + kk + 1;  // [lo, hi) relative to the staged base
+                            // common bits carry the index bias h and lie within h of both diagonals
+                            int lo = c_lo - 32 - 2 * hsm - kk - 1, hi = c_hi - 32 + mm + kk + 1;  // [lo, hi) relative to the staged base
                             if (lo < 0) lo = 0;
                             if (hi > wl_r) hi = wl_r;
                             const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -733,18 +731,35 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                                 sall[r] = 1, sqn[5] = 1;
                             }
                         };
+                        // first / last common bit; nearly always they form ONE cluster (a single region of a few
+                        // consecutive bits), which needs no walk over the bits
+                        int f_i = 0, l_i = 0;
+                        bool got = false;
 #pragma unroll
                         for (int w = 0; w <= NW; ++w) {
-                            uint32_t bits = Cm[w];
-                            while (bits) {
-                                const int g = 32 * w + __builtin_ctz(bits);
-                                bits &= bits - 1u;
-                                if (c_lo >= 0 && g - c_hi > gap) {
-                                    flush();
-                                    c_lo = g;
+                            if (!got && Cm[w]) {
+                                f_i = 32 * w + __builtin_ctz(Cm[w]);
+                                got = true;
+                            }
+                            if (Cm[w]) l_i = 32 * w + 31 - __builtin_clz(Cm[w]);
+                        }
+                        if (l_i - f_i <= gap) {
+                            c_lo = f_i;
+                            c_hi = l_i;
+                        } else {
+#pragma unroll
+                            for (int w = 0; w <= NW; ++w) {
+                                uint32_t bits = Cm[w];
+                                while (bits) {
+                                    const int g = 32 * w + __builtin_ctz(bits);
+                                    bits &= bits - 1u;
+                                    if (c_lo >= 0 && g - c_hi > gap) {
+                                        flush();
+                                        c_lo = g;
+                                    }
+                                    if (c_lo < 0) c_lo = g;
+                                    c_hi = g;
                                 }
-                                if (c_lo < 0) c_lo = g;
-                                c_hi = g;
                             }
                         }
                         flush();

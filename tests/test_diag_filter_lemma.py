@@ -4,8 +4,9 @@ checked against the oracle's plain unit-cost semi-global distance (CPU only).
 Claim: a barcode of length m aligned with at most kb edit operations leaves at least
 two of its kb+2 disjoint pieces untouched; they occur in the read on diagonals (read position -
 barcode offset) at most kb apart, and the alignment lies inside [d - kb - 1, d + m + kb + 1) for either
-diagonal d.  So (1) every pair with unit distance <= kb is flagged, and (2) the distance over the
-flagged window equals the distance over the whole read.
+diagonal d.  The kernel smears every 4-mer occurrence over h = ceil(kb / 2) positions to either side, so
+that two pieces on diagonals <= kb <= 2h apart share a bit.  So (1) every pair with unit distance <= kb
+is flagged, and (2) the distance over the flagged window equals the distance over the whole read.
 """
 import ctypes as C
 import os
@@ -50,28 +51,26 @@ def test_two_intact_pieces_filter_is_lossless(m, kb, n_reads):
     for i in range(n_reads):
         r = bytes(seq[off[i]:off[i + 1]])
         n = len(r)
+        # index as the kernel builds it: a 4-mer at position p sets bits p .. p + 2h (h = ceil(kb / 2))
+        h = (kb + 1) // 2
         occ = {}
         for p in range(n - 3):
-            occ[r[p:p + 4]] = occ.get(r[p:p + 4], 0) | (1 << p)
+            occ[r[p:p + 4]] = occ.get(r[p:p + 4], 0) | (((1 << (2 * h + 1)) - 1) << p)
         for b in bcs:
             bb = b.encode()
-            U = FU = Cm = 0
+            SU = Cm = 0
             for t in range(P):
                 o = t * L
-                D = occ.get(bb[o:o + 4], 0) << (32 - o)
-                FD = 0
-                for s in range(kb + 1):
-                    FD |= D << s
-                Cm |= (FU & D) | (U & FD)
-                U |= D
-                FU |= FD
+                S = occ.get(bb[o:o + 4], 0) << (32 - o)
+                Cm |= SU & S  # a DIFFERENT, earlier piece within 2h >= kb diagonals
+                SU |= S
             d_full = ud(bb, r)
             near += d_full <= kb
             if not Cm:
                 missed += d_full <= kb
                 continue
             flagged += 1
-            # clusters of candidate diagonals closer than 2 kb + 2, one window each (as the kernel does)
+            # clusters of common bits closer than 2 kb + 2, one window each (as the kernel does)
             bits = [g for g in range(Cm.bit_length()) if (Cm >> g) & 1]
             clusters, lo, hi = [], bits[0], bits[0]
             for g in bits[1:]:
@@ -80,7 +79,7 @@ def test_two_intact_pieces_filter_is_lossless(m, kb, n_reads):
                     lo = g
                 hi = g
             clusters.append((lo, hi))
-            best = min(ud(bb, r[max(0, a - 32 - kb - 1):min(n, e - 32 + m + kb + 1)]) for a, e in clusters)
+            best = min(ud(bb, r[max(0, a - 32 - 2 * h - kb - 1):min(n, e - 32 + m + kb + 1)]) for a, e in clusters)
             if d_full <= kb and best != d_full:
                 window_bad += 1
     assert near > 20, "the generator must produce pairs within the budget"
