@@ -449,9 +449,9 @@ int build_diag_tables(bdx_ctx *ctx) {
     // worth it only if clearly fewer pairs are swept (a flagged pair costs ~ a quarter of a whole-read sweep)
     if ((flagged + (double)n_always) * 2.0 > (double)total_bc) return BDX_OK;
     // ... and only for enough barcodes: the index forces 4..8-read tiles, whose per-tile latency costs about
-    // as much as sweeping ~50 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.0235 us/pair
+    // as much as sweeping ~40 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.017 us/pair
     // against 0.054 us/pair of the plain sweep)
-    if (total_bc < 64) return BDX_OK;
+    if (total_bc < 48) return BDX_OK;
     // ... and only when this kernel gives the verdicts itself: in split mode the small tiles cost more than
     // the skipped sweeps save (measured: 127 vs 140 M reads/s with trimming at B = 96)
     for (int k = 0; k < npass; ++k)
