@@ -452,10 +452,6 @@ int build_diag_tables(bdx_ctx *ctx) {
     // as much as sweeping ~40 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.017 us/pair
     // against 0.054 us/pair of the plain sweep)
     if (total_bc < 48) return BDX_OK;
-    // ... and only when this kernel gives the verdicts itself: in split mode the small tiles cost more than
-    // the skipped sweeps save (measured: 127 vs 140 M reads/s with trimming at B = 96)
-    for (int k = 0; k < npass; ++k)
-        if (!ctx->bplan.known_ok[k]) return BDX_OK;
     sp.diag_qcap = (int)((flagged + (double)n_always) * 1.6) + 16;  // sweep-queue entries per read
     size_t bytes = 0;
     size_t o_meta[2], o_keys[2], o_always[2];

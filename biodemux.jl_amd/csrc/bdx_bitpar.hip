@@ -346,6 +346,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         const LDS unsigned char *pq;
         uint32_t Pv, Mv;
         int score, best, ncol, r, b, p;
+        int e_lo, e_hi, kbv;  // tracked sweeps (split mode of the seeded variants): first / last column j with score <= kbv
     };
     // wlo_rel / whi_rel: optional column sub-window [lo, hi) relative to the read's first staged
     // base (seeded path); (0, 0xFFFF) = the whole pass window
@@ -361,6 +362,9 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.Mv = 0;
         w.score = 0;
         w.best = 0x7FFFFFFF;
+        w.e_lo = 0;
+        w.e_hi = -1;
+        w.kbv = -1;
         if (!valid) return;
         int jf = win[(p * 2 + 0) * R + r];
         int jl = win[(p * 2 + 1) * R + r];
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.b = b;
         w.Pv = (p ? pv1 : pv0)[b];
         w.score = __builtin_popcount(w.Pv);  // = barcode length m
+        w.kbv = (p ? kb1 : kb0)[b];
         w.best = w.score;
         if (!sg) {
             // :hamming / :exact bound the START positions by the window (SURVEY Q11,
@@ -403,7 +408,27 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.Mv = Ph & Xv;
         w.best = w.score < w.best ? w.score : w.best;
     };
+    // Split mode of the seeded variants: the sweeps themselves record the first / last column whose unit
+    // distance is <= kb instead of a second, sparsely populated pass over the survivors.
+    const bool track = SEED && a.split && a.wins_out[0] != nullptr;
+    auto step_tracked = [&](Sweep &w, const int j, const int sh) __attribute__((always_inline)) {
+        step(w, j, sh);
+        const bool in = w.score <= w.kbv;
+        w.e_lo = (in && w.e_hi < 0) ? j : w.e_lo;
+        w.e_hi = in ? j : w.e_hi;
+    };
     auto finish = [&](const Sweep &w) __attribute__((always_inline)) {
+        if (track && w.ncol > 0 && w.e_hi >= 0) {
+            const int kk = __hip_atomic_fetch_add(&wcl[w.p * R + w.r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (kk < BDX_WCAP) {
+                const int jf_abs = (int)(w.c - (codes + roff[w.r])) + 1;  // 1-based column of sweep column 0
+                const int mm = __builtin_popcount((w.p ? pv1 : pv0)[w.b]);
+                uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((r0 + w.r) * BDX_WCAP + kk) * 3;
+                dst[0] = (uint32_t)w.b;
+                dst[1] = (uint32_t)(jf_abs + w.e_lo - 2 * (mm + w.kbv) - 1);
+                dst[2] = (uint32_t)(jf_abs + w.e_hi);
+            }
+        }
         if (w.ncol > 0 && w.best <= (w.p ? kb1 : kb0)[w.b]) {
             const int cw = w.p ? cw1 : cw0;
             LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
@@ -422,15 +447,27 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         const int shA = A.p ? bsh1 : bsh0, shB = Bw.p ? bsh1 : bsh0;
         const int common = A.ncol < Bw.ncol ? A.ncol : Bw.ncol;
         int j = 0;
+        if (track) {  // workgroup-uniform
 #pragma unroll 4
-        for (; j < common; ++j) {
-            step(A, j, shA);
-            step(Bw, j, shB);
+            for (; j < common; ++j) {
+                step_tracked(A, j, shA);
+                step_tracked(Bw, j, shB);
+            }
+#pragma unroll 4
+            for (int ja = j; ja < A.ncol; ++ja) step_tracked(A, ja, shA);
+#pragma unroll 4
+            for (int jb = j; jb < Bw.ncol; ++jb) step_tracked(Bw, jb, shB);
+        } else {
+#pragma unroll 4
+            for (; j < common; ++j) {
+                step(A, j, shA);
+                step(Bw, j, shB);
+            }
+#pragma unroll 4
+            for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
+#pragma unroll 4
+            for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
         }
-#pragma unroll 4
-        for (int ja = j; ja < A.ncol; ++ja) step(A, ja, shA);
-#pragma unroll 4
-        for (int jb = j; jb < Bw.ncol; ++jb) step(Bw, jb, shB);
         finish(A);
         finish(Bw);
     };
@@ -838,7 +875,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // earlier, and another m + kb + 1 columns of warm-up make every cell <= allowed_error
             // independent of the fresh start -> the exact DP runs over e_lo - 2(m+kb) - 1 .. e_hi only.
             constexpr int WQCAP = 4 * R;
-            if (staged) {
+            if (staged && !track) {
                 for (int idx = tid; idx < nr * (cw0 + cw1); idx += BS) {
                     const int p = idx >= nr * cw0 ? 1 : 0;
                     const int loc = p ? idx - nr * cw0 : idx;
@@ -856,7 +893,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             __syncthreads();
             const int nq = sqn[4];
             const bool usable = staged && nq <= WQCAP;  // overflow / unstaged tile: no windows, whole-window DP
-            if (usable) {
+            if (usable && !track) {
                 for (int k = tid; k < nq; k += BS) {
                     const uint32_t e = wq[k];
                     const int r = (int)(e >> 16), p = (int)((e >> 15) & 1u), b = (int)(e & 0x7FFFu);

@@ -553,10 +553,14 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             // {barcode, first column, last column} per read and pass; none -> the whole window)
             int cjlo = -0x40000000, cjhi = 0x40000000;
             if (wcount <= BDX_WCAP) {
+                // several entries of one barcode (separately swept occurrences) are united
+                bool any_entry = false;
                 for (int e = 0; e < wcount; ++e)
                     if ((int)went[3 * e] == b) {
-                        cjlo = (int)went[3 * e + 1];
-                        cjhi = (int)went[3 * e + 2];
+                        const int lo_e = (int)went[3 * e + 1], hi_e = (int)went[3 * e + 2];
+                        cjlo = any_entry ? (lo_e < cjlo ? lo_e : cjlo) : lo_e;
+                        cjhi = any_entry ? (hi_e > cjhi ? hi_e : cjhi) : hi_e;
+                        any_entry = true;
                     }
             }
             const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476

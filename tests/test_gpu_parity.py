@@ -308,7 +308,7 @@ DIAG = "qgram2+bitpar+verify"
 @pytest.mark.parametrize("kw", [
     dict(max_error_rate=0.2),                                   # the reference's default: kb = 4, 6 pieces of 4
     dict(max_error_rate=0.2, min_delta=0.1),
-    dict(max_error_rate=0.2, trim_side=5),                      # split mode: plain sweep (small tiles do not pay there)
+    dict(max_error_rate=0.2, trim_side=5),                      # split mode: the sweeps also record the column windows
     dict(max_error_rate=0.2, trim_side=3, summary=True),
     dict(max_error_rate=0.17),                                  # kb = 4 as well (floor(4.08))
     dict(max_error_rate=0.2, mismatch=2, indel=2, min_delta=0.05),  # cmin = 2 -> kb = 2: single seeds take it
@@ -317,7 +317,7 @@ DIAG = "qgram2+bitpar+verify"
 def test_diag_c2_shape(kw):
     bcs = synth.make_barcodes(96, 24, seed=41)
     seq, off, _ = synth.make_reads(bcs, 20000, 150, seed=42)
-    expect = None if ("mismatch" in kw or "trim_side" in kw or kw.get("matching_algorithm") == "hamming") else DIAG
+    expect = None if "mismatch" in kw else DIAG
     exp = _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path=expect)
     assert (exp["bc1"] > 0).mean() > 0.5
 
@@ -332,7 +332,7 @@ def test_diag_variable_lengths_and_dual():
     cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[len(b) for b in b1], ids=[f"x{i}" for i in range(60)],
                             is_dual=True, bc_seqs2=b2, bc_lengths_no_N2=[24] * 12, ids2=[f"y{i}" for i in range(12)],
                             max_error_rate=0.2, trim_side=5, trim_side2=3)
-    _all_filters_agree(cfg, seq, off)
+    _all_filters_agree(cfg, seq, off, expect_path=DIAG)
     cfg2 = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[len(b) for b in b1], ids=[f"x{i}" for i in range(60)],
                              is_dual=True, bc_seqs2=b2, bc_lengths_no_N2=[24] * 12, ids2=[f"y{i}" for i in range(12)],
                              max_error_rate=0.2)
@@ -368,7 +368,7 @@ def test_diag_low_complexity_queue_overflow():
             s[int(rng.integers(0, 150))] = "ACGT"[int(rng.integers(0, 4))]
         reads.append("".join(s))
     seq, off = H.bdx.pack_reads(reads)
-    for kw in (dict(max_error_rate=0.2), dict(max_error_rate=0.2, min_delta=0.08)):
+    for kw in (dict(max_error_rate=0.2), dict(max_error_rate=0.2, min_delta=0.08), dict(max_error_rate=0.2, trim_side=3)):
         exp = _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path=DIAG)
     assert (exp["bc1"] != 0).mean() > 0.3
 
@@ -382,8 +382,8 @@ def test_diag_with_wildcards_and_short_barcodes():
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=nn, ids=[str(i) for i in range(len(bcs))], max_error_rate=0.2)
     _all_filters_agree(cfg, seq, off, expect_path=DIAG)
     cfgn = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=nn, ids=[str(i) for i in range(len(bcs))], max_error_rate=0.2,
-                             nindel=1)  # N-scoring: outside the known-score class -> plain sweep + split
-    _all_filters_agree(cfgn, seq, off)
+                             nindel=1)  # N-scoring: the barcode with N is swept unconditionally; split mode
+    _all_filters_agree(cfgn, seq, off, expect_path=DIAG)
 
 
 # ---- window-slot staging (long reads, short column windows) ----
