@@ -451,7 +451,11 @@ int build_diag_tables(bdx_ctx *ctx) {
     // ... and only for enough barcodes: the index forces 4..8-read tiles, whose per-tile latency costs about
     // as much as sweeping ~40 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.017 us/pair
     // against 0.054 us/pair of the plain sweep)
-    if (total_bc < 48) return BDX_OK;
+    {
+        int min_b = 48;
+        if (const char *e = getenv("BDX_DIAG_MIN_B")) min_b = atoi(e);  // tuning experiments
+        if (total_bc < min_b) return BDX_OK;
+    }
     sp.diag_qcap = (int)((flagged + (double)n_always) * 1.6) + 16;  // sweep-queue entries per read
     size_t bytes = 0;
     size_t o_meta[2], o_keys[2], o_always[2];
