@@ -169,7 +169,7 @@ __device__ __forceinline__ AlignOut sg_core(LDS int *DP, LDS int *OG, const int 
 // Why: lanes of a wave sit in their barcode's match region at different columns, so the wave
 // runs ~m rows in every column anyway; without LDS round-trips in the dependent chain the
 // statically unrolled form is several times faster.
-template <bool TB, bool NS, int M, bool STAGED>
+template <bool TB, bool NS, int M, bool STAGED, bool ENDPOS = false>
 __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
                                                 const int n, const int ae, const Costs c, const int trim_side,
                                                 int first, int last, const int max_start,
@@ -284,7 +284,7 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
             lact -= 1;
             if (j >= min_end) {
                 if (prev == 0 && (!TB || trim_side == 5)) {  // :420-430
-                    AlignOut z{0, TB ? prev_o : -1, TB ? j : -1};
+                    AlignOut z{0, TB ? prev_o : -1, (TB || ENDPOS) ? j : -1};
                     return z;
                 }
                 if (TB) {  // :142-153
@@ -293,8 +293,9 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
                         res.start = prev_o;
                         res.end = j;
                     }
-                } else {
-                    res.raw = prev < res.raw ? prev : res.raw;
+                } else if (prev < res.raw) {
+                    res.raw = prev;
+                    if (ENDPOS) res.end = j;  // trim_side == 5 needs the end column only (:910-919): no origins
                 }
             }
         }
@@ -569,8 +570,13 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                 a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
                             : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             } else if (REGM > 0) {
-                a = need_tb ? sg_core_reg<true, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
-                            : sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
+                // With trim_side == 5 and nobody asking for the start position, the alignment's END is all that is
+                // observable (keep_start = end + 1, :914): the origin half of the DP is dropped.  Same values, same
+                // early exit (:420) and the same strict-improvement rule as the traceback form with trim_side 5.
+                const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
+                a = !need_tb ? sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
+                    : end_only ? sg_core_reg<false, false, (REGM > 0 ? REGM : 4), STAGED, true>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
+                               : sg_core_reg<true, false, (REGM > 0 ? REGM : 4), STAGED>(q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             } else {
                 a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
                             : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);

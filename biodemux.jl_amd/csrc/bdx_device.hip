@@ -284,6 +284,7 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     a.wcnt[1] = d_wcnt1;
     a.list = d_list;
     a.list_count = d_list_count;
+    a.cfg.end_only_ok = out.pass_start == nullptr ? 1 : 0;
     a.dp_rows = plan.dp_rows;
     a.stage_bytes = plan.stage_bytes;
     a.bc_stage_bytes = plan.bc_stage_bytes;

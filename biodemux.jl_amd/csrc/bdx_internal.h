@@ -46,6 +46,7 @@ struct BdxDevCfg {
     int match, mismatch, indel;
     int has_nindel, nindel;
     int need_traceback;
+    int end_only_ok;   // per launch: the caller did not ask for pass_start (an end-only DP may serve trim_side 5)
     int max_m;
     int force_lds_dp;   // testing: use the LDS-resident DP even for short barcodes (env BDX_LDS_DP)
     int any_traceback;  // origin array needed (trim or summary in any pass)

@@ -434,3 +434,33 @@ def test_cli_directory_mode_on_the_gpu(tmp_path):
     rc = cli.main([os.path.join(H.REF, "FASTQ_files", "demo1_R1"), os.path.join(H.REF, "reference_files", "demo1.tsv"), out])
     assert rc == 0
     assert H.check_output_files(out, os.path.join(H.REF, "results", "demo1_R1")) > 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_error_rate=0.1, trim_side=5),
+    dict(max_error_rate=0.2, trim_side=5, min_delta=0.05),
+    dict(max_error_rate=0.25, trim_side=5, mismatch=1, indel=2),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_trim5_without_pass_outputs_uses_the_end_only_dp(kw):
+    """With trim_side = 5 and no per-pass outputs requested the exact kernel drops the origin half of the DP
+    (only the alignment's end is observable).  Verdicts and trim coordinates must equal the oracle's, for
+    every filter mode; also dual with trim 5 / 3 (pass 1 end-only, pass 2 with origins)."""
+    bcs = synth.make_barcodes(40, 24, seed=61)
+    seq, off, _ = synth.make_reads(bcs, 12000, 150, seed=62)
+    cfg = _c2_config(bcs, **kw)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(seq, off)
+    for flt in ("off", "bitpar", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=False, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            for k in ("bc1", "bc2", "keep_start", "keep_end"):
+                assert np.array_equal(got[k], exp[k]), (flt, k)
+    b2 = synth.make_barcodes(10, 24, seed=63)
+    s2, o2, _ = synth.make_reads(bcs, 8000, 150, seed=64, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+    cfg2 = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[24] * 40, ids=[f"x{i}" for i in range(40)], is_dual=True,
+                             bc_seqs2=b2, bc_lengths_no_N2=[24] * 10, ids2=[f"y{i}" for i in range(10)],
+                             max_error_rate=kw["max_error_rate"], trim_side=5, trim_side2=3)
+    exp2 = H.orc.OracleClassifier(cfg2, nthreads=16, want_pass=False).classify(s2, o2)
+    with H.bdx.HipClassifier(cfg2, want_pass=False) as hc:
+        got2 = hc.classify(s2, o2)
+        for k in ("bc1", "bc2", "keep_start", "keep_end"):
+            assert np.array_equal(got2[k], exp2[k]), k
