@@ -960,6 +960,167 @@ static int64_t unit_cols(const uint8_t *q, int64_t m, const uint8_t *r, int64_t 
     return found;
 }
 
+/* ---- model of the HIP register DP (csrc/bdx_core.h sg_core_reg), test-only --------------------------
+ * Same row-mask formulation as the kernel (all rows visited, state changes predicated on fact..lact),
+ * SimpleScoring only, plus the kernel's "reachability cone" for restricted runs: in a run that ends at
+ * column E = min(last, col_hi), a cell (i, j) can lie on an alignment that reaches row m by column E with
+ * at most kbr = allowed_error / min(mismatch, indel) operations only if  m - i <= (E - j) + kbr;  rows
+ * above  bound(j) = m - kbr - (E - j)  are skipped and the deletion input of row bound(j) is infinite.
+ * orc_selftest_cone checks the model against the line-faithful core above. */
+static orc_align_t kernel_model_core(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n, double max_error,
+                                     int64_t match, int64_t mismatch, int64_t indel, int32_t output_mode,
+                                     int32_t trim_side, int64_t first, int64_t last, int64_t max_start,
+                                     int64_t min_end, int64_t norm, int64_t col_lo, int64_t col_hi, int cone) {
+    const uint8_t *q = q0 - 1, *r = r0 - 1;
+    const int tb = output_mode == ORC_OUT_TRACEBACK;
+    const int64_t BIG = (int64_t)1 << 40;
+    res_t res = init_result();
+    int64_t DP[72], OG[72];
+    if (m == 0 || n == 0) return finalize_result(output_mode, res, norm);
+    const int64_t ae = (int64_t)floor(max_error * (double)norm);
+    const int64_t steps = ae / indel;
+    const int64_t min_valid_start = min_end - (m + steps) + 1;
+    if (min_valid_start > max_start) return finalize_result(output_mode, res, norm);
+    if (min_valid_start > first) first = min_valid_start;
+    const int64_t band = imax(m - n - steps, -max_start - steps);
+    for (int64_t i = 1; i <= m; i++) {
+        DP[i] = indel * i;
+        OG[i] = 1 - i;
+    }
+    int64_t lact = imin(ae + 1, m);
+    const int restricted = col_hi != INT64_MAX;
+    if (col_lo > first) first = col_lo;
+    if (col_hi < last) last = col_hi;
+    const int64_t cmin = mismatch < indel ? mismatch : indel;
+    const int cone_on = cone && restricted && cmin > 0 && match >= 0 && ae >= 0;
+    const int64_t kbr = cone_on ? ae / cmin : 0;
+    for (int64_t j = first; j <= last; j++) {
+        int64_t prev_o = j, fact, prev;
+        if (j + band >= 1) {
+            fact = j + band;
+            prev = ae;
+        } else {
+            fact = 1;
+            prev = 0;
+        }
+        if (fact > lact) return finalize_result(output_mode, res, norm);
+        const int64_t bound = cone_on ? m - kbr - (last - j) : -BIG;
+        const int64_t seed = prev;
+        int64_t diag = 0, diag_o = j;
+        for (int64_t i = 1; i <= m; i++) {
+            const int64_t old = DP[i], old_o = OG[i];
+            const int inb = i >= fact && i <= lact && i >= bound;
+            const int64_t ins = (i == m) ? BIG : old + indel;
+            const int64_t del = (i == bound) ? BIG : prev + indel;
+            const int64_t sub = diag + (q[i] == r[j] ? match : mismatch);
+            int64_t cur_o = prev_o, best = del;
+            if (sub < best) {
+                best = sub;
+                cur_o = diag_o;
+            }
+            if (ins < best) cur_o = old_o;
+            const int64_t nv = min3(ins, del, sub);
+            const int seedrow = (i == fact - 1);
+            DP[i] = inb ? nv : (seedrow ? seed : old);
+            OG[i] = inb ? cur_o : (seedrow ? j : old_o);
+            if (inb) {
+                prev = nv;
+                prev_o = cur_o;
+            }
+            diag = old;
+            diag_o = old_o;
+        }
+        if (lact == m && prev <= ae) {
+            lact -= 1;
+            if (j >= min_end) {
+                if (prev == 0 && (!tb || trim_side == 5)) {
+                    res_t z = {0, tb ? prev_o : -1, tb ? j : -1};
+                    return finalize_result(output_mode, z, norm);
+                }
+                if (tb) res = update_result_traceback(trim_side, res, prev, j, prev_o);
+                else res = update_result_scoreonly(res, prev);
+            }
+        }
+        for (int64_t i = m; i >= 1; --i)
+            if (lact == i && DP[i] > ae) lact = i - 1;
+        lact += 1;
+    }
+    return finalize_result(output_mode, res, norm);
+}
+
+/* Differential self-test of the kernel model: (a) unrestricted, no cone == the line-faithful core;
+ * (b) restricted to e_lo - 2(m+kb) - 1 .. e_hi WITH the cone == the line-faithful core over the whole range.
+ * Returns the number of disagreements (first one described in first_bad[0..7]). */
+int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[6] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[260];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 2 + (int64_t)(st_next(&s) % 31);
+        int64_t n = (int64_t)(st_next(&s) % 250);
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % 4];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % ((st_next(&s) % 50) ? 4 : 5)];
+        int copies = (int)(st_next(&s) % 3);
+        for (int cpy = 0; cpy < copies && n > 0; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 5) r[pos++] = (uint8_t)AL[st_next(&s) % 4];
+                else if (u < 8) continue;
+                else if (u < 11) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        double rate = RATES[st_next(&s) % 8];
+        int64_t mismatch = 1 + (int64_t)(st_next(&s) % 3), indel = 1 + (int64_t)(st_next(&s) % 3);
+        int64_t match = (st_next(&s) % 8) == 0 ? 1 : 0;
+        int32_t mode = (int32_t)(st_next(&s) % 2);
+        int32_t trim = mode ? (int32_t)((int[]){0, 3, 5}[st_next(&s) % 3]) : 0;
+        int64_t first = 1, last = n, max_start = n, min_end = 1;
+        if (n > 0 && (st_next(&s) % 3) == 0) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        if (n > 0 && (st_next(&s) % 4) == 0) max_start = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+        if (n > 0 && (st_next(&s) % 4) == 0) min_end = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+        int64_t ae0 = (int64_t)floor(rate * (double)m);
+        int64_t cmin = mismatch < indel ? mismatch : indel;
+        int64_t kb = ae0 < 0 ? -1 : ae0 / cmin;
+        double used = (st_next(&s) % 3) ? rate : rate * (double)(st_next(&s) % 100) / 100.0;
+        orc_align_t full = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, 0, 1, mode, trim, first,
+                                                last, max_start, min_end, m, INT64_MIN, INT64_MAX);
+        orc_align_t plain = kernel_model_core(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, max_start,
+                                              min_end, m, INT64_MIN, INT64_MAX, 0);
+        int64_t e_lo = 0, e_hi = 0;
+        int64_t f = first < 1 ? 1 : first, l = last > n ? n : last;
+        int found = (n > 0 && l >= f && kb >= 0) ? (int)unit_cols(q, m, r, f, l, 0, kb, &e_lo, &e_hi) : 0;
+        orc_align_t res;
+        if (!found) {
+            res.score = INFINITY;
+            res.raw = INF_INT;
+            res.start = -1;
+            res.end = -1;
+        } else {
+            res = kernel_model_core(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, max_start, min_end,
+                                    m, e_lo - 2 * (m + kb) - 1, e_hi, 1);
+        }
+        const int bad_plain = plain.raw != full.raw || plain.start != full.start || plain.end != full.end;
+        const int bad_cone = res.raw != full.raw || res.start != full.start || res.end != full.end;
+        if (bad_plain || bad_cone) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = full.raw;
+                first_bad[4] = bad_plain ? plain.raw : res.raw; first_bad[5] = full.start;
+                first_bad[6] = bad_plain ? plain.start : res.start; first_bad[7] = (bad_plain ? 1000 : 0) + mode * 10 + trim;
+            }
+            bad++;
+        }
+    }
+    return bad;
+}
+
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
     static const char AL[6] = "ACGTN";
     static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};

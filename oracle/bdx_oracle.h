@@ -164,6 +164,7 @@ int orc_classify_batch(const orc_config_t *cfg, const uint8_t *seq_bytes, const 
 int64_t orc_unit_distance(const uint8_t *q, int64_t m, const uint8_t *r, int64_t n);
 int64_t orc_selftest_known_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad);
+int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad);
 
 #ifdef __cplusplus
 }

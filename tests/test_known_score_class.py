@@ -30,3 +30,15 @@ def test_restricted_exact_run_equals_full_run():
     fb = (C.c_int64 * 8)()
     bad = H.orc.lib().orc_selftest_windowed_exact(20260515, 300_000, fb)
     assert bad == 0, f"first disagreement (iter, m, n, full.raw, res.raw, full.start, res.start, mode*10+trim): {list(fb)}"
+
+
+def test_register_dp_formulation_equals_the_faithful_core():
+    """The HIP register DP visits ALL rows and predicates state changes on fact..lact (csrc/bdx_core.h
+    sg_core_reg); oracle/bdx_oracle.c kernel_model_core restates that formulation in C.  It must return the
+    same (score, start, end) as the line-faithful core — unrestricted, and over the restricted column range
+    of §3.2 together with the reachability cone (rows that cannot reach row m by the last column within the
+    operation budget are skipped).  The cone is exact (0 disagreements in 6 M cases) but was not kept in the
+    kernel: the union over the 64 lanes of a wave leaves almost every row block active."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_cone(20260515, 300_000, fb)
+    assert bad == 0, f"first disagreement (iter, m, n, full.raw, model.raw, full.start, model.start, 1000*plain + mode*10+trim): {list(fb)}"
