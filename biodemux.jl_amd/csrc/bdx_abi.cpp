@@ -456,7 +456,7 @@ int build_diag_tables(bdx_ctx *ctx) {
         if (const char *e = getenv("BDX_DIAG_MIN_B")) min_b = atoi(e);  // tuning experiments
         if (total_bc < min_b) return BDX_OK;
     }
-    sp.diag_qcap = (int)((flagged + (double)n_always) * 1.6) + 16;  // sweep-queue entries per read
+    sp.diag_qcap = (int)((flagged + (double)n_always) * 1.3) + 12;  // sweep-queue entries per read (a sub-batch shares 8 reads' worth)
     size_t bytes = 0;
     size_t o_meta[2], o_keys[2], o_always[2];
     for (int k = 0; k < 2; ++k) {
@@ -558,7 +558,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     const int tries[7] = {256, 128, 64, 32, 16, 8, 4};
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
-        if (diag ? R > 16 : R < 16) continue;  // the diagonal variant keeps 5 KiB of index per read: small tiles
+        if (diag ? R > 32 : R < 16) continue;  // the diagonal variant indexes 8 reads at a time (40 KiB): small tiles
         if (forced && R != forced) continue;
         if (!forced && R > r_cap) continue;
         if (!forced && !ctx->splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
@@ -570,7 +570,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         bp.read_len_hint_for_lds = read_len;
         const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->splan);
         if (lds > LDS_MAX) continue;
-        int blocks = (int)(LDS_MAX / lds);
+        int blocks = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));  // LDS is allocated in 1280-byte granules (measured: 54128 B -> 2 per CU, 51872 B -> 3)
         // Measured on MI355X (tools/probe.py): tile size matters more than residency once 3
         // workgroups (12 waves) share a CU — larger tiles fill the 256 lanes of the sparse
         // sweep / exact stages better.  Rank: >= 3 resident (largest R wins), then 2, then 1.

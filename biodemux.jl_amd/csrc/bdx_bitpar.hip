@@ -80,6 +80,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     static_assert(!DIAG || SEED, "the diagonal variant is a seeded variant");
     constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
     constexpr int NW = 5;                 // DIAG: position words per 4-mer key (reads of <= 160 staged bases)
+    constexpr int SB = DIAG ? (R < 8 ? R : 8) : R;  // DIAG: reads indexed at a time (5 KiB of index each); larger tiles are walked in sub-batches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const int RCAP = SEED ? a.seed_rcap : 8;
     const int RCAP_LOG2 = 31 - __builtin_clz(RCAP);
     const int SQCAP = (SEED && a.seed_rcap >= 16) ? 16 * R : 8 * R;  // capacity of the seed-hit queue
-    const int PQCAP = DIAG ? a.diag_qcap * R : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
+    const int PQCAP = DIAG ? a.diag_qcap * SB : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
     const int npass = cfg.is_dual ? 2 : 1;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *slh = (LDS uint32_t *)take(SEED ? (size_t)R * 4 : 0);  // per read: first | (last + 1) << 16 seed start, relative to the first staged base
     LDS int *srw = (LDS int *)take(SEED ? (size_t)R * 4 : 0);            // per read: stage offset of its first staged base
     // DIAG variant: per-read inverted index of 4-mers (bit p of occ[r][key][.] <=> the 4-mer at staged position p is key)
-    LDS uint32_t *occ = (LDS uint32_t *)take(DIAG ? (size_t)R * 256 * NW * 4 : 0);
+    LDS uint32_t *occ = (LDS uint32_t *)take(DIAG ? (size_t)SB * 256 * NW * 4 : 0);
     LDS uint32_t *dm0 = (LDS uint32_t *)take(DIAG ? (size_t)B0 * 4 : 0);
     LDS uint32_t *dm1 = (LDS uint32_t *)take(DIAG ? (size_t)B1 * 4 : 0);
     LDS uint32_t *dk0 = (LDS uint32_t *)take(DIAG ? (size_t)B0 * 8 : 0);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             }
         if (DIAG) {
             const u32x4 z = {0u, 0u, 0u, 0u};
-            for (int i = tid; i < R * 256 * NW / 4; i += BS) ((LDS u32x4 *)occ)[i] = z;
+            for (int i = tid; i < SB * 256 * NW / 4; i += BS) ((LDS u32x4 *)occ)[i] = z;
         }
         if (tid < 2) sqn[tid] = 0;
     }
@@ -509,6 +510,11 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // whole-window minimum whenever the latter is <= kb — the only case anything
             // downstream looks at.
             const int q = a.seed_q;
+            // DIAG walks the tile in sub-batches of SB reads (index, pair test, sweeps); HASH: one pass over the tile
+            const int nbatch = DIAG ? (nr + SB - 1) / SB : 1;
+            for (int bi = 0; bi < nbatch; ++bi) {
+            const int rb0 = DIAG ? bi * SB : 0;
+            const int rbn = DIAG ? (nr - rb0 < SB ? nr - rb0 : SB) : nr;  // reads of this sub-batch
             if constexpr (HASH) {
             // scan: lane = (read, group of 16 consecutive bases of the flat 2-bit image); the group's 16
             // start positions share one 64-bit window (16 + 7 bases), every key is probed in the bitmap.  The
@@ -676,12 +682,20 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             //     candidates are swept over [b_min - h - kb - 1, b_max + h + m + kb + 1).
             const int hsm = (a.diag_kmax + 1) >> 1;
             {
+                if (bi > 0) {  // the previous sub-batch is done with the index and the sweep queue
+                    __syncthreads();
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    for (int i = tid; i < SB * 256 * NW / 4; i += BS) ((LDS u32x4 *)occ)[i] = z;
+                    if (tid == 0) sqn[1] = 0;
+                    __syncthreads();
+                }
                 const int G = a.seed_groups;
                 const int dr = BS / G, dg = BS - dr * G;
-                int r = tid / G, g = tid - r * G;
-                const int total_items = (a.dbg & 8) ? 0 : nr * G;
+                int rl = tid / G, g = tid - rl * G;  // rl: read within the sub-batch
+                const int total_items = (a.dbg & 8) ? 0 : rbn * G;
                 const LDS uint32_t *spk32 = (const LDS uint32_t *)spk;
-                for (int idx = tid; idx < total_items; idx += BS, r += dr, g += dg, r += (g >= G), g -= (g >= G) ? G : 0) {
+                for (int idx = tid; idx < total_items; idx += BS, rl += dr, g += dg, rl += (g >= G), g -= (g >= G) ? G : 0) {
+                    const int r = rb0 + rl;
                     const int rw = srw[r];
                     const uint32_t lh = slh[r];
                     const int F = (rw >> 4) + g;
@@ -691,7 +705,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     i1 = i1 > 15 ? 15 : i1;
                     if (sall[r] || i0 > i1) continue;
                     const uint32_t w0 = spk32[F], w1 = spk32[F + 1];
-                    LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
+                    LDS uint32_t *oc = occ + (size_t)rl * 256 * NW;
                     for (int i = i0; i <= i1; ++i) {
                         const uint32_t key = __builtin_amdgcn_alignbit(w1, w0, 2 * i) & 255u;
                         const int lo = p0 + i, hi = lo + 2 * hsm;  // bits [pos, pos + 2h]: <= 32 NW - 1 (reads <= 32 NW - 8 bases)
@@ -711,11 +725,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int B = p ? B1 : B0;
                 const LDS uint32_t *dm = p ? dm1 : dm0;
                 const LDS uint32_t *dk = p ? dk1 : dk0;
-                const int total = (a.dbg & 4) ? 0 : nr * B;
-                for (int pair0 = 0; pair0 < total; pair0 += BS) {  // uniform trip count: wave-aggregated append
+                const int total = (a.dbg & 4) ? 0 : rbn * B;
+                for (int pair0 = 0; pair0 < total; pair0 += BS) {
                     const int pair = pair0 + tid;
                     const bool in = pair < total;
-                    const int r = in ? pair / B : 0, b = in ? pair - r * B : 0;
+                    const int rl = in ? pair / B : 0, b = in ? pair - rl * B : 0;
+                    const int r = rb0 + rl;
                     const uint32_t meta = in ? dm[b] : 0u;
                     uint32_t Cm[NW + 1];
                     bool cand_pair = false;
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         const uint32_t k0 = dk[2 * b], k1 = dk[2 * b + 1];
                         kk = (p ? kb1 : kb0)[b];
                         mm = __builtin_popcount((p ? pv1 : pv0)[b]);
-                        const LDS uint32_t *oc = occ + (size_t)r * 256 * NW;
+                        const LDS uint32_t *oc = occ + (size_t)rl * 256 * NW;
                         uint32_t SU[NW + 1];
 #pragma unroll
                         for (int w = 0; w <= NW; ++w) SU[w] = Cm[w] = 0u;
@@ -807,9 +822,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // barcodes that are swept unconditionally (wildcards, pieces shorter than 5): whole window
             for (int p = 0; p < npass; ++p) {
                 const int na = a.seed_n_always[p];
-                for (int idx = tid; idx < nr * na; idx += BS) {
-                    const int r = idx / na;
-                    const int b = a.seed_always[p][idx - r * na];
+                for (int idx = tid; idx < rbn * na; idx += BS) {
+                    const int rl = idx / na;
+                    const int r = rb0 + rl;
+                    const int b = a.seed_always[p][idx - rl * na];
                     const int kq = __hip_atomic_fetch_add(&sqn[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (kq < PQCAP) {
                         spq[kq] = ((uint32_t)r << 16) | ((uint32_t)p << 15) | (uint32_t)(b + 1);
@@ -820,8 +836,6 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 }
             }
             __syncthreads();
-            const int any_sall = sqn[5];
-            if ((a.dbg & 128) && tid == 0 && any_sall) atomicAdd(a.exc_count + 3, 1u);  // does any read of this tile need the whole-read fallback below?
             {
                 const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
                 for (int k = tid; k < np; k += 2 * BS) {
@@ -838,6 +852,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     }
                     sweep2(A, Bw);
                 }
+            }
+            }  // sub-batches
+            if (DIAG) __syncthreads();  // orders the last sub-batch's flag writes before the read below
+            const int any_sall = sqn[5];  // does any read of this tile need the whole-read fallback below?
+            if ((a.dbg & 128) && tid == 0 && any_sall) atomicAdd(a.exc_count + 3, 1u);
+            {
                 // reads whose lists overflowed: every barcode over the whole window, exactly once
                 for (int p = 0; p < npass; ++p) {
                     const int B = p ? B1 : B0;
@@ -1036,7 +1056,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     // persistent grid: enough workgroups to fill every CU at the LDS-limited residency,
     // never more than there are tiles
     const long long tiles = (n_reads + R - 1) / R;
-    long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
+    long long per_cu = (long long)((160 * 1024) / (lds ? ((lds + 1279) / 1280) * 1280 : 1));  // 1280-byte LDS granules
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     long long blocks = 256 * per_cu;  // exactly the resident set; the tile queue balances it
@@ -1063,9 +1083,10 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
-        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (sp->diag_qcap > 0 ? sp->diag_qcap : 64) * R * 4);
+        const int SBh = R < 8 ? R : 8;  // index sub-batch (see the kernel)
+        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (sp->diag_qcap > 0 ? sp->diag_qcap : 64) * SBh * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
-        o += al((size_t)R * 256 * 5 * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
+        o += al((size_t)SBh * 256 * 5 * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
     } else if (sp && sp->enabled) {
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 32);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
@@ -1141,6 +1162,8 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     const bool seed = sp.enabled != 0;
     if (seed && sp.diag) {
         switch (bp.reads_per_block) {
+            case 32:
+                return launch_one<256, 32, true, true>(a, lds, n_reads, stream);
             case 16:
                 return launch_one<256, 16, true, true>(a, lds, n_reads, stream);
             case 8:
