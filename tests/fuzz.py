@@ -69,6 +69,41 @@ def random_case(seed: int, n_reads: int = 600):
     return cfg, seq, off
 
 
+def random_case_many_barcodes(seed: int, n_reads: int = 1500):
+    """Like random_case but in the domain of the seeded variants: 48..160 barcodes of 20..32 nt, reads of up
+    to 152 (sometimes longer) bases, rates around the budgets where single seeds / two intact pieces apply."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    alg = ["semiglobal", "semiglobal", "semiglobal", "semiglobal", "hamming"][int(rng.integers(0, 5))]
+    B = int(rng.integers(48, 160))
+    lo = int([20, 24, 24, 28, 32][int(rng.integers(0, 5))])
+    hi = lo if rng.random() < 0.7 else min(32, lo + int(rng.integers(1, 9)))
+    bcs = _rand_barcodes(rng, B, lo, hi, False)
+    dual = rng.random() < 0.25
+    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 40)), lo, hi, False) if dual else []
+    unit = rng.random() < 0.7
+    kw = dict(
+        bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
+        max_error_rate=float([0.1, 0.13, 0.17, 0.2, 0.2, 0.22, 0.25][int(rng.integers(0, 7))]),
+        min_delta=float([0.0, 0.0, 0.05, 0.1][int(rng.integers(0, 4))]),
+        match=0, mismatch=1 if unit else int(rng.integers(1, 3)), indel=1 if unit else int(rng.integers(1, 3)),
+        nindel=None,
+        ref_search_range=H.bdx.parse_dynamic_range(["1:end", "1:end", "1:end", "5:end-3", "1:120"][int(rng.integers(0, 5))]),
+        trim_side=[None, None, 3, 5][int(rng.integers(0, 4))],
+        summary=bool(rng.random() < 0.15),
+        matching_algorithm=alg,
+    )
+    if dual:
+        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[len(b) for b in bcs2], ids2=[f"b{i}" for i in range(len(bcs2))],
+                  trim_side2=[None, 3, 5][int(rng.integers(0, 3))])
+    cfg = H.bdx.DemuxConfig(**kw)
+    max_len = int([100, 150, 150, 152, 151, 200][int(rng.integers(0, 6))])
+    second = (bcs2, max_len // 2, None) if dual else None
+    seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 2 if rng.random() < 0.5 else max_len, max_len, seed=seed,
+                                          plant_frac=0.85, sub=0.05, ins=0.02, dele=0.02, n_rate=0.003,
+                                          plant_hi=(max_len // 3 if dual else None), second=second)
+    return cfg, seq, off
+
+
 def assert_same(got: dict, exp: dict, what: str = ""):
     for k in ("bc1", "bc2", "keep_start", "keep_end", "pass_bc", "pass_start", "pass_end"):
         if k in got and k in exp:

@@ -30,6 +30,26 @@ for seed in range(lo, hi):
             print("MISMATCH", e, flush=True)
 print(f"fuzz seeds {lo}..{hi - 1}: {bad} mismatches, paths {paths}, {time.time() - t0:.0f} s", flush=True)
 
+# the seeded variants' domain: many barcodes, budgets around the single-seed / two-intact-pieces switch
+lo2, hi2 = int(os.environ.get("SEED2_LO", "5000")), int(os.environ.get("SEED2_HI", "5150"))
+paths2 = {}
+t0 = time.time()
+for seed in range(lo2, hi2):
+    cfg, seq, off = fuzz.random_case_many_barcodes(seed)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt, want in (("off", True), ("auto", True), ("auto", False)):
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want, filter=flt) as hc:
+                got = hc.classify(seq, off)
+                paths2[hc.kernel_path] = paths2.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"seed {seed} filter {flt} want_pass {want} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), f"seed {seed} counters"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"many-barcode seeds {lo2}..{hi2 - 1}: paths {paths2}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
 
 def stress(name, bcs, seq, off, **kw):
     global bad
