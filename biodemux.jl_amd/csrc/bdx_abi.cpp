@@ -407,6 +407,7 @@ int build_diag_tables(bdx_ctx *ctx) {
     std::vector<uint16_t> always[2];
     int total_bc = 0, kmax = 0;
     double flagged = 0.0;  // expected falsely flagged pairs per read of ~150 bases
+    double flag_coef = 0.0;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
         if (p.n_barcodes > 32767) return BDX_OK;
@@ -441,6 +442,7 @@ int build_diag_tables(bdx_ctx *ctx) {
             keys[k][2 * b + 1] = (uint32_t)(kk >> 32);
             const double hits = 147.0 / 256.0;  // occurrences of one 4-mer in the read
             flagged += (double)(P * (P - 1) / 2) * hits * hits * (double)(2 * kb + 1) / (150.0 + m);
+            flag_coef += (double)(P * (P - 1) / 2) * (double)(2 * kb + 1);
         }
     }
     const size_t n_always = always[0].size() + always[1].size();
@@ -456,7 +458,7 @@ int build_diag_tables(bdx_ctx *ctx) {
         if (const char *e = getenv("BDX_DIAG_MIN_B")) min_b = atoi(e);  // tuning experiments
         if (total_bc < min_b) return BDX_OK;
     }
-    sp.diag_qcap = (int)((flagged + (double)n_always) * 1.3) + 12;  // sweep-queue entries per read (a sub-batch shares 8 reads' worth)
+    const double coef_keep = flag_coef;
     size_t bytes = 0;
     size_t o_meta[2], o_keys[2], o_always[2];
     for (int k = 0; k < 2; ++k) {
@@ -477,9 +479,8 @@ int build_diag_tables(bdx_ctx *ctx) {
     HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
     HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
-    const int qcap = sp.diag_qcap;
     sp = BdxSeedPlan{};
-    sp.diag_qcap = qcap;
+    sp.diag_flag_coef = coef_keep;
     for (int k = 0; k < 2; ++k) {
         sp.d_dmeta[k] = (const uint32_t *)(base + o_meta[k]);
         sp.d_dkeys[k] = (const uint32_t *)(base + o_keys[k]);
@@ -553,7 +554,15 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     const int slot = slot_mode ? ((wmax + 15 + 16 + 15) & ~15) : 0;
     bp.slot_bytes = slot;
     bp.seed_span = slot_mode ? wmax : read_len;
-    if (ctx->splan.enabled && ctx->splan.diag && bp.seed_span > 152) ctx->splan.enabled = 0;  // index holds 160 positions
+    if (ctx->splan.enabled && ctx->splan.diag) {
+        // index width for this read length, and the sweep queue for the expected number of flagged pairs
+        if (bp.seed_span > 312) ctx->splan.enabled = 0;  // the widest index holds 320 positions
+        bp.diag_nw = bp.seed_span <= 152 ? 5 : 10;
+        const double L = (double)(bp.seed_span < 32 ? 32 : bp.seed_span);
+        const double flagged = ctx->splan.diag_flag_coef * ((L - 3.0) / 256.0) * ((L - 3.0) / 256.0) / (L + 24.0) +
+                               (double)(ctx->splan.n_always[0] + ctx->splan.n_always[1]);
+        bp.diag_qcap = (int)(flagged * 1.3) + 12;  // per read (a sub-batch shares 4..8 reads' worth)
+    }
     const bool diag = ctx->splan.enabled && ctx->splan.diag;
     const int tries[7] = {256, 128, 64, 32, 16, 8, 4};
     int best_R = 0, best_blocks = 0, best_stage = 0;

@@ -75,12 +75,13 @@ struct BitparArgs {
 // The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
 // VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
 // are short and barrier-separated, so throughput follows the number of resident waves closely.
-template <int BS, int R, bool SEED, bool DIAG>
+template <int BS, int R, bool SEED, bool DIAG, int NW = 5>
 __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     static_assert(!DIAG || SEED, "the diagonal variant is a seeded variant");
     constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
-    constexpr int NW = 5;                 // DIAG: position words per 4-mer key (reads of <= 160 staged bases)
-    constexpr int SB = DIAG ? (R < 8 ? R : 8) : R;  // DIAG: reads indexed at a time (5 KiB of index each); larger tiles are walked in sub-batches
+    // NW (DIAG): position words per 4-mer key: 5 for reads of <= 152 staged bases, 10 for <= 312
+    constexpr int SBMAX = NW <= 5 ? 8 : 4;           // 40 KiB of index either way
+    constexpr int SB = DIAG ? (R < SBMAX ? R : SBMAX) : R;  // DIAG: reads indexed at a time (5 KiB of index each); larger tiles are walked in sub-batches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -1044,11 +1045,11 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 }
 
-template <int BS, int R, bool SEED, bool DIAG = false>
+template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG>,
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -1063,7 +1064,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     if (const char *e = getenv("BDX_GRID")) blocks = atoll(e);
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
+    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1083,10 +1084,12 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
-        const int SBh = R < 8 ? R : 8;  // index sub-batch (see the kernel)
-        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (sp->diag_qcap > 0 ? sp->diag_qcap : 64) * SBh * 4);
+        const int nw = bp.diag_nw > 0 ? bp.diag_nw : 5;
+        const int sbmax = nw <= 5 ? 8 : 4;
+        const int SBh = R < sbmax ? R : sbmax;  // index sub-batch (see the kernel)
+        o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (bp.diag_qcap > 0 ? bp.diag_qcap : 64) * SBh * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
-        o += al((size_t)SBh * 256 * 5 * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
+        o += al((size_t)SBh * 256 * nw * 4) + al((size_t)B0 * 4) + al((size_t)B1 * 4) + al((size_t)B0 * 8) + al((size_t)B1 * 8);
     } else if (sp && sp->enabled) {
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 32);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
@@ -1145,7 +1148,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_bm_log2 = sp.bm_log2;
     a.seed_rcap = sp.rcap > 0 ? sp.rcap : 8;
     a.diag_kmax = sp.diag_kmax;
-    a.diag_qcap = sp.diag_qcap > 0 ? sp.diag_qcap : 64;
+    a.diag_qcap = bp.diag_qcap > 0 ? bp.diag_qcap : 64;
     for (int k = 0; k < 2; ++k) {
         a.dmeta[k] = sp.d_dmeta[k];
         a.dkeys[k] = sp.d_dkeys[k];
@@ -1161,18 +1164,20 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp, &sp);
     const bool seed = sp.enabled != 0;
     if (seed && sp.diag) {
+#define BDX_LAUNCH_D(RR) return bp.diag_nw > 5 ? launch_one<256, RR, true, true, 10>(a, lds, n_reads, stream) : launch_one<256, RR, true, true, 5>(a, lds, n_reads, stream)
         switch (bp.reads_per_block) {
             case 32:
-                return launch_one<256, 32, true, true>(a, lds, n_reads, stream);
+                BDX_LAUNCH_D(32);
             case 16:
-                return launch_one<256, 16, true, true>(a, lds, n_reads, stream);
+                BDX_LAUNCH_D(16);
             case 8:
-                return launch_one<256, 8, true, true>(a, lds, n_reads, stream);
+                BDX_LAUNCH_D(8);
             case 4:
-                return launch_one<256, 4, true, true>(a, lds, n_reads, stream);
+                BDX_LAUNCH_D(4);
             default:
                 return hipErrorInvalidValue;
         }
+#undef BDX_LAUNCH_D
     }
 #define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream) : launch_one<256, RR, false>(a, lds, n_reads, stream)
     switch (bp.reads_per_block) {

@@ -81,6 +81,8 @@ struct BdxBitparPlan {
     int stage_bytes;       // capacity of each staging area (raw bytes, symbol codes)
     int read_len_hint;     // the read length the geometry was planned for
     int r_cap;             // ... and the tile-size cap the batch size implied
+    int diag_nw;           // diagonal variant: index words per key for this read length (5: <= 152 bases, 10: <= 312)
+    int diag_qcap;         //   ... and sweep-queue entries to provide per read
     int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
     int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
@@ -112,7 +114,7 @@ struct BdxSeedPlan {
     // two-intact-pieces ("diagonal") variant for budgets too large for single seeds (see bdx_bitpar.hip)
     int diag;                      // 1: q = 4 inverted index per read + per-pair diagonal test instead of bitmap / hash
     int diag_kmax;                 // largest operation budget among the seeded barcodes
-    int diag_qcap;                 // sweep-queue entries to provide per read
+    double diag_flag_coef;         // expected flagged pairs per read = coef * ((L - 3) / 256)^2 / (L + 24) for reads of L bases
     const uint32_t *d_dmeta[2];    // per barcode: pieces | piece length << 8 (0 = swept unconditionally)
     const uint32_t *d_dkeys[2];    // per barcode: 2 words, 8 bits per piece key (first 4 bases of the piece)
 };

@@ -348,11 +348,19 @@ def test_diag_ragged_reads(hint):
     _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, hint=hint)
 
 
-def test_diag_longer_reads_fall_back():
+def test_diag_longer_reads():
+    """Reads of up to 312 bases use the wide index (10 words per key, 4-read sub-batches); reads longer than
+    the planned width fall back to sweeping every barcode; beyond 312 bases the plain sweep is planned."""
     bcs = synth.make_barcodes(72, 24, seed=47)
     seq, off, _ = synth.make_ragged_reads(bcs, 8000, 100, 260, seed=47)
     _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, hint=150)  # hint says 150, reads are longer
-    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off)            # planned for 260: no diagonal index
+    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, expect_path=DIAG)  # planned for 260: wide index
+    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2, trim_side=3, min_delta=0.05), seq, off, expect_path=DIAG)
+    seq, off, _ = synth.make_ragged_reads(bcs, 6000, 0, 312, seed=48)
+    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, expect_path=DIAG)
+    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, hint=200)      # some reads beyond the hint
+    seq, off, _ = synth.make_ragged_reads(bcs, 4000, 200, 400, seed=49)
+    _all_filters_agree(_c2_config(bcs, max_error_rate=0.2), seq, off, expect_path="bitpar+verify")
 
 
 def test_diag_low_complexity_queue_overflow():

@@ -59,10 +59,25 @@ def bscale(n):
             outs=("bc1", "keep_start", "keep_end"))
 
 
+def lscale(n):
+    """Throughput against the read length (tile geometry, index width of the diagonal filter)."""
+    C = bdx.DemuxConfig
+    bcs = synth.make_barcodes(96, 24)
+    base = dict(bc_seqs=bcs, bc_lengths_no_N=[24] * 96, ids=[str(i) for i in range(96)])
+    for L in (50, 75, 100, 151, 250, 300):
+        seq, off, _ = synth.make_reads(bcs, n, L)
+        run(f"L={L} rate0.1", C(**base, max_error_rate=0.1), seq, off, check=1500)
+        run(f"L={L} rate0.2", C(**base, max_error_rate=0.2), seq, off, check=1500)
+        run(f"L={L} rate0.1 trim3", C(**base, max_error_rate=0.1, trim_side=3), seq, off, check=1500,
+            outs=("bc1", "keep_start", "keep_end"))
+
+
 def main():
     n = int(os.environ.get("N", "2000000"))
     if os.environ.get("BSCALE"):
         return bscale(n)
+    if os.environ.get("LSCALE"):
+        return lscale(n)
     bcs = synth.make_barcodes(96, 24)
     seq, off, _ = synth.make_reads(bcs, n, 150)
     base = dict(bc_seqs=bcs, bc_lengths_no_N=[24] * 96, ids=[str(i) for i in range(96)])
