@@ -472,3 +472,12 @@ def test_trim5_without_pass_outputs_uses_the_end_only_dp(kw):
         got2 = hc.classify(s2, o2)
         for k in ("bc1", "bc2", "keep_start", "keep_end"):
             assert np.array_equal(got2[k], exp2[k]), k
+
+
+@pytest.mark.parametrize("n_reads,max_len", [(4011, 150), (2003, 150), (4005, 300), (1001, 280)])
+def test_diag_partial_tiles_and_sub_batches(n_reads, max_len):
+    """Last tiles whose read count is not a multiple of the index sub-batch (8 reads, 4 with the wide index)."""
+    bcs = synth.make_barcodes(64, 24, seed=71)
+    seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 3, max_len, seed=72 + n_reads)
+    for kw in (dict(max_error_rate=0.2), dict(max_error_rate=0.2, trim_side=5, min_delta=0.05)):
+        _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path=DIAG)
