@@ -257,7 +257,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
 // the first q bases of that piece do.  Pairs without any such seed hit cannot be candidates and
 // are not swept.  Keys use 2 bits per base (symbol code & 3): equal bytes give equal keys, other
 // bytes may alias — that only adds sweeps, never removes one.
-int build_seed_tables(bdx_ctx *ctx) {
+int build_seed_tables(bdx_ctx *ctx, bool strict) {
     const bdx_config_t &c = ctx->cfg;
     BdxSeedPlan &sp = ctx->splan;
     sp = BdxSeedPlan{};
@@ -313,6 +313,10 @@ int build_seed_tables(bdx_ctx *ctx) {
     const double space = std::pow(4.0, q);
     const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
     if (expected * 3.0 > (double)total_bc) return BDX_OK;
+    // strict: single seeds only when they are really selective (q = 7, 8 in practice).  With ~14 falsely
+    // seeded barcodes per read (q = 6 at B = 96) the hit queue / record tables cost more than the
+    // two-intact-pieces variant, which is tried next (measured at kb = 3: 7.5 ms vs 5.7 ms per 2 M reads).
+    if (strict && expected > 7.0) return BDX_OK;
     sp.q = q;
     // hashed bitmap with >= 48 bits per key (<= ~2 % false hits per position), at most the key space
     // itself (then it is exact).  Too many false hits overflow the hit queue, and an overflow costs a
@@ -775,10 +779,14 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = build_bitpar_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
-    rc = build_seed_tables(ctx);
+    rc = build_seed_tables(ctx, true);
     if (rc != BDX_OK) return bail(rc);
     rc = build_diag_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
+    if (!ctx->splan.enabled) {  // neither: moderately selective single seeds still beat sweeping every pair
+        rc = build_seed_tables(ctx, false);
+        if (rc != BDX_OK) return bail(rc);
+    }
     ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
     ctx->filter_used = ctx->bplan.enabled ? (ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
     if (ctx->bplan.enabled) {
