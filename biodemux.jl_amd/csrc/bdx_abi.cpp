@@ -47,6 +47,10 @@ struct bdx_ctx {
     BdxBitparPlan bplan{};
     BdxSeedPlan splan{};
     DevBuf seed_tables;
+    // weak single seeds kept beside a two-intact-pieces plan: taken when the latter's index does not fit the
+    // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
+    BdxSeedPlan splan_alt{};
+    DevBuf seed_tables_alt;
     DevBuf bp_tables;
     DevBuf d_maxlen;
     int user_len_hint = 0;  // 0 = measure every device batch
@@ -257,9 +261,10 @@ int build_bitpar_tables(bdx_ctx *ctx) {
 // the first q bases of that piece do.  Pairs without any such seed hit cannot be candidates and
 // are not swept.  Keys use 2 bits per base (symbol code & 3): equal bytes give equal keys, other
 // bytes may alias — that only adds sweeps, never removes one.
-int build_seed_tables(bdx_ctx *ctx, bool strict) {
+int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
     const bdx_config_t &c = ctx->cfg;
-    BdxSeedPlan &sp = ctx->splan;
+    BdxSeedPlan &sp = alt ? ctx->splan_alt : ctx->splan;
+    DevBuf &tables = alt ? ctx->seed_tables_alt : ctx->seed_tables;
     sp = BdxSeedPlan{};
     if (!ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || getenv("BDX_NO_SEED")) return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
@@ -365,9 +370,9 @@ int build_seed_tables(bdx_ctx *ctx, bool strict) {
     memcpy(blob.data() + bitmap.size() * 4 + hash.size() * 4, hash_ps.data(), hash_ps.size());
     for (int k = 0; k < 2; ++k)
         if (!always[k].empty()) memcpy(blob.data() + o_always[k], always[k].data(), always[k].size() * 2);
-    HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
-    HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
-    const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
+    HIP_TRY(ctx, tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)tables.p;
     sp.d_bitmap = (const uint32_t *)base;
     sp.d_hash = (const uint32_t *)(base + bitmap.size() * 4);
     sp.d_hash_ps = base + bitmap.size() * 4 + hash.size() * 4;
@@ -560,7 +565,11 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     bp.seed_span = slot_mode ? wmax : read_len;
     if (ctx->splan.enabled && ctx->splan.diag) {
         // index width for this read length, and the sweep queue for the expected number of flagged pairs
-        if (bp.seed_span > 312) ctx->splan.enabled = 0;  // the widest index holds 320 positions
+        if (bp.seed_span > 312) {  // the widest index holds 320 positions: weak single seeds if they apply, else the plain sweep
+            ctx->splan = ctx->splan_alt;  // (disabled if weak seeds do not apply either)
+            ctx->splan_alt = BdxSeedPlan{};
+            return size_bitpar(ctx, read_len, n_reads);
+        }
         bp.diag_nw = bp.seed_span <= 152 ? 5 : 10;
         const double L = (double)(bp.seed_span < 32 ? 32 : bp.seed_span);
         const double flagged = ctx->splan.diag_flag_coef * ((L - 3.0) / 256.0) * ((L - 3.0) / 256.0) / (L + 24.0) +
@@ -596,8 +605,10 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         }
     }
     if (best_R && diag && best_blocks < 2) {
-        // the index leaves room for one workgroup per CU only (very many barcodes): the plain sweep is faster
-        ctx->splan.enabled = 0;
+        // the index leaves room for one workgroup per CU only (very many barcodes): weak single seeds if they
+        // apply, else the plain sweep
+        ctx->splan = ctx->splan_alt;  // (disabled if weak seeds do not apply either)
+        ctx->splan_alt = BdxSeedPlan{};
         return size_bitpar(ctx, read_len, n_reads);
     }
     if (best_R) {
@@ -786,6 +797,9 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (!ctx->splan.enabled) {  // neither: moderately selective single seeds still beat sweeping every pair
         rc = build_seed_tables(ctx, false);
         if (rc != BDX_OK) return bail(rc);
+    } else if (ctx->splan.diag) {  // the fallback of size_bitpar when the index does not fit a batch
+        rc = build_seed_tables(ctx, false, true);
+        if (rc != BDX_OK) return bail(rc);
     }
     ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
     ctx->filter_used = ctx->bplan.enabled ? (ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
@@ -827,6 +841,7 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->counts_own.release();
     ctx->bp_tables.release();
     ctx->seed_tables.release();
+    ctx->seed_tables_alt.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
     ctx->d_seq.release();
