@@ -181,7 +181,6 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             }
     }
     __syncthreads();
-    const int ncode = a.ncode;
     // kernel-argument arrays indexed by a per-lane pass number would be fetched with vector loads from
     // the argument segment: select between two scalars instead
     const int bsh0 = a.bshift[0], bsh1 = a.bshift[1];
