@@ -1023,6 +1023,19 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
     return BDX_OK;
 }
 
+// Page-locked host memory for the buffers handed to bdx_classify_host (reads, offsets, outputs): the
+// copies then run as asynchronous DMA at PCIe speed instead of being staged through the driver.
+void *bdx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void bdx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int64_t bdx_counts_len(const bdx_ctx *ctx) { return ctx ? ctx->dev.n_counts : 0; }
 
 int32_t bdx_get_counts(bdx_ctx *ctx, int64_t *out, int64_t n) {

@@ -27,8 +27,25 @@ ABI_SYMBOLS = [
     "bdx_abi_version", "bdx_create", "bdx_destroy", "bdx_last_error", "bdx_classify_host",
     "bdx_classify_device", "bdx_sync", "bdx_set_stream", "bdx_counts_len", "bdx_get_counts",
     "bdx_reset_counts", "bdx_counts_device_ptr", "bdx_set_counts_buffer", "bdx_kernel_path",
-    "bdx_launch_info", "bdx_set_read_length_hint",
+    "bdx_launch_info", "bdx_set_read_length_hint", "bdx_host_alloc", "bdx_host_free",
 ]
+
+
+def pinned_empty(n: int, dtype) -> "np.ndarray":
+    """A numpy array in page-locked host memory (bdx_host_alloc): buffers handed to ``HipClassifier.classify``
+    from such arrays are copied by asynchronous DMA.  The memory is released when the array is collected."""
+    import weakref
+
+    lib = load_library()
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n) * dt.itemsize)
+    p = lib.bdx_host_alloc(nbytes)
+    if not p:
+        raise MemoryError(f"bdx_host_alloc({nbytes}) failed")
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt, count=int(n))
+    weakref.finalize(buf, lib.bdx_host_free, p)
+    return arr
 
 
 class BdxError(RuntimeError):
@@ -152,6 +169,10 @@ def load_library(path: Optional[str] = None):
     L.bdx_set_counts_buffer.argtypes = [vp, vp]
     L.bdx_set_read_length_hint.restype = C.c_int32
     L.bdx_set_read_length_hint.argtypes = [vp, C.c_int32]
+    L.bdx_host_alloc.restype = vp
+    L.bdx_host_alloc.argtypes = [C.c_size_t]
+    L.bdx_host_free.restype = None
+    L.bdx_host_free.argtypes = [vp]
     L.bdx_kernel_path.restype = C.c_char_p
     L.bdx_kernel_path.argtypes = [vp]
     L.bdx_launch_info.restype = C.c_int32
@@ -266,19 +287,13 @@ class HipClassifier:
         seq_bytes = np.ascontiguousarray(seq_bytes, dtype=np.uint8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
         n = len(seq_off) - 1
-        out = {
-            "bc1": np.zeros(n, dtype=np.int32),
-            "bc2": np.zeros(n, dtype=np.int32),
-            "keep_start": np.full(n, -1, dtype=np.int32),
-            "keep_end": np.full(n, -1, dtype=np.int32),
-        }
+        # every entry of every requested output is written by the kernels: no initialisation pass over them
+        out = {k: np.empty(n, dtype=np.int32) for k in ("bc1", "bc2", "keep_start", "keep_end")}
         if self.want_pass:
-            out["pass_start"] = np.full((n, 2), -1, dtype=np.int32)
-            out["pass_end"] = np.full((n, 2), -1, dtype=np.int32)
-            out["pass_raw"] = np.full((n, 2), -1, dtype=np.int32)
-            out["pass_score"] = np.full((n, 2), np.inf, dtype=np.float64)
-            out["pass_bc"] = np.zeros((n, 2), dtype=np.int32)
-            out["pass_delta"] = np.full((n, 2), np.inf, dtype=np.float64)
+            for k in ("pass_start", "pass_end", "pass_raw", "pass_bc"):
+                out[k] = np.empty((n, 2), dtype=np.int32)
+            for k in ("pass_score", "pass_delta"):
+                out[k] = np.empty((n, 2), dtype=np.float64)
         if n == 0:
             return out
         if seq_bytes.size == 0:

@@ -198,6 +198,12 @@ int32_t bdx_reset_counts(bdx_ctx *ctx);
 void *bdx_counts_device_ptr(bdx_ctx *ctx);
 int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts);
 
+/* Optional: page-locked host memory for the buffers given to bdx_classify_host (the reference's reader task
+ * would fill its chunk buffers here, core.jl:43-110).  With pinned buffers the host <-> device copies are
+ * asynchronous DMA at PCIe speed; ordinary (pageable) memory works too, just slower.  NULL on failure. */
+void *bdx_host_alloc(size_t bytes);
+void bdx_host_free(void *p);
+
 /* Introspection for bench/tests: name of the kernel path a classify call will take, and numbers of the
  * last launch.  "generic": exact kernel only; "bitpar+verify": bit-vector sweep of every pair, then the exact
  * stage; "qgram+bitpar+verify": single-piece q-gram seeds in front of the sweep; "qgram2+bitpar+verify":
