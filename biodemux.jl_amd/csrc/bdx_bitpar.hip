@@ -1046,12 +1046,15 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
 
 template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one flag per device of this process (contexts may live on several GPUs)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     // persistent grid: enough workgroups to fill every CU at the LDS-limited residency,
     // never more than there are tiles
