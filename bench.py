@@ -168,6 +168,7 @@ def main():
     # rocprofv3 --pmc summary of this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # x2 correction on FETCH_SIZE — MI355X_MICROARCH.md §HBM), produced by tools/summarize_prof.py.
     traffic, traffic_src = None, None
+    valu = None  # from the same committed profile: what actually bounds the kernel
     try:
         prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_final_pmc.json"))
         if prof and n == 10_000_000 and path.startswith("qgram"):
@@ -176,6 +177,13 @@ def main():
                 if "bitpar" in kname and "hbm_read_bytes_corrected" in e:
                     traffic = e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
                     traffic_src = f"profiles/{prof[-1]} ({kname})"
+                    c = e.get("counters_per_dispatch", {})
+                    if c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
+                        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES cycles
+                        # summed over the 32 shader engines
+                        valu = {"valu_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["SQ_BUSY_CYCLES"] / 32), 3),
+                                "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
+                                "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
     except Exception:
         pass
 
@@ -197,6 +205,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
                          "kernel_ms_avg": kern_ms_avg, "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
+                         "valu": valu,
                          "note": "integer-VALU / latency bound path (SURVEY F6); HBM fraction reported as asked"},
             "cpu_baseline": cpu,
         }
