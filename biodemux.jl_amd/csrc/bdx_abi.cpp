@@ -323,11 +323,11 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
     // two-intact-pieces variant, which is tried next (measured at kb = 3: 7.5 ms vs 5.7 ms per 2 M reads).
     if (strict && expected > 7.0) return BDX_OK;
     sp.q = q;
-    // hashed bitmap with >= 48 bits per key (<= ~2 % false hits per position), at most the key space
+    // hashed bitmap with >= 96 bits per key (<= ~1 % false hits per position), at most the key space
     // itself (then it is exact).  Too many false hits overflow the hit queue, and an overflow costs a
     // whole-read sweep of every barcode.
     sp.bm_log2 = 5;
-    while ((1u << sp.bm_log2) < pieces.size() * 48 && sp.bm_log2 < 2 * q) sp.bm_log2++;
+    while ((1u << sp.bm_log2) < pieces.size() * 96 && sp.bm_log2 < 2 * q) sp.bm_log2++;
     // sweep records per read: the true barcode(s) plus the expected falsely seeded ones, generously
     {
         const double false_pairs = 150.0 * (double)pieces.size() / space;

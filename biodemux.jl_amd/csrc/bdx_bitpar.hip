@@ -206,10 +206,14 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     __syncthreads();
     const long long tile = sqn[2];
     if (tile >= ntiles) break;
+    // Phases with fewer items than lanes (per-read setup, hit resolve, sweeps, reducer replay) would always land
+    // on the first waves — and with them on the same SIMDs of the CU.  The lane numbering of those phases is
+    // rotated by one wave per tile, so that over a workgroup's tiles all four SIMDs carry them.
+    const int ltid = (tid + (((int)tile & (BS / 64 - 1)) << 6)) & (BS - 1);
     for (int i = tid; i < R * (cw0 + cw1); i += BS) cand[i] = 0;
     for (int i = tid; i < 2 * R; i += BS) scnt[i] = 0;
     if (SEED) {
-        for (int i = tid; i < R; i += BS) sall[i] = 0;
+        for (int i = ltid; i < R; i += BS) sall[i] = 0;  // (same lane as the per-read setup below, which may set it)
         if (HASH)
             for (int i = tid; i < R * RCAP; i += BS) {
                 srid[i] = 0u;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         for (int k = tid; k < nvec; k += BS) dst[k] = __builtin_nontemporal_load(src + k);
     }
     // per-read lengths, stage offsets and column windows of both passes
-    for (int t = tid; t < nr; t += BS) {
+    for (int t = ltid; t < nr; t += BS) {
         const long long ro = a.off[r0 + t];
         const long long rn = a.off[r0 + t + 1] - ro;
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             {
                 const int nh = (a.dbg & 4) ? 0 : (sqn[0] < SQCAP ? sqn[0] : SQCAP);
                 const uint32_t hmask = (1u << a.seed_hash_log2) - 1u;
-                for (int k = tid; k < nh; k += BS) {
+                for (int k = ltid; k < nh; k += BS) {
                     const uint32_t h = shq[k];
                     const int t = shr[k];
                     const int prel = (int)(h >> 16);
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             __syncthreads();
             {
                 const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
-                for (int k = tid; k < np; k += 2 * BS) {
+                for (int k = ltid; k < np; k += 2 * BS) {
                     Sweep A, Bw;
                     const uint32_t ea = spq[k], wa = spw[k];
                     const bool hb = k + BS < np;
@@ -959,28 +963,28 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     // (DESIGN.md §3.1).  The other reads — more survivors, a range that binds, or a tile that did not
     // fit the staging area — are handed to the exact kernel through a list in HBM together with
     // their candidate masks; this kernel holds no DP state at all. ----
-    const bool active = tid < nr;
-    const long long ridx = r0 + tid;
+    const bool active = ltid < nr;
+    const long long ridx = r0 + ltid;
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     bool done = false;
     if (active && !(a.dbg & 1)) {
-        const int cnt0 = scnt[0 * R + tid], cnt1 = scnt[1 * R + tid];
-        bool known = staged && full[0 * R + tid] && cnt0 <= 4;
-        if (npass > 1) known = known && full[1 * R + tid] && cnt1 <= 4;
+        const int cnt0 = scnt[0 * R + ltid], cnt1 = scnt[1 * R + ltid];
+        bool known = staged && full[0 * R + ltid] && cnt0 <= 4;
+        if (npass > 1) known = known && full[1 * R + ltid] && cnt1 <= 4;
         if (known) {
-            const LDS uint32_t *e0 = slots + (0 * R + tid) * 4;
-            const LDS uint32_t *e1 = slots + (1 * R + tid) * 4;
+            const LDS uint32_t *e0 = slots + (0 * R + ltid) * 4;
+            const LDS uint32_t *e1 = slots + (1 * R + ltid) * 4;
             const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt0};
             const KnownPass kn1{true, e1[0], e1[1], e1[2], e1[3], cnt1};
             const auto m0 = [&](const int b) { return (int)__builtin_popcount(pv0[b]); };
             const auto m1 = [&](const int b) { return (int)__builtin_popcount(pv1[b]); };
-            classify_known(cfg, m0, m1, rlen[tid], kn0, kn1, v, p1, p2);
+            classify_known(cfg, m0, m1, rlen[ltid], kn0, kn1, v, p1, p2);
             done = true;
         } else {
             for (int p = 0; p < npass; ++p) {
                 const int cw = p ? cw1 : cw0;
-                const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0) + tid * cw;
+                const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0) + ltid * cw;
                 uint32_t *dst = (p ? a.cand_out[1] : a.cand_out[0]) + ridx * cw;
                 for (int w = 0; w < cw; ++w) dst[w] = staged ? cnd[w] : 0xFFFFFFFFu;
             }
