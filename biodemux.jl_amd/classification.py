@@ -49,8 +49,8 @@ def _rng(r) -> Tuple[int, int]:
 _FULL = DynamicRange(1, False, 0, True)
 
 
-def _one(cfg: DemuxConfig, seq: str, window, device: int = 0):
-    with HipClassifier(cfg, device=device, want_pass=True, windows={0: window}, filter="off") as hc:
+def _one(cfg: DemuxConfig, seq: str, window, device: int = 0, filter: str = "auto"):
+    with HipClassifier(cfg, device=device, want_pass=True, windows={0: window}, filter=filter) as hc:
         blob, off = pack_reads([seq])
         return hc.classify(blob, off)
 
@@ -65,11 +65,11 @@ def _align_cfg(query: str, max_error: float, match: int, mismatch: int, indel: i
 
 def semiglobal_alignment(ws, query: str, ref: str, max_error: float, match: int, mismatch: int, indel: int,
                          ref_search_range, max_start_pos: int, min_end_pos: int, trim_side: Optional[int] = None,
-                         need_traceback: bool = False, *, device: int = 0):
+                         need_traceback: bool = False, *, device: int = 0, filter: str = "auto"):
     """classification.jl:447-461.  Returns a float (ScoreOnly) or ``(score, start, end)``."""
     cfg = _align_cfg(query, max_error, match, mismatch, indel, None, None, trim_side, need_traceback, "semiglobal")
     a, b = _rng(ref_search_range)
-    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device)
+    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device, filter)
     score = float(out["pass_score"][0, 0])
     if trim_side is None and not need_traceback:
         return score
@@ -78,12 +78,13 @@ def semiglobal_alignment(ws, query: str, ref: str, max_error: float, match: int,
 
 def semiglobal_alignment_N(ws, query: str, ref: str, max_error: float, match: int, mismatch: int, indel: int,
                            nindel: int, ref_search_range, max_start_pos: int, min_end_pos: int, non_N_m: int,
-                           trim_side: Optional[int] = None, need_traceback: bool = False, *, device: int = 0):
+                           trim_side: Optional[int] = None, need_traceback: bool = False, *, device: int = 0,
+                           filter: str = "auto"):
     """classification.jl:463-477."""
     cfg = _align_cfg(query, max_error, match, mismatch, indel, nindel, non_N_m, trim_side, need_traceback,
                      "semiglobal")
     a, b = _rng(ref_search_range)
-    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device)
+    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device, filter)
     score = float(out["pass_score"][0, 0])
     if trim_side is None and not need_traceback:
         return score
@@ -91,26 +92,26 @@ def semiglobal_alignment_N(ws, query: str, ref: str, max_error: float, match: in
 
 
 def exact_align(query: str, ref: str, ref_search_range, max_start_pos: int, min_end_pos: int,
-                trim_side: Optional[int], *, device: int = 0):
+                trim_side: Optional[int], *, device: int = 0, filter: str = "auto"):
     """classification.jl:485-548.  ``(0.0, s, e)`` or ``(Inf, -1, -1)``."""
     cfg = _align_cfg(query, 0.0, 0, 1, 1, None, None, trim_side, False, "exact")
     a, b = _rng(ref_search_range)
-    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device)
+    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device, filter)
     return (float(out["pass_score"][0, 0]), int(out["pass_start"][0, 0]), int(out["pass_end"][0, 0]))
 
 
 def hamming_align(query: str, ref: str, max_error_rate: float, ref_search_range, max_start_pos: int,
-                  min_end_pos: int, trim_side: Optional[int], *, device: int = 0):
+                  min_end_pos: int, trim_side: Optional[int], *, device: int = 0, filter: str = "auto"):
     """classification.jl:557-625."""
     cfg = _align_cfg(query, max_error_rate, 0, 1, 1, None, None, trim_side, False, "hamming")
     a, b = _rng(ref_search_range)
-    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device)
+    out = _one(cfg, ref, (a, b, max_start_pos, min_end_pos, 2), device, filter)
     return (float(out["pass_score"][0, 0]), int(out["pass_start"][0, 0]), int(out["pass_end"][0, 0]))
 
 
 def find_best_matching_bc(seq: str, bc_seqs: List[str], bc_lengths_no_N: List[int], config: DemuxConfig, ws,
                           ref_search_range, max_start_pos: int, min_end_pos: int, trim_side: Optional[int],
-                          need_traceback: bool = False, *, device: int = 0):
+                          need_traceback: bool = False, *, device: int = 0, filter: str = "auto"):
     """classification.jl:722-728.  Returns ``(min_score_bc, min_score, delta, best_start, best_end)``."""
     import copy
 
@@ -122,7 +123,7 @@ def find_best_matching_bc(seq: str, bc_seqs: List[str], bc_lengths_no_N: List[in
     # need_tb = trim_side !== nothing || stats !== nothing (:812); here it is given directly
     cfg.summary = bool(need_traceback)
     a, b = _rng(ref_search_range)
-    out = _one(cfg, seq, (a, b, max_start_pos, min_end_pos, 1), device)
+    out = _one(cfg, seq, (a, b, max_start_pos, min_end_pos, 1), device, filter)
     return (int(out["pass_bc"][0, 0]), float(out["pass_score"][0, 0]), float(out["pass_delta"][0, 0]),
             int(out["pass_start"][0, 0]), int(out["pass_end"][0, 0]))
 
@@ -139,9 +140,9 @@ def filename_for(config: DemuxConfig, bc1: int, bc2: int) -> str:
     return str(config.ids[bc1 - 1]) + suffix
 
 
-def determine_filename(seq: str, config: DemuxConfig, ws=None, *, device: int = 0):
+def determine_filename(seq: str, config: DemuxConfig, ws=None, *, device: int = 0, filter: str = "auto"):
     """classification.jl:871-938.  Returns ``(filename, keep_start, keep_end)``."""
-    with HipClassifier(config, device=device) as hc:
+    with HipClassifier(config, device=device, filter=filter) as hc:
         blob, off = pack_reads([seq])
         out = hc.classify(blob, off)
     bc1, bc2 = int(out["bc1"][0]), int(out["bc2"][0])

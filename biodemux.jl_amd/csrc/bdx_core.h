@@ -605,6 +605,12 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 // unit-cost semi-global distance delivered by the bit-vector sweep.  `entries` holds up to four
 // (barcode << 8 | d) words of this read in arbitrary order; they are replayed in ascending
 // barcode (= file) order through the very same reducer.
+// The reference evaluates every barcode ONCE over the whole window (:638, :676).  The seeded variants
+// may sweep one (read, barcode) pair over several column windows (one per cluster of seed diagonals:
+// a barcode that occurs twice in a read, or overlapping clusters around one occurrence) and so push
+// several entries of one barcode; each is the minimum over its window, the window holding the best
+// occurrence delivers the whole-window minimum d*, so the barcode's value is the SMALLEST of its
+// entries.  Ascending (barcode << 8 | d) order visits that one first; the others are skipped.
 template <class MLen>
 __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const MLen mlen,
                                                   const uint32_t e0, const uint32_t e1, const uint32_t e2,
@@ -612,6 +618,7 @@ __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const ML
     Reducer red;
     red.init(cfg);
     uint32_t last = 0;  // entries are > 0 only if barcode > 0 or d > 0; use +1 bias below
+    int fed_b = -1;     // barcode of the entry fed last
     for (int k = 0; k < count; ++k) {
         // smallest biased entry greater than `last` (static scan: no dynamic register indexing)
         uint32_t pick = 0xFFFFFFFFu;
@@ -620,10 +627,13 @@ __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const ML
         if (count > 1 && c1 > last && c1 < pick) pick = c1;
         if (count > 2 && c2 > last && c2 < pick) pick = c2;
         if (count > 3 && c3 > last && c3 < pick) pick = c3;
+        if (pick == 0xFFFFFFFFu) break;  // equal duplicates: fewer distinct entries than `count`
         last = pick;
         const uint32_t e = pick - 1u;
         const int b = (int)(e >> 8);
         const int d = (int)(e & 255u);
+        if (b == fed_b) continue;  // a larger entry of the barcode just fed (another window of the same pair)
+        fed_b = b;
         const int m = mlen(b);  // barcode length
         const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
         AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};

@@ -98,9 +98,11 @@ def random_case_many_barcodes(seed: int, n_reads: int = 1500):
     cfg = H.bdx.DemuxConfig(**kw)
     max_len = int([100, 150, 150, 152, 151, 200][int(rng.integers(0, 6))])
     second = (bcs2, max_len // 2, None) if dual else None
+    # every third seed: half of the reads are concatemers (the same barcode twice, two barcodes, shifted copies)
+    repeat = dict(frac=0.5) if seed % 3 == 2 else None
     seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 2 if rng.random() < 0.5 else max_len, max_len, seed=seed,
                                           plant_frac=0.85, sub=0.05, ins=0.02, dele=0.02, n_rate=0.003,
-                                          plant_hi=(max_len // 3 if dual else None), second=second)
+                                          plant_hi=(max_len // 3 if dual else None), second=second, repeat=repeat)
     return cfg, seq, off
 
 

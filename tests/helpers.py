@@ -47,10 +47,12 @@ def oracle_factory(cfg):
     return orc.OracleClassifier(cfg, nthreads=1, want_pass=bool(cfg.summary))
 
 
-def run_kat(vec, api: str):
-    """Evaluate one KAT with ``api`` in {"oracle", "hip"}; returns (got, expect)."""
+def run_kat(vec, api: str, filter: str = "auto"):
+    """Evaluate one KAT with ``api`` in {"oracle", "hip"}; returns (got, expect).  ``filter`` (hip only)
+    selects the kernel path in front of the exact evaluation: every value must give the same answer."""
     fn, args, expect = vec["fn"], [_dec(a) for a in vec["args"]], _dec(vec["expect"])
     hip = api == "hip"
+    fk = dict(filter=filter) if hip else {}
     if fn == "parse_dynamic_range":
         dr = bdx.parse_dynamic_range(args[0])
         return [dr.start_offset, dr.start_from_end, dr.end_offset, dr.end_from_end], expect
@@ -61,26 +63,26 @@ def run_kat(vec, api: str):
         ts = args[9] if len(args) > 9 else None
         tb = args[10] if len(args) > 10 else False
         if hip:
-            got = bdx.semiglobal_alignment(None, q, r, me, ma, mi, ind, tuple(rng), ms, mn, ts, tb)
+            got = bdx.semiglobal_alignment(None, q, r, me, ma, mi, ind, tuple(rng), ms, mn, ts, tb, **fk)
         else:
             got = orc.semiglobal_alignment(q, r, me, ma, mi, ind, tuple(rng), ms, mn, ts, tb)
     elif fn == "semiglobal_alignment_N":
         q, r, me, ma, mi, ind, nind, rng, ms, mn, nn = args[:11]
         if hip:
-            got = bdx.semiglobal_alignment_N(None, q, r, me, ma, mi, ind, nind, tuple(rng), ms, mn, nn)
+            got = bdx.semiglobal_alignment_N(None, q, r, me, ma, mi, ind, nind, tuple(rng), ms, mn, nn, **fk)
         else:
             got = orc.semiglobal_alignment_N(q, r, me, ma, mi, ind, nind, tuple(rng), ms, mn, nn)
     elif fn == "hamming_align":
         q, r, me, rng, ms, mn, ts = args
-        got = (bdx.hamming_align if hip else orc.hamming_align)(q, r, me, tuple(rng), ms, mn, ts)
+        got = (bdx.hamming_align if hip else orc.hamming_align)(q, r, me, tuple(rng), ms, mn, ts, **fk)
     elif fn == "exact_align":
         q, r, rng, ms, mn, ts = args
-        got = (bdx.exact_align if hip else orc.exact_align)(q, r, tuple(rng), ms, mn, ts)
+        got = (bdx.exact_align if hip else orc.exact_align)(q, r, tuple(rng), ms, mn, ts, **fk)
     elif fn == "determine_filename":
         read, over = args
         cfg = make_config(over)
         if hip:
-            got = bdx.determine_filename(read, cfg)
+            got = bdx.determine_filename(read, cfg, **fk)
         else:
             v = orc.determine_filename(read, cfg)
             got = (bdx.filename_for(cfg, v.bc1, v.bc2), v.keep_start, v.keep_end)

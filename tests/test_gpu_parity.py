@@ -26,10 +26,12 @@ def _need_gpu():
 
 
 # ---- the reference's unit tests, through the kernel ----
+@pytest.mark.parametrize("flt", ["off", "auto"])
 @pytest.mark.parametrize("vec", KAT, ids=[f"{v['fn']}@{v['src']}" for v in KAT])
-def test_kat_hip(vec):
-    got, expect = H.run_kat(vec, "hip")
-    assert got == expect, vec["src"]
+def test_kat_hip(vec, flt):
+    """filter="off": the exact kernel alone; "auto" (the product default): the fused filter kernel in front."""
+    got, expect = H.run_kat(vec, "hip", filter=flt)
+    assert got == expect, (vec["src"], flt)
 
 
 # ---- the reference's integration tests + golden files, through the kernel ----
@@ -66,6 +68,21 @@ def test_fuzz_vs_oracle(seed):
             got = hc.classify(seq, off)
             fuzz.assert_same(got, exp, f"seed {seed} filter {flt} [{hc.kernel_path}]")
             assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+
+
+# ---- the seeded variants' domain (48..160 barcodes of 20..32 nt, rates 0.1..0.25): single-piece seeds,
+# two intact pieces, plain sweep; every third seed turns half of the reads into concatemers ----
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_many_barcodes_vs_oracle(seed):
+    cfg, seq, off = fuzz.random_case_many_barcodes(seed, n_reads=1500)
+    for want_pass in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want_pass)
+        exp = oc.classify(seq, off)
+        for flt in (("off", "auto") if want_pass else ("auto",)):
+            with H.bdx.HipClassifier(cfg, want_pass=want_pass, filter=flt) as hc:
+                got = hc.classify(seq, off)
+                fuzz.assert_same(got, exp, f"seed {seed} filter {flt} pass outputs {want_pass} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
 
 
 def _c2_config(bcs, **kw):
@@ -320,6 +337,35 @@ def test_diag_c2_shape(kw):
     expect = None if "mismatch" in kw else DIAG
     exp = _all_filters_agree(_c2_config(bcs, **kw), seq, off, expect_path=expect)
     assert (exp["bc1"] > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("rate", [0.2, 0.17])
+@pytest.mark.parametrize("min_delta", [0.0, 0.05, 0.1])
+def test_diag_same_barcode_planted_twice(rate, min_delta):
+    """Concatemer / chimeric reads: the same barcode twice (1 vs 2, 0 vs 3, 0 vs 0 edits, >= 2 kb + 3 columns
+    apart), two different barcodes in one read, a barcode and an overlapping shifted copy.  The diagonal variant
+    sweeps one window per cluster of seed diagonals, so one (read, barcode) pair may deliver several unit
+    distances; the reference evaluates every barcode once (classification.jl:676-711) — the reducer replay
+    must see one entry per barcode (its minimum), else the second copy becomes sub_min and a clean match
+    turns ambiguous."""
+    bcs = synth.make_barcodes(96, 24, seed=41)
+    seq, off, _ = synth.make_reads(bcs, 12000, 150, seed=43, repeat=dict(frac=0.7))
+    cfg = _c2_config(bcs, max_error_rate=rate, min_delta=min_delta)
+    exp = _all_filters_agree(cfg, seq, off, expect_path=DIAG)
+    assert (exp["bc1"] > 0).mean() > 0.4
+    if min_delta > 0:
+        # the case is not vacuous: reads with the same barcode twice are matches with delta = Inf in the reference
+        assert np.isinf(exp["pass_delta"][:, 0][exp["bc1"] > 0]).mean() > 0.3
+
+
+def test_diag_repeats_ragged_trim_and_hamming():
+    """The same concatemer reads through the split path (trimming: windows of one barcode are united) and
+    :hamming, on ragged reads."""
+    bcs = synth.make_barcodes(80, 24, seed=51)
+    seq, off, _ = synth.make_ragged_reads(bcs, 9000, 60, 152, seed=52, repeat=dict(frac=0.6, other=0.4))
+    for kw in (dict(max_error_rate=0.2, trim_side=3, min_delta=0.05), dict(max_error_rate=0.2, trim_side=5),
+               dict(max_error_rate=0.2, matching_algorithm="hamming", min_delta=0.05), dict(min_delta=0.1)):
+        _all_filters_agree(_c2_config(bcs, **kw), seq, off)
 
 
 def test_diag_variable_lengths_and_dual():
