@@ -12,71 +12,11 @@
 #include <string>
 #include <vector>
 
-#include "bdx_internal.h"
-
-namespace {
+#include "bdx_ctx.h"
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap && p) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes < 256 ? 256 : bytes;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-}  // namespace
-
-struct bdx_ctx {
-    bdx_config_t cfg{};
-    BdxDevCfg dev{};
-    BdxGenericPlan plan{};
-    BdxBitparPlan bplan{};
-    BdxSeedPlan splan{};
-    DevBuf seed_tables;
-    // weak single seeds kept beside a two-intact-pieces plan: taken when the latter's index does not fit the
-    // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
-    BdxSeedPlan splan_alt{};
-    DevBuf seed_tables_alt;
-    DevBuf bp_tables;
-    DevBuf d_maxlen;
-    int user_len_hint = 0;  // 0 = measure every device batch
-    int filter_used = BDX_FILTER_OFF;
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // device tables
-    DevBuf bc_bytes[2], bc_off[2], bc_nn[2];
-    DevBuf counts_own;
-    unsigned long long *counts = nullptr;
-    // staging for the host entry point
-    DevBuf d_seq, d_off, d_out_i32, d_out_f64;
-    // candidate masks (filtered paths)
-    DevBuf d_cand[2];
-    DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel
-    DevBuf d_exc;                 // known-score mode: reads handed over to the exact kernel
-    std::string err;
-    std::string path;
-    int64_t launches = 0;
-    int64_t last_blocks = 0;
-};
-
-namespace {
-
-int fail(bdx_ctx *ctx, int code, const char *fmt, ...) {
+int bdx_fail(bdx_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -89,12 +29,26 @@ int fail(bdx_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(ctx, call)                                                                      \
-    do {                                                                                        \
-        hipError_t e__ = (call);                                                                \
-        if (e__ != hipSuccess)                                                                  \
-            return fail(ctx, BDX_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__));     \
-    } while (0)
+namespace {
+
+#define fail bdx_fail
+
+BdxTuning read_tuning() {
+    BdxTuning t;
+    t.no_known = getenv("BDX_NO_KNOWN") != nullptr;
+    t.no_seed = getenv("BDX_NO_SEED") != nullptr;
+    t.no_diag = getenv("BDX_NO_DIAG") != nullptr;
+    t.no_windows = getenv("BDX_NO_WINDOWS") != nullptr;
+    t.no_slot = getenv("BDX_NO_SLOT") != nullptr;
+    t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
+    if (const char *e = getenv("BDX_BITPAR_R")) t.bitpar_r = atoi(e);
+    if (const char *e = getenv("BDX_GRID")) t.grid = atoll(e);
+    if (const char *e = getenv("BDX_DIAG_MIN_B")) t.diag_min_b = atoi(e);
+#ifdef BDX_TUNING
+    if (const char *e = getenv("BDX_DEBUG")) t.debug = atoi(e);
+#endif
+    return t;
+}
 
 BdxDevRange cvt_range(const bdx_range_t &r) {
     BdxDevRange d;
@@ -248,7 +202,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         const bool score_only = c.pass[k].trim_side == 0 && !c.need_traceback;
         bp.known_ok[k] = c.algorithm == BDX_ALG_SEMIGLOBAL && !c.has_nindel && c.match == 0 && c.mismatch == 1 &&
                          c.indel == 1 && score_only && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE &&
-                         !getenv("BDX_NO_KNOWN");
+                         !ctx->tune.no_known;
     }
     bp.enabled = 1;
     return BDX_OK;
@@ -266,7 +220,7 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
     BdxSeedPlan &sp = alt ? ctx->splan_alt : ctx->splan;
     DevBuf &tables = alt ? ctx->seed_tables_alt : ctx->seed_tables;
     sp = BdxSeedPlan{};
-    if (!ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || getenv("BDX_NO_SEED")) return BDX_OK;
+    if (!ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed) return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;
     if (c.algorithm == BDX_ALG_SEMIGLOBAL) {
@@ -395,7 +349,7 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
 int build_diag_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
     BdxSeedPlan &sp = ctx->splan;
-    if (sp.enabled || !ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || getenv("BDX_NO_SEED") || getenv("BDX_NO_DIAG"))
+    if (sp.enabled || !ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag)
         return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;
@@ -463,9 +417,7 @@ int build_diag_tables(bdx_ctx *ctx) {
     // as much as sweeping ~40 barcodes over a whole 150-base read (measured: 1.44 us/read + 0.017 us/pair
     // against 0.054 us/pair of the plain sweep)
     {
-        int min_b = 48;
-        if (const char *e = getenv("BDX_DIAG_MIN_B")) min_b = atoi(e);  // tuning experiments
-        if (total_bc < min_b) return BDX_OK;
+        if (total_bc < ctx->tune.diag_min_b) return BDX_OK;  // 48 unless overridden for tuning experiments
     }
     const double coef_keep = flag_coef;
     size_t bytes = 0;
@@ -515,8 +467,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     while (r_cap > 16 && n_reads / r_cap < 1024) r_cap >>= 1;
     if (bp.read_len_hint == read_len && bp.r_cap == r_cap && bp.reads_per_block > 0) return true;
     bp.r_cap = r_cap;
-    int forced = 0;
-    if (const char *e = getenv("BDX_BITPAR_R")) forced = atoi(e);
+    const int forced = ctx->tune.bitpar_r;
     // Pick the R that keeps the most waves resident per CU (the sweep is latency-bound):
     // workgroups/CU = min(8, floor(160 KiB / LDS(R))) with 4 waves each; ties -> larger R
     // (fewer table reloads).  R = 16 is only taken when nothing larger fits.
@@ -559,7 +510,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         if (uhi > ulo) wmax = (int)(uhi - ulo);
         else wmax = 16;
     }
-    const bool slot_mode = (long long)wmax * 2 + 96 <= (long long)read_len && !getenv("BDX_NO_SLOT");
+    const bool slot_mode = (long long)wmax * 2 + 96 <= (long long)read_len && !ctx->tune.no_slot;
     const int slot = slot_mode ? ((wmax + 15 + 16 + 15) & ~15) : 0;
     bp.slot_bytes = slot;
     bp.seed_span = slot_mode ? wmax : read_len;
@@ -697,7 +648,7 @@ int upload_tables(bdx_ctx *ctx) {
     d.has_nindel = c.has_nindel != 0;
     d.nindel = c.has_nindel ? c.nindel : 0;
     d.need_traceback = c.need_traceback != 0;
-    d.force_lds_dp = getenv("BDX_LDS_DP") ? 1 : 0;
+    d.force_lds_dp = ctx->tune.lds_dp;
     d.max_m = 1;
     d.any_traceback = d.need_traceback;
     const int npass = d.is_dual ? 2 : 1;
@@ -770,6 +721,7 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (!ctx) return fail(nullptr, BDX_E_DEVICE, "out of host memory");
     ctx->cfg = *config;
     ctx->device = config->device;
+    ctx->tune = read_tuning();  // the environment is consulted here and nowhere else
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         bdx_destroy(ctx);
@@ -848,6 +800,8 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->d_off.release();
     ctx->d_out_i32.release();
     ctx->d_out_f64.release();
+    bdx_comm_release(ctx);
+    ctx->counts_sum.release();
     delete ctx;
 }
 
@@ -901,6 +855,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     }
     if (filtered) {
         ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);
+        ctx->bplan.grid_override = ctx->tune.grid;
+        ctx->bplan.dbg = ctx->tune.debug;
         // The fused kernel filters; the exact DP runs at full width in the generic kernel:
         //  * split (trimming / summary / weighted costs / N-scoring / Hamming / exact): every read's
         //    candidate mask (+ column windows) goes through HBM, the generic kernel gives every verdict;
@@ -913,7 +869,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
-        const bool windows = split && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !getenv("BDX_NO_WINDOWS");
+        const bool windows = split && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !ctx->tune.no_windows;
         for (int k = 0; k < npass; ++k) {
             HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
             if (windows) {
@@ -948,14 +904,15 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
                                             nullptr, exc_list, exc_count));
-        if (const char *e = getenv("BDX_DEBUG"))
-            if (atoi(e) & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
+#ifdef BDX_TUNING
+        if (ctx->tune.debug & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
                 unsigned int st[4] = {0, 0, 0, 0};
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 HIP_TRY(ctx, hipMemcpy(st, exc_count, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bdx] handed over %u reads; %u windowed sweeps, %u columns, %u tiles with a fallback read (of %lld reads)\n",
                         st[0], st[1], st[2], st[3], (long long)n_reads);
-            }
+        }
+#endif
         ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
         ctx->path = ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;

@@ -24,6 +24,7 @@
 // dwords: the 64 lanes of a wave hold consecutive barcodes (stride a power of two), so the table read is conflict-free
 // for any code, and lanes of the same read fetch the same symbol byte (LDS broadcast).  Pairs
 // are flattened (pair = read * B + barcode) so lanes stay busy for any B (96 = 1.5 waves).
+#include <atomic>
 #include <cstdlib>
 
 #include "bdx_core.h"
@@ -68,9 +69,17 @@ struct BitparArgs {
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
-    int dbg;  // timing experiments only (env BDX_DEBUG), results are wrong when set: 1 skip stage 2, 2 skip
-              // sweeps, 4 skip hit resolve, 8 skip seed scan, 16 skip 2-bit packing, 32 skip transcode, 64 skip copy
+    int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a
+              // skip bit is set: 1 skip stage 2, 2 skip sweeps, 4 skip hit resolve, 8 skip seed scan, 32 skip
+              // transcode, 64 skip copy; 128 = sweep statistics (results stay correct)
 };
+
+// The product library has no phase-skip switches: BDX_DBG folds to 0 and the branches disappear.
+#ifdef BDX_TUNING
+#define BDX_DBG(bit) (a.dbg & (bit))
+#else
+#define BDX_DBG(bit) 0
+#endif
 
 // The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
 // VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const int head = (int)(g0 - g0a);
     const long long need = slot ? (long long)nr * slot : (span1 - span0) + head;
     bool staged = slot ? true : (need + 16 <= (long long)a.stage_bytes);  // wave-uniform (whole workgroup)
-    if (!slot && staged && !(a.dbg & 64)) {
+    if (!slot && staged && !BDX_DBG(64)) {
         const int nvec = (int)((need + 15) >> 4);
         const GlobalVec16 src = (GlobalVec16)g0a;
         LDS u32x4 *dst = (LDS u32x4 *)rstage;
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         // ---- transcode bytes -> symbol codes (4 per lane per step); the seeded variant also packs the
         // same four symbols to 2 bits each: one byte of the flat 2-bit image of the whole staging area
         // (packed byte k holds staged bytes 4k .. 4k+3, whatever read they belong to) ----
-        const int nvec4 = (a.dbg & 32) ? 0 : (int)((need + 3) >> 2);
+        const int nvec4 = BDX_DBG(32) ? 0 : (int)((need + 3) >> 2);
         for (int k = tid; k < nvec4; k += BS) {
             const uint32_t w = ((LDS uint32_t *)rstage)[k];
             const uint32_t c = (uint32_t)lut[w & 255] | ((uint32_t)lut[(w >> 8) & 255] << 8) |
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         if (!SEED) {
             for (int p = 0; p < npass; ++p) {
                 const int B = p ? B1 : B0;
-                const int total = (a.dbg & 2) ? 0 : nr * B;
+                const int total = BDX_DBG(2) ? 0 : nr * B;
                 for (int pair = tid; pair < total; pair += 2 * BS) {
                     Sweep A, Bw;
                     const int pb = pair + BS;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int lane = tid & 63;
                 const int dr = BS / G, dg = BS - dr * G;
                 int r = tid / G, g = tid - r * G;
-                const int total_items = (a.dbg & 8) ? 0 : nr * G;
+                const int total_items = BDX_DBG(8) ? 0 : nr * G;
                 const int bml = a.seed_bm_log2;
                 const uint32_t bmmask = (1u << bml) - 1u;
                 const bool bm_direct = bml >= 2 * q;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // resolve: one lane per hit probes the hash table; every (pass, barcode) it finds is merged
             // into the read's small record table (CAS on the id, atomic min/max on the window)
             {
-                const int nh = (a.dbg & 4) ? 0 : (sqn[0] < SQCAP ? sqn[0] : SQCAP);
+                const int nh = BDX_DBG(4) ? 0 : (sqn[0] < SQCAP ? sqn[0] : SQCAP);
                 const uint32_t hmask = (1u << a.seed_hash_log2) - 1u;
                 for (int k = ltid; k < nh; k += BS) {
                     const uint32_t h = shq[k];
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int G = a.seed_groups;
                 const int dr = BS / G, dg = BS - dr * G;
                 int rl = tid / G, g = tid - rl * G;  // rl: read within the sub-batch
-                const int total_items = (a.dbg & 8) ? 0 : rbn * G;
+                const int total_items = BDX_DBG(8) ? 0 : rbn * G;
                 const LDS uint32_t *spk32 = (const LDS uint32_t *)spk;
                 for (int idx = tid; idx < total_items; idx += BS, rl += dr, g += dg, rl += (g >= G), g -= (g >= G) ? G : 0) {
                     const int r = rb0 + rl;
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int B = p ? B1 : B0;
                 const LDS uint32_t *dm = p ? dm1 : dm0;
                 const LDS uint32_t *dk = p ? dk1 : dk0;
-                const int total = (a.dbg & 4) ? 0 : rbn * B;
+                const int total = BDX_DBG(4) ? 0 : rbn * B;
                 for (int pair0 = 0; pair0 < total; pair0 += BS) {
                     const int pair = pair0 + tid;
                     const bool in = pair < total;
@@ -841,7 +850,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             }
             __syncthreads();
             {
-                const int np = (a.dbg & 2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
+                const int np = BDX_DBG(2) ? 0 : (sqn[1] < PQCAP ? sqn[1] : PQCAP);
                 for (int k = ltid; k < np; k += 2 * BS) {
                     Sweep A, Bw;
                     const uint32_t ea = spq[k], wa = spw[k];
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     const int ra = (int)(ea >> 16), rb = (int)(eb >> 16);
                     setup(!sall[ra], (int)((ea >> 15) & 1u), ra, (int)(ea & 0x7FFFu) - 1, A, (int)(wa >> 16), (int)(wa & 0xFFFFu));
                     setup(hb && !sall[rb], (int)((eb >> 15) & 1u), rb, (int)(eb & 0x7FFFu) - 1, Bw, (int)(wb >> 16), (int)(wb & 0xFFFFu));
-                    if (a.dbg & 128) {  // statistics for tuning (results stay correct): sweeps and swept columns
+                    if (BDX_DBG(128)) {  // statistics for tuning (results stay correct): sweeps and swept columns
                         atomicAdd(a.exc_count + 1, 1u + (hb ? 1u : 0u));
                         atomicAdd(a.exc_count + 2, (unsigned)(A.ncol + Bw.ncol));
                     }
@@ -860,12 +869,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             }  // sub-batches
             if (DIAG) __syncthreads();  // orders the last sub-batch's flag writes before the read below
             const int any_sall = sqn[5];  // does any read of this tile need the whole-read fallback below?
-            if ((a.dbg & 128) && tid == 0 && any_sall) atomicAdd(a.exc_count + 3, 1u);
+            if (BDX_DBG(128) && tid == 0 && any_sall) atomicAdd(a.exc_count + 3, 1u);
             {
                 // reads whose lists overflowed: every barcode over the whole window, exactly once
                 for (int p = 0; p < npass; ++p) {
                     const int B = p ? B1 : B0;
-                    const int total = ((a.dbg & 2) || !any_sall) ? 0 : nr * B;
+                    const int total = (BDX_DBG(2) || !any_sall) ? 0 : nr * B;
                     for (int pair = tid; pair < total; pair += 2 * BS) {
                         Sweep A, Bw;
                         const int pb = pair + BS;
@@ -968,7 +977,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     bool done = false;
-    if (active && !(a.dbg & 1)) {
+    if (active && !BDX_DBG(1)) {
         const int cnt0 = scnt[0 * R + ltid], cnt1 = scnt[1 * R + ltid];
         bool known = staged && full[0 * R + ltid] && cnt0 <= 4;
         if (npass > 1) known = known && full[1 * R + ltid] && cnt1 <= 4;
@@ -1049,16 +1058,17 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
 }
 
 template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5>
-hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream) {
-    // the attribute is per device: one flag per device of this process (contexts may live on several GPUs)
-    static bool attr_set[64] = {};
+hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream, long long grid_override) {
+    // the attribute is per device: one flag per device of this process.  Contexts of several OS threads may
+    // launch concurrently: setting the attribute twice is harmless, the flag itself must not be a data race.
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (dev < 0 || !attr_set[dev]) {
+    if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0) attr_set[dev] = true;
+        if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
     // persistent grid: enough workgroups to fill every CU at the LDS-limited residency,
     // never more than there are tiles
@@ -1067,7 +1077,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     long long blocks = 256 * per_cu;  // exactly the resident set; the tile queue balances it
-    if (const char *e = getenv("BDX_GRID")) blocks = atoll(e);
+    if (grid_override > 0) blocks = grid_override;
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
@@ -1131,7 +1141,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
         while ((4 << (a.bshift[k] - 2)) < bp.bpad[k] * 4) a.bshift[k]++;
     }
     a.ncodes = bp.ncodes;
-    a.dbg = 0;
+    a.dbg = bp.dbg;
     a.slot_bytes = bp.slot_bytes;
     a.ncode = bp.ncode_N;
     a.split = split;
@@ -1146,7 +1156,6 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.tile_counter = bp.d_tile_counter;
     a.known_ok[0] = bp.known_ok[0];
     a.known_ok[1] = bp.known_ok[1];
-    if (const char *e = getenv("BDX_DEBUG")) a.dbg = atoi(e);
     a.seed_q = sp.q;
     a.seed_groups = (bp.seed_span + 15 + 15) / 16;  // 16-base groups of the flat image that can overlap one read
     a.seed_hash_log2 = sp.hash_log2;
@@ -1170,7 +1179,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp, &sp);
     const bool seed = sp.enabled != 0;
     if (seed && sp.diag) {
-#define BDX_LAUNCH_D(RR) return bp.diag_nw > 5 ? launch_one<256, RR, true, true, 10>(a, lds, n_reads, stream) : launch_one<256, RR, true, true, 5>(a, lds, n_reads, stream)
+#define BDX_LAUNCH_D(RR) return bp.diag_nw > 5 ? launch_one<256, RR, true, true, 10>(a, lds, n_reads, stream, bp.grid_override) : launch_one<256, RR, true, true, 5>(a, lds, n_reads, stream, bp.grid_override)
         switch (bp.reads_per_block) {
             case 32:
                 BDX_LAUNCH_D(32);
@@ -1185,7 +1194,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
         }
 #undef BDX_LAUNCH_D
     }
-#define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream) : launch_one<256, RR, false>(a, lds, n_reads, stream)
+#define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override) : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override)
     switch (bp.reads_per_block) {
         case 256:
             BDX_LAUNCH_R(256);

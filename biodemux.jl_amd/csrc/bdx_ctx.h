@@ -1,0 +1,93 @@
+// bdx_ctx.h — the context object behind the C-ABI (private; shared by bdx_abi.cpp and bdx_comm.cpp).
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "bdx_internal.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Developer switches.  Read from the environment ONCE, in bdx_create; none of them
+// changes a result — they only select between kernel paths that must agree (the parity tests run them).
+struct BdxTuning {
+    int no_known = 0;     // BDX_NO_KNOWN: no reducer replay, every config runs split (filter -> exact kernel)
+    int no_seed = 0;      // BDX_NO_SEED: no q-gram seeds at all
+    int no_diag = 0;      // BDX_NO_DIAG: no two-intact-pieces variant
+    int no_windows = 0;   // BDX_NO_WINDOWS: split mode without column windows
+    int no_slot = 0;      // BDX_NO_SLOT: long reads use flat staging instead of window slots
+    int lds_dp = 0;       // BDX_LDS_DP: exact kernel with LDS columns instead of the register DP
+    int bitpar_r = 0;     // BDX_BITPAR_R: forced tile size of the fused kernel
+    long long grid = 0;   // BDX_GRID: forced persistent grid
+    int diag_min_b = 48;  // BDX_DIAG_MIN_B: barcode threshold of the diagonal filter
+    int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
+};
+
+struct bdx_comm_state;  // bdx_comm.cpp
+
+struct bdx_ctx {
+    bdx_config_t cfg{};
+    BdxDevCfg dev{};
+    BdxGenericPlan plan{};
+    BdxBitparPlan bplan{};
+    BdxSeedPlan splan{};
+    BdxTuning tune{};
+    DevBuf seed_tables;
+    // weak single seeds kept beside a two-intact-pieces plan: taken when the latter's index does not fit the
+    // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
+    BdxSeedPlan splan_alt{};
+    DevBuf seed_tables_alt;
+    DevBuf bp_tables;
+    DevBuf d_maxlen;
+    int user_len_hint = 0;  // 0 = measure every device batch
+    int filter_used = BDX_FILTER_OFF;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // device tables
+    DevBuf bc_bytes[2], bc_off[2], bc_nn[2];
+    DevBuf counts_own;
+    unsigned long long *counts = nullptr;
+    // staging for the host entry point
+    DevBuf d_seq, d_off, d_out_i32, d_out_f64;
+    // candidate masks (filtered paths)
+    DevBuf d_cand[2];
+    DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel
+    DevBuf d_exc;                 // known-score mode: reads handed over to the exact kernel
+    // multi-GPU: communicator + the reduced counter vector (bdx_comm.cpp)
+    bdx_comm_state *comm = nullptr;
+    DevBuf counts_sum;
+    std::string err;
+    std::string path;
+    int64_t launches = 0;
+    int64_t last_blocks = 0;
+};
+
+// records the message on ctx (or as the create error when ctx is NULL) and returns `code`
+int bdx_fail(bdx_ctx *ctx, int code, const char *fmt, ...);
+void bdx_comm_release(bdx_ctx *ctx);  // bdx_comm.cpp: frees ctx->comm (called by bdx_destroy)
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return bdx_fail(ctx, BDX_E_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)

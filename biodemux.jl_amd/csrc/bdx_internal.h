@@ -88,6 +88,8 @@ struct BdxBitparPlan {
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
     int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
+    long long grid_override;  // > 0: forced persistent grid (tuning, BdxTuning::grid)
+    int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
     int *d_tile_counter;           // device int, zeroed before each launch

@@ -56,6 +56,25 @@ def shard_bounds(n_reads: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_reads, lo + per)
 
 
+def init_abi_comm(classifier, rank: int = None, world: int = None) -> bool:
+    """Gives ``classifier`` (a HipClassifier) the RCCL communicator of the C-ABI (bdx_comm_init_rank): rank 0
+    makes the unique id, torch.distributed — whatever its backend — only carries those 128 bytes to the other
+    ranks.  Afterwards ``classifier.allreduce_counts()`` is merge_stats across the GPUs without torch in the
+    data path.  Returns False when the job has a single rank (nothing to set up)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return False
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    from .hipabi import comm_unique_id
+
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    classifier.comm_init_rank(box[0], rank, world)
+    return True
+
+
 def allreduce_counts(counts):
     """Sum the counter vector over all ranks (merge_stats across GPUs).  ``counts`` is a torch
     int64 tensor (device tensor -> RCCL, CPU tensor -> gloo) or a numpy array (copied).

@@ -28,7 +28,12 @@ ABI_SYMBOLS = [
     "bdx_classify_device", "bdx_sync", "bdx_set_stream", "bdx_counts_len", "bdx_get_counts",
     "bdx_reset_counts", "bdx_counts_device_ptr", "bdx_set_counts_buffer", "bdx_kernel_path",
     "bdx_launch_info", "bdx_set_read_length_hint", "bdx_host_alloc", "bdx_host_free",
+    # merge_stats across GPUs (RCCL, opened lazily)
+    "bdx_comm_get_unique_id", "bdx_comm_init_rank", "bdx_comm_init_all", "bdx_comm_destroy", "bdx_comm_rank",
+    "bdx_comm_size", "bdx_allreduce_counts", "bdx_allreduce_counts_all", "bdx_reduced_counts_device_ptr",
+    "bdx_get_reduced_counts",
 ]
+BDX_COMM_ID_BYTES = 128
 
 
 def pinned_empty(n: int, dtype) -> "np.ndarray":
@@ -177,9 +182,54 @@ def load_library(path: Optional[str] = None):
     L.bdx_kernel_path.argtypes = [vp]
     L.bdx_launch_info.restype = C.c_int32
     L.bdx_launch_info.argtypes = [vp, C.POINTER(BdxLaunchInfo)]
+    L.bdx_comm_get_unique_id.restype = C.c_int32
+    L.bdx_comm_get_unique_id.argtypes = [vp]
+    L.bdx_comm_init_rank.restype = C.c_int32
+    L.bdx_comm_init_rank.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.bdx_comm_init_all.restype = C.c_int32
+    L.bdx_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32]
+    L.bdx_comm_destroy.restype = C.c_int32
+    L.bdx_comm_destroy.argtypes = [vp]
+    L.bdx_comm_rank.restype = C.c_int32
+    L.bdx_comm_rank.argtypes = [vp]
+    L.bdx_comm_size.restype = C.c_int32
+    L.bdx_comm_size.argtypes = [vp]
+    L.bdx_allreduce_counts.restype = C.c_int32
+    L.bdx_allreduce_counts.argtypes = [vp]
+    L.bdx_allreduce_counts_all.restype = C.c_int32
+    L.bdx_allreduce_counts_all.argtypes = [C.POINTER(vp), C.c_int32]
+    L.bdx_reduced_counts_device_ptr.restype = vp
+    L.bdx_reduced_counts_device_ptr.argtypes = [vp]
+    L.bdx_get_reduced_counts.restype = C.c_int32
+    L.bdx_get_reduced_counts.argtypes = [vp, vp, C.c_int64]
     if path is None:
         _lib = L
     return L
+
+
+def comm_unique_id() -> bytes:
+    """bdx_comm_get_unique_id: the 128-byte RCCL id rank 0 makes and the host ships to every rank."""
+    lib = load_library()
+    buf = (C.c_uint8 * BDX_COMM_ID_BYTES)()
+    if lib.bdx_comm_get_unique_id(buf) != 0:
+        raise BdxError(lib.bdx_last_error(None).decode())
+    return bytes(buf)
+
+
+def comm_init_all(classifiers) -> None:
+    """bdx_comm_init_all: one process, one HipClassifier per (distinct) device."""
+    lib = load_library()
+    arr = (C.c_void_p * len(classifiers))(*[c.h for c in classifiers])
+    if lib.bdx_comm_init_all(arr, len(classifiers)) != 0:
+        raise BdxError((lib.bdx_last_error(classifiers[0].h) or lib.bdx_last_error(None)).decode())
+
+
+def allreduce_counts_all(classifiers) -> None:
+    """bdx_allreduce_counts_all: the grouped collective over the contexts of one process."""
+    lib = load_library()
+    arr = (C.c_void_p * len(classifiers))(*[c.h for c in classifiers])
+    if lib.bdx_allreduce_counts_all(arr, len(classifiers)) != 0:
+        raise BdxError((lib.bdx_last_error(classifiers[0].h) or lib.bdx_last_error(None)).decode())
 
 
 def _mk_range(dr) -> BdxRange:
@@ -336,6 +386,33 @@ class HipClassifier:
 
     def set_counts_buffer(self, d_ptr: int):
         self._check(self.lib.bdx_set_counts_buffer(self.h, d_ptr))
+
+    # -- merge_stats across GPUs through the C-ABI (RCCL) --
+    def comm_init_rank(self, unique_id: bytes, rank: int, n_ranks: int):
+        assert len(unique_id) == BDX_COMM_ID_BYTES
+        buf = (C.c_uint8 * BDX_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self.lib.bdx_comm_init_rank(self.h, buf, int(rank), int(n_ranks)))
+
+    def comm_destroy(self):
+        self._check(self.lib.bdx_comm_destroy(self.h))
+
+    @property
+    def comm_size(self) -> int:
+        return int(self.lib.bdx_comm_size(self.h))
+
+    @property
+    def comm_rank(self) -> int:
+        return int(self.lib.bdx_comm_rank(self.h))
+
+    def allreduce_counts(self):
+        """Enqueue the all-reduce (sum over the ranks) of the counter vector on this context's stream."""
+        self._check(self.lib.bdx_allreduce_counts(self.h))
+
+    @property
+    def reduced_counts(self) -> np.ndarray:
+        out = np.zeros(self.counts_len, dtype=np.int64)
+        self._check(self.lib.bdx_get_reduced_counts(self.h, out.ctypes.data, len(out)))
+        return out
 
     @property
     def kernel_path(self) -> str:

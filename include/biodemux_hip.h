@@ -35,6 +35,7 @@ extern "C" {
 #define BDX_E_INVALID (-1)   /* bad argument / config outside the supported domain */
 #define BDX_E_DEVICE (-2)    /* HIP runtime error (no GPU, OOM, launch failure) */
 #define BDX_E_STATE (-3)     /* call sequence error */
+#define BDX_E_COMM (-4)      /* RCCL not available / a collective failed */
 
 /* DemuxConfig.matching_algorithm (classification.jl:57): :semiglobal / :hamming / :exact */
 #define BDX_ALG_SEMIGLOBAL 0
@@ -197,6 +198,34 @@ int32_t bdx_reset_counts(bdx_ctx *ctx);
  * int64 so the collective can run on it directly; NULL restores the internal one. */
 void *bdx_counts_device_ptr(bdx_ctx *ctx);
 int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts);
+
+/* ---- merge_stats across GPUs (reporting.jl:1-9; called at core.jl:495 and :628) ----------------------
+ * The reference sums the per-worker DemuxStats in one process.  With one context per GPU the scalar part of
+ * that merge is ONE all-reduce (sum, int64, bdx_counts_len() words) over RCCL / xGMI, reachable from any host
+ * language through the calls below (RCCL itself is opened lazily, on the first communicator call).
+ *
+ * One process, several devices (the Julia host: one HipWorker per GPU):
+ *     bdx_comm_init_all(ctxs, n)        ncclCommInitAll over the contexts' (distinct) devices; rank i = ctxs[i]
+ *     bdx_allreduce_counts_all(ctxs, n) the grouped collective, driven by the calling thread
+ * One process per GPU (torchrun / mpirun):
+ *     bdx_comm_get_unique_id(id)        on rank 0; the host ships the BDX_COMM_ID_BYTES bytes to every rank
+ *     bdx_comm_init_rank(ctx, id, rank, n_ranks)
+ *     bdx_allreduce_counts(ctx)         also valid for one context per OS thread in the first shape
+ * The collective is enqueued on the context's stream and writes the SUM into a second, library-owned vector
+ * (bdx_reduced_counts_device_ptr / bdx_get_reduced_counts, which synchronises); the per-rank counters stay as
+ * they are, so accumulation can go on.  Without a communicator the "sum" is a copy (a 1-GPU host runs the same
+ * sequence).  All contexts of a communicator must be built from the same config. */
+#define BDX_COMM_ID_BYTES 128
+int32_t bdx_comm_get_unique_id(void *id_out);
+int32_t bdx_comm_init_rank(bdx_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
+int32_t bdx_comm_init_all(bdx_ctx *const *ctxs, int32_t n);
+int32_t bdx_comm_destroy(bdx_ctx *ctx);          /* also done by bdx_destroy */
+int32_t bdx_comm_rank(const bdx_ctx *ctx);       /* 0 without a communicator */
+int32_t bdx_comm_size(const bdx_ctx *ctx);       /* 1 without a communicator */
+int32_t bdx_allreduce_counts(bdx_ctx *ctx);
+int32_t bdx_allreduce_counts_all(bdx_ctx *const *ctxs, int32_t n);
+void *bdx_reduced_counts_device_ptr(bdx_ctx *ctx);
+int32_t bdx_get_reduced_counts(bdx_ctx *ctx, int64_t *out, int64_t n);
 
 /* Optional: page-locked host memory for the buffers given to bdx_classify_host (the reference's reader task
  * would fill its chunk buffers here, core.jl:43-110).  With pinned buffers the host <-> device copies are

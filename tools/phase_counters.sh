@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a library built with -DBDX_TUNING (HIPCC_EXTRA=-DBDX_TUNING python -c "import __graft_entry__ as g; g.build_hip(force=True)"): the product build has no phase-skip switches
 # per-phase instruction attribution: cumulative phase-skip flags + SQ counters (developer tool)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for d in 0 1 3 7 15 31 63 127; do

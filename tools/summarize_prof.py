@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Collect rocprofv3 outputs from gpurun_out/ into profiles/<tag>_*.{csv,json} (tracked).
-usage: summarize_prof.py <tag> <stats_dir> [<pmc_dir> ...]"""
+usage: summarize_prof.py <tag> <reads per launch> <stats_dir> [<pmc_dir> ...]
+<tag> should carry the bench config between underscores (r02_C2_final, r02_C4_...): bench.py looks for
+profiles/*_<config>_*_pmc.json."""
 import collections
 import csv
 import glob
@@ -9,12 +11,12 @@ import os
 import shutil
 import sys
 
-tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+tag, reads, stats_dir, pmc_dirs = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4:]
 os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
-summary = {"tag": tag, "kernels": {}}
+summary = {"tag": tag, "reads_per_launch": reads, "kernels": {}}
 for d in pmc_dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
