@@ -20,11 +20,12 @@ from .core import execute_demultiplexing
 from .fileio import preprocess_bc_file, read_fastq, write_fastq
 from .hipabi import ABI_SYMBOLS, LIB_PATH, BdxError, HipClassifier, load_library, pack_reads
 from .ranges import DynamicRange, parse_dynamic_range, resolve
+from .reporting import generate_summary_report
 
 __all__ = [
     "DemuxConfig", "DemuxStats", "DynamicRange", "SemiGlobalWorkspace", "HipClassifier", "BdxError",
     "build_config", "determine_filename", "exact_align", "execute_demultiplexing", "filename_for",
     "find_best_matching_bc", "hamming_align", "load_library", "merge_stats", "pack_reads",
-    "parse_dynamic_range", "preprocess_bc_file", "read_fastq", "resolve", "semiglobal_alignment",
+    "generate_summary_report", "parse_dynamic_range", "preprocess_bc_file", "read_fastq", "resolve", "semiglobal_alignment",
     "semiglobal_alignment_N", "write_fastq", "ABI_SYMBOLS", "LIB_PATH",
 ]

@@ -192,6 +192,35 @@ class DemuxStats:
                 s.sample_counts[(b1 + 1, b2 + 1 if n_bc2 else 0)] = c
         return s
 
+    def add_device_tables(self, tables: dict, config) -> None:
+        """Decode the histogram tables of the C-ABI (bdx_get_stats, hipabi.HipClassifier.stats_tables): per pass
+        [key][barcode] counts of best_start, best_end - best_start + 1 and the integer score numerator; the score
+        keys are round(raw / normalisation, digits = 2) exactly as classification.jl:835 computes them (Float64
+        division, then Julia's round-half-even on the scaled value)."""
+        import numpy as np
+
+        for p, tag in ((0, "bc1"), (1, "bc2")):
+            if p not in tables:
+                continue
+            seqs = config.bc_seqs if p == 0 else config.bc_seqs2
+            nn = config.bc_lengths_no_N if p == 0 else config.bc_lengths_no_N2
+            n_scoring = config.nindel is not None and str(config.matching_algorithm).lstrip(":") == "semiglobal"
+            for name, field_ in (("pos", "pos_counts"), ("len", "len_counts"), ("raw", "score_counts")):
+                tab, key0 = tables[p][name]
+                g = getattr(self, f"{tag}_{field_}")
+                per = getattr(self, f"{tag}_per_bc_{field_}")
+                rows, cols = np.nonzero(tab)
+                for r, b in zip(rows.tolist(), cols.tolist()):
+                    c = int(tab[r, b])
+                    if name == "raw":
+                        norm = float(nn[b]) if n_scoring else float(len(seqs[b]))
+                        key = float(_round2(np.float64(r) / np.float64(norm)))
+                    else:
+                        key = r + key0
+                    g[key] = g.get(key, 0) + c
+                    d = per.setdefault(b + 1, {})
+                    d[key] = d.get(key, 0) + c
+
     def add_pass_outputs(self, out: dict, min_delta: float) -> None:
         """Histogram update of match_barcode_pass (classification.jl:827-865) for one batch: a pass
         contributes iff its status is :match (winner found and delta >= min_delta); pass 2 only ran

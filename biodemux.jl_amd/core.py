@@ -22,6 +22,7 @@ from .config import DemuxConfig, build_config
 from .fileio import read_fastq
 from . import nativeio
 from .hipabi import HipClassifier
+from .reporting import canonical_duration, generate_summary_report
 
 _PREFIX_RE = re.compile(r"\.fastq(\.gz)?$")
 
@@ -206,10 +207,11 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
         o["barcode_start_range2"], o["barcode_end_range2"], o["trim_side"], o["trim_side2"], o["summary"],
         o["summary_format"], o["matching_algorithm"])
 
-    # summary=true also wants the histograms of classification.jl:827-865: ask for the per-pass outputs
-    classifier = (_classifier_factory(config) if _classifier_factory
-                  else HipClassifier(config, device=device, want_pass=bool(config.summary)))
-    hist = DemuxStats() if config.summary else None
+    # summary=true: the HIP classifier collects the histograms of classification.jl:827-865 on the device
+    # (bdx_get_stats); a test-injected classifier without such tables hands over per-pass outputs instead
+    classifier = _classifier_factory(config) if _classifier_factory else HipClassifier(config, device=device)
+    device_stats = hasattr(classifier, "stats_tables")
+    hist = DemuxStats() if (config.summary and not device_stats) else None
 
     def on_batch(out):
         if hist is not None and "pass_bc" in out:
@@ -225,15 +227,23 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
         else:
             _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads, on_batch)
         counts = np.asarray(classifier.counts)
+        tables = classifier.stats_tables() if (config.summary and device_stats) else None
     finally:
         classifier.close()
 
-    if o["log"]:  # core.jl:484-491
-        _log(f"Done: Finished in {_dt.datetime.now() - start_time}.")
+    duration = _dt.datetime.now() - start_time  # core.jl:484-485
+    if o["log"]:  # core.jl:487-491
+        _log(f"Done: Finished in {canonical_duration(duration)}.")
     stats = DemuxStats.from_counts(counts, len(config.bc_seqs), len(config.bc_seqs2) if config.is_dual else 0)
+    if tables is not None:
+        stats.add_device_tables(tables, config)
     if hist is not None:
         for f in ("bc1", "bc2"):
             for k in ("pos_counts", "len_counts", "score_counts", "per_bc_score_counts", "per_bc_pos_counts",
                       "per_bc_len_counts"):
                 setattr(stats, f"{f}_{k}", getattr(hist, f"{f}_{k}"))
+    if config.summary:  # core.jl:493-497 / :626-630 (merge_stats over the workers: one device context here)
+        generate_summary_report(stats, config, output_directory, fastq1, barcode_file, fastq2, o["barcode_file2"],
+                                bc_complement=o["bc_complement"], bc_rev=o["bc_rev"], trim_side=o["trim_side"],
+                                trim_side2=o["trim_side2"], n_threads=1, duration=duration)
     return stats

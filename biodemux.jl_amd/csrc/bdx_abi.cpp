@@ -699,6 +699,62 @@ int upload_tables(bdx_ctx *ctx) {
 
 }  // namespace
 
+int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
+    if (!ctx->dev.need_traceback || rows <= ctx->st_rows) return BDX_OK;
+    long long want = rows;
+    if (!exact) {  // generous steps: a batch with slightly longer reads must not re-allocate every time
+        want = ctx->st_rows ? ctx->st_rows + ctx->st_rows / 2 : 0;
+        if (want < rows) want = rows;
+        want = (want + 63) & ~63LL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int npass = ctx->dev.is_dual ? 2 : 1;
+    for (int p = 0; p < npass; ++p)
+        for (int w = 0; w < 2; ++w) {  // pos, len (raw has a fixed height)
+            const size_t old_bytes = bdx_stats_words(ctx, p, w, ctx->st_rows) * 8;
+            const size_t new_bytes = bdx_stats_words(ctx, p, w, want) * 8;
+            DevBuf nb;
+            HIP_TRY(ctx, nb.ensure(new_bytes));
+            HIP_TRY(ctx, hipMemset(nb.p, 0, new_bytes));
+            if (old_bytes) HIP_TRY(ctx, hipMemcpy(nb.p, ctx->st_tab[p][w].p, old_bytes, hipMemcpyDeviceToDevice));
+            ctx->st_tab[p][w].release();
+            ctx->st_tab[p][w] = nb;  // row-major by key: the old table is a prefix of the new one
+        }
+    ctx->st_rows = want;
+    return BDX_OK;
+}
+
+namespace {
+
+// statistics tables whose size is known from the config: the raw-score table (and the overflow flag)
+int init_stats(bdx_ctx *ctx) {
+    if (!ctx->dev.need_traceback) return BDX_OK;
+    const bdx_config_t &c = ctx->cfg;
+    const int npass = c.is_dual ? 2 : 1;
+    double top = 0.0;  // the largest recordable numerator: floor(rate * normalisation) at the initial threshold
+    for (int k = 0; k < npass; ++k)
+        for (int b = 0; b < c.pass[k].n_barcodes; ++b) {
+            const int m = (int)(c.pass[k].bc_off[b + 1] - c.pass[k].bc_off[b]);
+            const double norm = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) ? (double)c.pass[k].bc_len_no_N[b] : (double)m;
+            const double ae = c.algorithm == BDX_ALG_EXACT ? 0.0 : std::floor(c.max_error_rate * norm);
+            if (ae > top) top = ae;
+        }
+    if (top > (double)(1 << 20))
+        return fail(ctx, BDX_E_INVALID, "summary statistics support scores up to %d; max_error_rate * barcode length gives %g", 1 << 20, top);
+    ctx->st_raw_rows = (int)top + 1;
+    for (int p = 0; p < npass; ++p) {
+        const size_t bytes = bdx_stats_words(ctx, p, 2, 0) * 8;
+        HIP_TRY(ctx, ctx->st_tab[p][2].ensure(bytes));
+        HIP_TRY(ctx, hipMemset(ctx->st_tab[p][2].p, 0, bytes));
+    }
+    HIP_TRY(ctx, ctx->st_flag.ensure(256));
+    HIP_TRY(ctx, hipMemset(ctx->st_flag.p, 0, 256));
+    return BDX_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int32_t bdx_abi_version(void) { return BDX_ABI_VERSION; }
@@ -739,6 +795,8 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     rc = upload_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
     rc = plan_generic(ctx);  // needs the caller's host tables: run before they are dropped
+    if (rc != BDX_OK) return bail(rc);
+    rc = init_stats(ctx);
     if (rc != BDX_OK) return bail(rc);
     rc = build_bitpar_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
@@ -802,6 +860,12 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->d_out_f64.release();
     bdx_comm_release(ctx);
     ctx->counts_sum.release();
+    for (int p = 0; p < 2; ++p)
+        for (int w = 0; w < 3; ++w) {
+            ctx->st_tab[p][w].release();
+            ctx->st_sum[p][w].release();
+        }
+    ctx->st_flag.release();
     delete ctx;
 }
 
@@ -841,9 +905,32 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     o.pass_score = d_out->pass_score;
     o.pass_bc = d_out->pass_bc;
     o.pass_delta = d_out->pass_delta;
+    BdxDevStats st{};
+    const BdxDevStats *stp = nullptr;
+    int measured_len = -1;
+    if (ctx->dev.need_traceback) {
+        // statistics tables are sized from the batch's true maximum read length (a hint is only a hint)
+        HIP_TRY(ctx, ctx->d_maxlen.ensure(256));
+        HIP_TRY(ctx, bdx_launch_maxlen((const long long *)d_seq_off, n_reads, (int *)ctx->d_maxlen.p, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&measured_len, ctx->d_maxlen.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = bdx_stats_reserve(ctx, (long long)measured_len + ctx->dev.max_m + 2);
+        if (rc != BDX_OK) return rc;
+        for (int p = 0; p < 2; ++p) {
+            st.pos[p] = (unsigned long long *)ctx->st_tab[p][0].p;
+            st.len[p] = (unsigned long long *)ctx->st_tab[p][1].p;
+            st.raw[p] = (unsigned long long *)ctx->st_tab[p][2].p;
+        }
+        st.rows = ctx->st_rows;
+        st.raw_rows = ctx->st_raw_rows;
+        st.pos_bias = ctx->dev.max_m;
+        st.overflow = (unsigned int *)ctx->st_flag.p;
+        stp = &st;
+    }
     bool filtered = false;
     if (ctx->bplan.enabled) {
         int len = ctx->user_len_hint;
+        if (len <= 0 && measured_len >= 0) len = measured_len > 0 ? measured_len : 1;
         if (len <= 0) {  // measure the batch: one tiny kernel + a 4-byte copy
             int host_len = 0;
             HIP_TRY(ctx, bdx_launch_maxlen((const long long *)d_seq_off, n_reads, (int *)ctx->d_maxlen.p, ctx->stream));
@@ -899,11 +986,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (split)
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
-                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr));
+                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, nullptr, nullptr, stp));
         else
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
-                                            nullptr, exc_list, exc_count));
+                                            nullptr, exc_list, exc_count, stp));
 #ifdef BDX_TUNING
         if (ctx->tune.debug & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
                 unsigned int st[4] = {0, 0, 0, 0};
@@ -918,7 +1005,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                        ctx->counts, nullptr, nullptr, ctx->stream));
+                                        ctx->counts, nullptr, nullptr, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, stp));
         ctx->last_blocks = (n_reads + ctx->plan.threads - 1) / ctx->plan.threads;
         ctx->path = "generic";
         ctx->filter_used = BDX_FILTER_OFF;
@@ -1008,6 +1096,39 @@ int32_t bdx_reset_counts(bdx_ctx *ctx) {
     if (!ctx) return BDX_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts, 0, (size_t)ctx->dev.n_counts * 8, ctx->stream));
+    if (ctx->dev.need_traceback)
+        for (int p = 0; p < (ctx->dev.is_dual ? 2 : 1); ++p)
+            for (int w = 0; w < 3; ++w)
+                if (ctx->st_tab[p][w].p)
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->st_tab[p][w].p, 0, bdx_stats_words(ctx, p, w, ctx->st_rows) * 8, ctx->stream));
+    return BDX_OK;
+}
+
+int32_t bdx_stats_shape(const bdx_ctx *ctx, int32_t pass, int32_t which, int64_t *rows, int64_t *key0, int64_t *n_barcodes) {
+    if (!ctx) return BDX_E_INVALID;
+    if (pass < 0 || pass > 1 || which < BDX_STATS_POS || which > BDX_STATS_RAW) return BDX_E_INVALID;
+    const bool on = ctx->dev.need_traceback && (pass == 0 || ctx->dev.is_dual);
+    if (rows) *rows = !on ? 0 : (which == BDX_STATS_RAW ? ctx->st_raw_rows : ctx->st_rows);
+    if (key0) *key0 = which == BDX_STATS_POS ? 1 - (int64_t)ctx->dev.max_m : 0;
+    if (n_barcodes) *n_barcodes = on ? ctx->dev.pass[pass].n_barcodes : 0;
+    return BDX_OK;
+}
+
+int32_t bdx_get_stats(bdx_ctx *ctx, int32_t pass, int32_t which, int32_t reduced, int64_t *out, int64_t n_words) {
+    if (!ctx || !out) return BDX_E_INVALID;
+    if (pass < 0 || pass > 1 || which < BDX_STATS_POS || which > BDX_STATS_RAW) return fail(ctx, BDX_E_INVALID, "bad statistics table selector");
+    if (!ctx->dev.need_traceback || (pass == 1 && !ctx->dev.is_dual)) return fail(ctx, BDX_E_STATE, "the config collects no statistics for this pass (need_traceback = 0)");
+    const long long rows = reduced ? ctx->st_sum_rows : ctx->st_rows;
+    const size_t words = bdx_stats_words(ctx, pass, which, rows);
+    if ((size_t)n_words < words) return fail(ctx, BDX_E_INVALID, "statistics buffer too small: need %zu words", words);
+    const DevBuf &src = reduced ? ctx->st_sum[pass][which] : ctx->st_tab[pass][which];
+    if (reduced && !src.p) return fail(ctx, BDX_E_STATE, "bdx_allreduce_counts has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->st_flag.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+    if (words) HIP_TRY(ctx, hipMemcpyAsync(out, src.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(ctx, BDX_E_STATE, "a statistics key fell outside its table (internal sizing error)");
     return BDX_OK;
 }
 

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only; nothing here is linked against librccl
 
+#include <cstdarg>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -92,6 +93,19 @@ Rccl *rccl(bdx_ctx *ctx) {
         if (r__ != ncclSuccess) return bdx_fail(ctx, BDX_E_COMM, "%s failed: %s", #call, (R)->GetErrorString(r__)); \
     } while (0)
 
+// group calls: whichever context the host asks afterwards (or none: bdx_last_error(NULL)) has the message
+int fail_group(bdx_ctx *const *ctxs, int n, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    bdx_fail(nullptr, code, "%s", buf);
+    for (int i = 0; i < n; ++i)
+        if (ctxs && ctxs[i]) ctxs[i]->err = buf;
+    return code;
+}
+
 int ensure_sum_buffer(bdx_ctx *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->counts_sum.ensure((size_t)ctx->dev.n_counts * 8));
@@ -149,13 +163,13 @@ int32_t bdx_comm_init_all(bdx_ctx *const *ctxs, int32_t n) {
     if (!ctxs || n < 1) return bdx_fail(nullptr, BDX_E_INVALID, "bdx_comm_init_all needs at least one context");
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return bdx_fail(nullptr, BDX_E_INVALID, "context %d is NULL", i);
-        if (ctxs[i]->comm) return bdx_fail(ctxs[i], BDX_E_STATE, "the context already has a communicator");
+        if (ctxs[i]->comm) return fail_group(ctxs, i + 1, BDX_E_STATE, "the context already has a communicator");
         if (ctxs[i]->dev.n_counts != ctxs[0]->dev.n_counts)
-            return bdx_fail(ctxs[i], BDX_E_INVALID, "contexts of one communicator must share the config (counter vectors differ: %d vs %d)",
-                            ctxs[i]->dev.n_counts, ctxs[0]->dev.n_counts);
+            return fail_group(ctxs, i + 1, BDX_E_INVALID, "contexts of one communicator must share the config (counter vectors differ: %d vs %d)",
+                              ctxs[i]->dev.n_counts, ctxs[0]->dev.n_counts);
         for (int j = 0; j < i; ++j)
             if (ctxs[j]->device == ctxs[i]->device)
-                return bdx_fail(ctxs[i], BDX_E_INVALID, "contexts %d and %d share device %d (RCCL wants one rank per device)", j, i, ctxs[i]->device);
+                return fail_group(ctxs, i + 1, BDX_E_INVALID, "contexts %d and %d share device %d (RCCL wants one rank per device)", j, i, ctxs[i]->device);
     }
     Rccl *R = rccl(ctxs[0]);
     if (!R) return BDX_E_COMM;
@@ -184,16 +198,61 @@ int32_t bdx_comm_destroy(bdx_ctx *ctx) {
 int32_t bdx_comm_rank(const bdx_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->rank : 0; }
 int32_t bdx_comm_size(const bdx_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->n_ranks : 1; }
 
-// enqueue on ctx's stream: counts_sum = sum over the ranks of counts (the per-rank vector stays as it is)
+// ---- the statistics tables (summary = true) travel with the counters --------------------------------
+// Their height follows the longest read a rank has seen, so the ranks first agree on the maximum
+// (one tiny all-reduce, ncclMax), grow to it, and then every table is summed like the counter vector.
+static long long *rows_slot(bdx_ctx *ctx) { return (long long *)((char *)ctx->st_flag.p + 64); }
+
+static int stats_agree_enqueue(bdx_ctx *ctx, Rccl *R) {
+    if (!ctx->dev.need_traceback || !ctx->comm) return BDX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long mine = ctx->st_rows;
+    HIP_TRY(ctx, hipMemcpyAsync(rows_slot(ctx), &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    NCCL_TRY(ctx, R, R->AllReduce(rows_slot(ctx), rows_slot(ctx), 1, ncclInt64, ncclMax, ctx->comm->comm, ctx->stream));
+    return BDX_OK;
+}
+
+static int stats_agree_finish(bdx_ctx *ctx) {
+    if (!ctx->dev.need_traceback) return BDX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long long agreed = ctx->st_rows;
+    if (ctx->comm) {
+        HIP_TRY(ctx, hipMemcpyAsync(&agreed, rows_slot(ctx), sizeof agreed, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int rc = bdx_stats_reserve(ctx, agreed, true);
+    if (rc != BDX_OK) return rc;
+    const int npass = ctx->dev.is_dual ? 2 : 1;
+    for (int p = 0; p < npass; ++p)
+        for (int w = 0; w < 3; ++w) HIP_TRY(ctx, ctx->st_sum[p][w].ensure(bdx_stats_words(ctx, p, w, ctx->st_rows) * 8 + 8));
+    ctx->st_sum_rows = ctx->st_rows;
+    return BDX_OK;
+}
+
+// enqueue on ctx's stream: counts_sum (and the summed statistics tables) = sum over the ranks; the per-rank
+// vectors stay as they are
 static int enqueue_allreduce(bdx_ctx *ctx, Rccl *R) {
     int rc = ensure_sum_buffer(ctx);
     if (rc != BDX_OK) return rc;
     const size_t n = (size_t)ctx->dev.n_counts;
+    const int npass = ctx->dev.is_dual ? 2 : 1;
     if (!ctx->comm) {  // a single-GPU host runs the same call sequence: the sum over one rank
         HIP_TRY(ctx, hipMemcpyAsync(ctx->counts_sum.p, ctx->counts, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->dev.need_traceback)
+            for (int p = 0; p < npass; ++p)
+                for (int w = 0; w < 3; ++w) {
+                    const size_t words = bdx_stats_words(ctx, p, w, ctx->st_rows);
+                    if (words) HIP_TRY(ctx, hipMemcpyAsync(ctx->st_sum[p][w].p, ctx->st_tab[p][w].p, words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                }
         return BDX_OK;
     }
     NCCL_TRY(ctx, R, R->AllReduce(ctx->counts, ctx->counts_sum.p, n, ncclInt64, ncclSum, ctx->comm->comm, ctx->stream));
+    if (ctx->dev.need_traceback)
+        for (int p = 0; p < npass; ++p)
+            for (int w = 0; w < 3; ++w) {
+                const size_t words = bdx_stats_words(ctx, p, w, ctx->st_rows);
+                if (words) NCCL_TRY(ctx, R, R->AllReduce(ctx->st_tab[p][w].p, ctx->st_sum[p][w].p, words, ncclInt64, ncclSum, ctx->comm->comm, ctx->stream));
+            }
     return BDX_OK;
 }
 
@@ -201,7 +260,16 @@ int32_t bdx_allreduce_counts(bdx_ctx *ctx) {
     if (!ctx) return BDX_E_INVALID;
     Rccl *R = nullptr;
     if (ctx->comm && !(R = rccl(ctx))) return BDX_E_COMM;
-    return enqueue_allreduce(ctx, R);
+    int rc = stats_agree_enqueue(ctx, R);
+    if (rc == BDX_OK) rc = stats_agree_finish(ctx);
+    if (rc != BDX_OK) return rc;
+    if (R) NCCL_TRY(ctx, R, R->GroupStart());  // counters + tables as one fused launch
+    rc = enqueue_allreduce(ctx, R);
+    if (R) {
+        ncclResult_t rr = R->GroupEnd();
+        if (rc == BDX_OK && rr != ncclSuccess) rc = bdx_fail(ctx, BDX_E_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(rr));
+    }
+    return rc;
 }
 
 int32_t bdx_allreduce_counts_all(bdx_ctx *const *ctxs, int32_t n) {
@@ -213,17 +281,22 @@ int32_t bdx_allreduce_counts_all(bdx_ctx *const *ctxs, int32_t n) {
     }
     Rccl *R = nullptr;
     if (any_comm && !(R = rccl(ctxs[0]))) return BDX_E_COMM;
-    for (int i = 0; i < n; ++i) {  // allocations stay outside the group
-        const int rc0 = ensure_sum_buffer(ctxs[i]);
-        if (rc0 != BDX_OK) return rc0;
-    }
-    // one thread drives several devices: the per-device calls must be fused into one group
-    if (R) NCCL_TRY(ctxs[0], R, R->GroupStart());
     int rc = BDX_OK;
+    // one thread drives several devices: the per-device calls of a collective must be fused into one group
+    if (R) NCCL_TRY(ctxs[0], R, R->GroupStart());
+    for (int i = 0; i < n && rc == BDX_OK; ++i) rc = stats_agree_enqueue(ctxs[i], R);
+    if (R) {
+        ncclResult_t rr = R->GroupEnd();
+        if (rc == BDX_OK && rr != ncclSuccess) rc = fail_group(ctxs, n, BDX_E_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(rr));
+    }
+    for (int i = 0; i < n && rc == BDX_OK; ++i) rc = stats_agree_finish(ctxs[i]);  // allocations stay outside the groups
+    for (int i = 0; i < n && rc == BDX_OK; ++i) rc = ensure_sum_buffer(ctxs[i]);
+    if (rc != BDX_OK) return rc;
+    if (R) NCCL_TRY(ctxs[0], R, R->GroupStart());
     for (int i = 0; i < n && rc == BDX_OK; ++i) rc = enqueue_allreduce(ctxs[i], R);
     if (R) {
         ncclResult_t rr = R->GroupEnd();
-        if (rc == BDX_OK && rr != ncclSuccess) rc = bdx_fail(ctxs[0], BDX_E_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(rr));
+        if (rc == BDX_OK && rr != ncclSuccess) rc = fail_group(ctxs, n, BDX_E_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(rr));
     }
     return rc;
 }

@@ -72,6 +72,11 @@ struct bdx_ctx {
     DevBuf d_cand[2];
     DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel
     DevBuf d_exc;                 // known-score mode: reads handed over to the exact kernel
+    // DemuxStats histograms (summary = true): [pass][pos | len | raw] int64 tables of st_rows (raw: st_raw_rows)
+    // rows x n_barcodes, their all-reduced twins, and the overflow flag
+    DevBuf st_tab[2][3], st_sum[2][3], st_flag;
+    long long st_rows = 0, st_sum_rows = 0;
+    int st_raw_rows = 0;
     // multi-GPU: communicator + the reduced counter vector (bdx_comm.cpp)
     bdx_comm_state *comm = nullptr;
     DevBuf counts_sum;
@@ -84,6 +89,11 @@ struct bdx_ctx {
 // records the message on ctx (or as the create error when ctx is NULL) and returns `code`
 int bdx_fail(bdx_ctx *ctx, int code, const char *fmt, ...);
 void bdx_comm_release(bdx_ctx *ctx);  // bdx_comm.cpp: frees ctx->comm (called by bdx_destroy)
+// histogram tables: grow (append zero rows) to at least `rows` rows; synchronises the stream when it grows
+int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact = false);  // exact: the height the ranks agreed on
+inline size_t bdx_stats_words(const bdx_ctx *ctx, int pass, int which, long long rows) {
+    return (size_t)(which == 2 ? ctx->st_raw_rows : rows) * (size_t)ctx->dev.pass[pass].n_barcodes;
+}
 
 #define HIP_TRY(ctx, call)                                                                      \
     do {                                                                                        \

@@ -42,7 +42,24 @@ struct GenericArgs {
     const unsigned int *list_count;  // ... and how many (device-resident; the grid strides over them)
     int bc_stage_bytes; // bytes of the barcode staging area (both passes; 0: barcodes not staged)
     int hist_entries;
+    BdxDevStats stats;  // rows == 0: no histograms
 };
+
+// match_barcode_pass's statistics block (classification.jl:827-865): runs iff the pass returned :match
+__device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p, const int B, const PassOut &po) {
+    if (po.status != 1) return;
+    const long long b = po.bc - 1;
+    const long long prow = (long long)po.start - 1 + st.pos_bias;
+    const long long lrow = (long long)po.end - po.start + 1;
+    const long long rrow = po.raw;
+    if (prow < 0 || prow >= st.rows || lrow < 0 || lrow >= st.rows || rrow < 0 || rrow >= st.raw_rows) {
+        atomicOr(st.overflow, 1u);
+        return;
+    }
+    atomicAdd(&st.pos[p][prow * B + b], 1ULL);
+    atomicAdd(&st.len[p][lrow * B + b], 1ULL);
+    atomicAdd(&st.raw[p][rrow * B + b], 1ULL);
+}
 
 // LDS carve-up (all 16-byte aligned):
 //   [DP: dp_rows*BS int][OG: dp_rows*BS int if any_traceback][off0|off1: uint32][nn0|nn1: int]
@@ -188,6 +205,10 @@ __global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(co
             a.out.pass_delta[2 * ridx] = p1.delta;
             a.out.pass_delta[2 * ridx + 1] = p2.delta;
         }
+        if (a.stats.rows > 0) {
+            stats_update(a.stats, 0, B0, p1);
+            if (cfg.is_dual) stats_update(a.stats, 1, B1, p2);
+        }
     }
 
     // DemuxStats scalar counters (classification.jl:942-978), merged like reporting.jl:1-9
@@ -267,7 +288,7 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               unsigned long long *d_counts, const uint32_t *d_cand0, const uint32_t *d_cand1,
                               hipStream_t stream, const uint32_t *d_wins0, const uint32_t *d_wins1,
                               const uint8_t *d_wcnt0, const uint8_t *d_wcnt1, const uint32_t *d_list,
-                              const unsigned int *d_list_count) {
+                              const unsigned int *d_list_count, const BdxDevStats *stats) {
     if (n_reads <= 0) return hipSuccess;
     GenericArgs a;
     a.cfg = cfg;
@@ -284,6 +305,10 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     a.wcnt[1] = d_wcnt1;
     a.list = d_list;
     a.list_count = d_list_count;
+    if (stats)
+        a.stats = *stats;
+    else
+        a.stats = BdxDevStats{};
     a.cfg.end_only_ok = out.pass_start == nullptr ? 1 : 0;
     a.dp_rows = plan.dp_rows;
     a.stage_bytes = plan.stage_bytes;

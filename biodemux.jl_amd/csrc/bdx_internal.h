@@ -61,6 +61,19 @@ struct BdxDevOut {
     double *pass_score, *pass_delta;
 };
 
+// DemuxStats histograms (classification.jl:827-865), accumulated by the exact kernel when the config asks for
+// statistics (summary = true): per pass three int64 tables [rows][n_barcodes] — start position (row = start - 1
+// + pos_bias: origins may lie before the read), length end - start + 1, and the integer numerator of
+// the score (the host maps it to round(raw / norm, digits = 2), :835).  Row-major by KEY so that a longer read
+// in a later batch only appends rows.
+struct BdxDevStats {
+    unsigned long long *pos[2], *len[2], *raw[2];
+    long long rows;       // rows of pos / len (0: no statistics)
+    int raw_rows;
+    int pos_bias;         // = max barcode length
+    unsigned int *overflow;  // set when a key does not fit (cannot happen with rows sized from the batch)
+};
+
 // Launch geometry chosen on the host for the generic (unfiltered / verify) kernel.
 struct BdxGenericPlan {
     int threads;         // 64 / 128 / 256
@@ -139,5 +152,5 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               const uint32_t *d_cand1, hipStream_t stream, const uint32_t *d_wins0 = nullptr,
                               const uint32_t *d_wins1 = nullptr, const uint8_t *d_wcnt0 = nullptr,
                               const uint8_t *d_wcnt1 = nullptr, const uint32_t *d_list = nullptr,
-                              const unsigned int *d_list_count = nullptr);
+                              const unsigned int *d_list_count = nullptr, const BdxDevStats *stats = nullptr);
 hipError_t bdx_generic_set_lds_limit(size_t bytes);

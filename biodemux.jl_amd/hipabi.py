@@ -32,7 +32,10 @@ ABI_SYMBOLS = [
     "bdx_comm_get_unique_id", "bdx_comm_init_rank", "bdx_comm_init_all", "bdx_comm_destroy", "bdx_comm_rank",
     "bdx_comm_size", "bdx_allreduce_counts", "bdx_allreduce_counts_all", "bdx_reduced_counts_device_ptr",
     "bdx_get_reduced_counts",
+    # DemuxStats histograms (summary = true), collected on the device
+    "bdx_stats_shape", "bdx_get_stats",
 ]
+STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
 BDX_COMM_ID_BYTES = 128
 
 
@@ -202,6 +205,10 @@ def load_library(path: Optional[str] = None):
     L.bdx_reduced_counts_device_ptr.argtypes = [vp]
     L.bdx_get_reduced_counts.restype = C.c_int32
     L.bdx_get_reduced_counts.argtypes = [vp, vp, C.c_int64]
+    L.bdx_stats_shape.restype = C.c_int32
+    L.bdx_stats_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.bdx_get_stats.restype = C.c_int32
+    L.bdx_get_stats.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64]
     if path is None:
         _lib = L
     return L
@@ -412,6 +419,26 @@ class HipClassifier:
     def reduced_counts(self) -> np.ndarray:
         out = np.zeros(self.counts_len, dtype=np.int64)
         self._check(self.lib.bdx_get_reduced_counts(self.h, out.ctypes.data, len(out)))
+        return out
+
+    def stats_tables(self, reduced: bool = False) -> dict:
+        """The DemuxStats histograms the device collected (summary = true): ``{pass: {"pos" | "len" | "raw":
+        (int64[rows, n_barcodes], key0)}}`` — row r of a table holds key r + key0 (bdx_stats_shape / bdx_get_stats).
+        ``reduced`` reads the tables summed over the ranks by allreduce_counts()."""
+        out = {}
+        for p in range(2 if self.cfg.is_dual else 1):
+            out[p] = {}
+            for name, w in STATS_WHICH.items():
+                rows, key0, nb = C.c_int64(), C.c_int64(), C.c_int64()
+                self._check(self.lib.bdx_stats_shape(self.h, p, w, C.byref(rows), C.byref(key0), C.byref(nb)))
+                if reduced and name != "raw":  # the reduced tables have the height the ranks agreed on
+                    pass
+                tab = np.zeros((max(rows.value, 0), max(nb.value, 0)), dtype=np.int64)
+                if tab.size or rows.value:
+                    buf = np.zeros(max(tab.size, 1), dtype=np.int64)
+                    self._check(self.lib.bdx_get_stats(self.h, p, w, int(bool(reduced)), buf.ctypes.data, len(buf)))
+                    tab = buf[:tab.size].reshape(tab.shape)
+                out[p][name] = (tab, int(key0.value))
         return out
 
     @property

@@ -192,6 +192,21 @@ int32_t bdx_get_counts(bdx_ctx *ctx, int64_t *out, int64_t n);
 /* Zeroes the counters. */
 int32_t bdx_reset_counts(bdx_ctx *ctx);
 
+/* DemuxStats histograms (classification.jl:746-757, filled at :827-865 for every pass that returns :match;
+ * merged like reporting.jl:10-56).  Collected on the device when config.need_traceback (summary = true), as three
+ * int64 tables per pass, each [rows][n_barcodes(pass)] row-major by key:
+ *   BDX_STATS_POS  key = best_start (row r holds key r + key0, key0 = 1 - longest barcode: origins may precede the read)
+ *   BDX_STATS_LEN  key = best_end - best_start + 1
+ *   BDX_STATS_RAW  key = integer numerator of min_score; the host derives round(raw / normalisation, digits = 2) (:835)
+ * Summing a row over the barcodes gives bc{1,2}_{pos,len,score}_counts, a column bc{1,2}_per_bc_*.  rows grows with
+ * the longest read seen (pos, len); bdx_stats_shape reports the current shape.  reduced != 0 reads the tables
+ * summed over the ranks by bdx_allreduce_counts* (which all-reduces them together with the counter vector). */
+#define BDX_STATS_POS 0
+#define BDX_STATS_LEN 1
+#define BDX_STATS_RAW 2
+int32_t bdx_stats_shape(const bdx_ctx *ctx, int32_t pass, int32_t which, int64_t *rows, int64_t *key0, int64_t *n_barcodes);
+int32_t bdx_get_stats(bdx_ctx *ctx, int32_t pass, int32_t which, int32_t reduced, int64_t *out, int64_t n_words);
+
 /* Device address of the int64 counter vector — the buffer a multi-GPU host all-reduces
  * (sum) over RCCL, the analogue of merge_stats (reporting.jl:1-9).  bdx_set_counts_buffer
  * lets the host supply its own device buffer (e.g. a torch tensor) of bdx_counts_len()

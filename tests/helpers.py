@@ -290,9 +290,51 @@ def scenario_summary_counts(run, tmp):
     f1, f2 = os.path.join(tmp, "reads_R1.fastq"), os.path.join(tmp, "reads_R2.fastq")
     _write(f1, "@read1\nAAAACCCC\n+\nIIIIIIII\n@read2\nTTTTGGGG\n+\nIIIIIIII\n")
     _write(f2, "@read1\nNNNN\n+\nIIII\n@read2\nNNNN\n+\nIIII\n")
-    stats = run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="txt")
+    # summary_mode.jl:50-57: the text report
+    txt = os.path.join(out, "summary.txt")
+    content = open(txt).read()
+    for needle in ("Total Reads: 4", "Matched Reads: 2", "Run Information:", f"Barcode File: {bc}"):
+        assert needle in content, needle
+    assert "Barcode File 2:" not in content
+    assert "BC1\t1\t25.0%" in content and "Matched Reads: 2 (50.0%)" in content  # reporting.jl:111, :127 (Julia float printing)
+    # :59-67: a second run appends after a separator
+    run(fq, bc, out, max_error_rate=0.2, summary=True, summary_format="txt")
+    content = open(txt).read()
+    assert "==================================================" in content
+    assert content.split("\n").count("Run Information:") == 2
+    # :69-82: dual (inline), JSON
+    f1, f2 = os.path.join(tmp, "reads_R1.fastq"), os.path.join(tmp, "reads_R2.fastq")
+    _write(f1, "@read1\nAAAACCCC\n+\nIIIIIIII\n@read2\nTTTTGGGG\n+\nIIIIIIII\n")
+    _write(f2, "@read1\nNNNN\n+\nIIII\n@read2\nNNNN\n+\nIIII\n")
+    stats = run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="json")
     assert stats.total_reads == 2 and stats.matched_reads == 2
     assert stats.sample_counts == {(1, 1): 1, (2, 2): 1}
+    js = os.path.join(out, "summary.json")
+    content = open(js).read()
+    for needle in ('"total_reads": 2', '"matched_reads": 2', f'"barcode_file2": "{bc2}"', '"(1, 1)": 1', '"bc2_pos_counts": {"5": 2}'):
+        assert needle in content, needle
+    assert len(json.loads(content)) == 1  # the file is valid JSON: a list of run objects
+    # :84-95: a second JSON run extends the list
+    run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="json")
+    content = open(js).read().strip()
+    assert content.startswith("[") and content.endswith("]")
+    assert sum('"run_info"' in ln for ln in content.split("\n")) == 2
+    assert [r["total_reads"] for r in json.loads(content)] == [2, 2]
+    # :97-119: HTML, twice
+    run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="html")
+    content = open(os.path.join(out, "summary.html")).read()
+    assert "Total Reads" in content and "Barcode File 2:" in content and bc2 in content
+    run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="html")
+    content = open(os.path.join(out, "summary.html")).read()
+    assert sum("Run Information" in ln for ln in content.split("\n")) == 2 and content.count("</body>") == 1
+    # :121-141: stdout
+    import contextlib
+    import io as _io
+    buf = _io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        run(f1, f2, bc, out, barcode_file2=bc2, max_error_rate=0.2, summary=True, summary_format="stdout")
+    output = buf.getvalue()
+    assert "BioDemuX Summary Report" in output and f"Barcode File 2: {bc2}" in output and "Total Reads: 2" in output
 
 
 def scenario_summary_distribution_reads(run, tmp):
@@ -311,6 +353,16 @@ def scenario_summary_distribution_reads(run, tmp):
     assert stats.bc1_pos_counts[2] == 1 and stats.bc1_pos_counts[3] == 1
     assert set(stats.bc1_score_counts) == {0.0, 0.25} and stats.bc1_per_bc_pos_counts[1] == stats.bc1_pos_counts
     assert stats.bc2_pos_counts == {}
+    # summary_distributions.jl:30-52: the JSON report carries the distributions
+    content = open(os.path.join(tmp, "output_dist", "summary.json")).read()
+    for needle in ('"bc1_pos_counts": {', '"bc1_len_counts": {', '"bc1_score_counts": {', '"1":', '"2":', '"3":', '"4":',
+                   '"bc1_per_bc_pos_counts": {', '"bc1_per_bc_len_counts": {', '"bc1_per_bc_score_counts": {'):
+        assert needle in content, needle
+    run_obj = json.loads(content)[0]
+    assert run_obj["bc1_pos_counts"] == {"1": 3, "2": 1, "3": 1} and run_obj["bc1_len_counts"] == {"3": 2, "4": 3}
+    assert run_obj["bc1_score_counts"] == {"0.0": 3, "0.25": 2} and run_obj["bc1_per_bc_len_counts"] == {"1": {"3": 2, "4": 3}}
+    # ("AAAT" costs 1 either as a substitution or as AAA + one deleted base; the deletion wins the origin tie
+    # (classification.jl:310-321), so its length is 3 — the .jl comment "Len 4" is not what the code records)
 
 
 SCENARIOS_SMALL = [scenario_n_and_ranges, scenario_range_restrictions, scenario_dual, scenario_dual_trim,
