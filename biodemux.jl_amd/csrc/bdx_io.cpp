@@ -51,14 +51,106 @@ struct bdx_fq_file {
     std::condition_variable cv;
     std::string err;
     double avg_record = 330.0;    // bytes per record, learned from the batches indexed so far
+    bool parallel_members = false;  // the input was a size-tagged member chain inflated block-parallel
 };
+
 
 static thread_local std::string g_io_err;
 const char *bdx_io_last_error(void) { return g_io_err.c_str(); }
 
+// Compressed size of the gzip member that starts at c[0] if its header says so: BGZF ('B','C': 16-bit total
+// size - 1) or this library's own tag ('D','X': 32-bit total size).  0: untagged (a plain gzip stream).
+static size_t tagged_member_size(const uint8_t *c, size_t left) {
+    if (left < 18 || c[0] != 0x1f || c[1] != 0x8b || c[2] != 8 || !(c[3] & 4)) return 0;
+    const size_t xlen = (size_t)c[10] | ((size_t)c[11] << 8);
+    if (12 + xlen > left) return 0;
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+        const size_t len = (size_t)c[o + 2] | ((size_t)c[o + 3] << 8);
+        if (o + 4 + len > 12 + xlen) return 0;
+        if (c[o] == 'B' && c[o + 1] == 'C' && len == 2) return ((size_t)c[o + 4] | ((size_t)c[o + 5] << 8)) + 1;
+        if (c[o] == 'D' && c[o + 1] == 'X' && len == 4)
+            return (size_t)c[o + 4] | ((size_t)c[o + 5] << 8) | ((size_t)c[o + 6] << 16) | ((size_t)c[o + 7] << 24);
+        o += 4 + len;
+    }
+    return 0;
+}
+
+// Block-parallel inflate of a size-tagged member chain (BGZF or this library's own output): the members'
+// uncompressed sizes (ISIZE, the last 4 bytes of a member) give every member its place in the output, so T
+// threads inflate them independently; `avail` advances over the finished prefix.  Returns the bytes produced
+// and stops (`*stopped_at` = compressed offset) at the first member without a tag — the caller continues
+// there with the serial stream.  -1 on a corrupt member.
+static int64_t inflate_tagged_chain(bdx_fq_file *f, const uint8_t *comp, size_t csize, uint8_t *dst, size_t reserve,
+                                    int nthreads, size_t *stopped_at) {
+    struct Mem { size_t coff, clen, uoff, ulen; };
+    size_t coff = 0, uoff = 0;
+    int64_t result = 0;
+    const size_t WAVE = 4096;  // members walked, inflated and published per round (bounds the bookkeeping)
+    while (coff < csize && !f->cancel.load(std::memory_order_relaxed)) {
+        std::vector<Mem> ms;
+        while (coff < csize && ms.size() < WAVE) {
+            const size_t clen = tagged_member_size(comp + coff, csize - coff);
+            if (clen < 18 || coff + clen > csize) break;
+            const uint8_t *t = comp + coff + clen - 4;
+            const size_t ulen = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+            if (uoff + ulen + (1u << 22) > reserve) return -2;
+            ms.push_back(Mem{coff, clen, uoff, ulen});
+            coff += clen;
+            uoff += ulen;
+        }
+        if (ms.empty()) break;
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        std::vector<std::atomic<char>> done(ms.size());
+        for (auto &d : done) d.store(0);
+        std::mutex pub;
+        size_t published = 0;
+        const int T = std::max(1, std::min<int>(nthreads, (int)ms.size()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= ms.size() || bad.load() || f->cancel.load(std::memory_order_relaxed)) break;
+                    const Mem &m = ms[i];
+                    z_stream zs;
+                    memset(&zs, 0, sizeof(zs));
+                    if (inflateInit2(&zs, 15 + 16) != Z_OK) {
+                        bad.store(1);
+                        break;
+                    }
+                    zs.next_in = (Bytef *)(comp + m.coff);
+                    zs.avail_in = (uInt)m.clen;
+                    zs.next_out = dst + m.uoff;
+                    zs.avail_out = (uInt)m.ulen;
+                    const int rc = m.ulen ? inflate(&zs, Z_FINISH) : inflate(&zs, Z_FINISH);
+                    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 && zs.total_out == m.ulen;
+                    inflateEnd(&zs);
+                    if (!ok) {
+                        bad.store(1);
+                        break;
+                    }
+                    done[i].store(1, std::memory_order_release);
+                    std::lock_guard<std::mutex> lk(pub);  // advance `avail` over the finished prefix
+                    while (published < ms.size() && done[published].load(std::memory_order_acquire)) ++published;
+                    if (published > 0) {
+                        const Mem &l = ms[published - 1];
+                        f->avail.store((int64_t)(l.uoff + l.ulen), std::memory_order_release);
+                        f->cv.notify_all();
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+        if (bad.load()) return -1;
+        result = (int64_t)uoff;
+    }
+    *stopped_at = coff;
+    return result;
+}
+
 // Opens a FASTQ file: plain files are mmap'ed, ".gz" (case-insensitive, fileio.jl:78) is inflated
 // into memory with zlib.  Returns 0 on success.
-int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
+int32_t bdx_fq_open_mt(const char *path, int32_t nthreads_arg, bdx_fq_file **out) {
     *out = nullptr;
     auto *f = new bdx_fq_file();
     std::string p(path), low(p);
@@ -85,11 +177,49 @@ int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
         }
         f->data = (const uint8_t *)m;
         f->streaming = true;
-        f->inflater = std::thread([f, g, p]() {
+        const int nthreads = nthreads_arg > 0 ? nthreads_arg : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        f->inflater = std::thread([f, g0 = g, p, csize, nthreads]() {
+            gzFile g = g0;
             uint8_t *dst = (uint8_t *)f->data;
             size_t used = 0;
             int st = 1;
-            while (!f->cancel.load(std::memory_order_relaxed)) {
+            // size-tagged member chains (BGZF, this library's own .gz output) are inflated block-parallel;
+            // an untagged member (an ordinary gzip stream) — at the start or anywhere later — is read serially
+            if (csize > 0) {
+                int fd = open(p.c_str(), O_RDONLY);
+                void *cm = fd >= 0 ? mmap(nullptr, (size_t)csize, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+                if (fd >= 0) close(fd);
+                if (cm != MAP_FAILED) {
+                    size_t stopped = 0;
+                    const int64_t got = tagged_member_size((const uint8_t *)cm, (size_t)csize)
+                                            ? inflate_tagged_chain(f, (const uint8_t *)cm, (size_t)csize, dst, f->reserve, nthreads, &stopped)
+                                            : 0;
+                    munmap(cm, (size_t)csize);
+                    if (got < 0) {
+                        f->err = got == -2 ? "inflated size of " + p + " exceeds 64x its compressed size" : "corrupt gzip member in " + p;
+                        st = -1;
+                    } else {
+                        used = (size_t)got;
+                        f->parallel_members = got > 0;
+                        if (stopped >= (size_t)csize) {
+                            st = 2;  // everything was tagged: done
+                        } else if (stopped > 0) {
+                            // the rest is an ordinary gzip stream: a serial reader positioned at that member
+                            gzclose(g);
+                            int fd2 = open(p.c_str(), O_RDONLY);
+                            g = (fd2 >= 0 && lseek(fd2, (off_t)stopped, SEEK_SET) == (off_t)stopped) ? gzdopen(fd2, "rb") : nullptr;
+                            if (!g) {
+                                if (fd2 >= 0) close(fd2);
+                                f->err = "cannot continue reading " + p;
+                                st = -1;
+                            } else {
+                                gzbuffer(g, 1 << 20);
+                            }
+                        }
+                    }
+                }
+            }
+            while (st == 1 && !f->cancel.load(std::memory_order_relaxed)) {
                 if (f->reserve - used < (1u << 22)) {
                     f->err = "inflated size of " + p + " exceeds 64x its compressed size";
                     st = -1;
@@ -106,7 +236,8 @@ int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
                 f->avail.store((int64_t)used, std::memory_order_release);
                 f->cv.notify_all();
             }
-            gzclose(g);
+            if (g) gzclose(g);
+            if (st == 2) st = 1;
             {
                 std::lock_guard<std::mutex> lk(f->mu);
                 f->size = (int64_t)used;
@@ -147,6 +278,8 @@ int32_t bdx_fq_open(const char *path, bdx_fq_file **out) {
     return 0;
 }
 
+int32_t bdx_fq_open(const char *path, bdx_fq_file **out) { return bdx_fq_open_mt(path, 0, out); }
+
 void bdx_fq_close(bdx_fq_file *f) {
     if (!f) return;
     if (f->streaming) {
@@ -174,6 +307,13 @@ static int64_t wait_available(bdx_fq_file *f, int64_t target, bool *final, bool 
     *final = st != 0;
     *failed = st < 0;
     return st != 0 ? f->size : f->avail.load(std::memory_order_acquire);
+}
+
+// 1 when the .gz input turned out to be a size-tagged member chain that was inflated block-parallel
+int32_t bdx_fq_parallel_inflate(bdx_fq_file *f) {
+    bool fin, bad;
+    (void)wait_available(f, INT64_MAX, &fin, &bad);
+    return f->parallel_members ? 1 : 0;
 }
 
 const uint8_t *bdx_fq_data(const bdx_fq_file *f) { return f->data; }
@@ -430,6 +570,16 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
                         mb.bad = 1;
                         continue;
                     }
+                    // Every member carries its own compressed size in a gzip "extra" subfield ('D','X', 4 bytes LE;
+                    // the BGZF idea with a 32-bit size): any gzip reader skips it, bdx_fq_open uses it to walk
+                    // the member chain and inflate the members in parallel.
+                    static unsigned char extra[8] = {'D', 'X', 4, 0, 0, 0, 0, 0};
+                    gz_header hd;
+                    memset(&hd, 0, sizeof(hd));
+                    hd.os = 255;
+                    hd.extra = extra;
+                    hd.extra_len = 8;
+                    deflateSetHeader(&zs, &hd);
                     mb.out.resize(deflateBound(&zs, (uLong)mb.len) + 64);
                     zs.next_in = (Bytef *)(bufs[todo[mb.k]].data() + mb.off);
                     zs.avail_in = (uInt)mb.len;
@@ -438,6 +588,13 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
                     if (deflate(&zs, Z_FINISH) != Z_STREAM_END) mb.bad = 1;
                     mb.out.resize(mb.out.size() - zs.avail_out);
                     deflateEnd(&zs);
+                    // header: 10 fixed bytes, XLEN (2), then the subfield SI1 SI2 LEN(2) DATA(4) -> data at 16..19
+                    if (!mb.bad && mb.out.size() >= 20 && (mb.out[3] & 4) && mb.out[12] == 'D' && mb.out[13] == 'X') {
+                        const uint32_t cs = (uint32_t)mb.out.size();
+                        for (int b = 0; b < 4; ++b) mb.out[16 + b] = (uint8_t)(cs >> (8 * b));
+                    } else {
+                        mb.bad = 1;
+                    }
                 }
             });
         for (auto &t : th) t.join();

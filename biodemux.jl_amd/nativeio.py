@@ -40,6 +40,10 @@ def _load():
         L.bdx_io_last_error.restype = C.c_char_p
         L.bdx_fq_open.restype = C.c_int32
         L.bdx_fq_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.bdx_fq_open_mt.restype = C.c_int32
+        L.bdx_fq_open_mt.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+        L.bdx_fq_parallel_inflate.restype = C.c_int32
+        L.bdx_fq_parallel_inflate.argtypes = [vp]
         L.bdx_fq_close.restype = None
         L.bdx_fq_close.argtypes = [vp]
         L.bdx_fq_size.restype = C.c_int64
@@ -71,10 +75,12 @@ def _threads() -> int:
 
 
 class FastqFile:
-    def __init__(self, path: str):
+    def __init__(self, path: str, nthreads: int = 0):
+        """``nthreads``: inflate threads for size-tagged .gz member chains (BGZF, this library's own output);
+        0 = one per available core (at most 16).  Ordinary gzip streams are inflated by one thread."""
         self.L = _load()
         h = C.c_void_p()
-        if self.L.bdx_fq_open(path.encode(), C.byref(h)) != 0:
+        if self.L.bdx_fq_open_mt(path.encode(), int(nthreads), C.byref(h)) != 0:
             raise OSError(self.L.bdx_io_last_error().decode())
         self.h = h
         self.cursor = 0
@@ -83,6 +89,11 @@ class FastqFile:
     def size(self) -> int:
         """Total bytes (a .gz input is inflated in the background: this waits for the end of the stream)."""
         return int(self.L.bdx_fq_size(self.h))
+
+    @property
+    def parallel_inflate(self) -> bool:
+        """True when the .gz input was a size-tagged member chain inflated block-parallel (waits for the end)."""
+        return bool(self.L.bdx_fq_parallel_inflate(self.h))
 
     def release(self, upto: int) -> None:
         """Records below byte `upto` are written out: a streamed .gz input gives their pages back."""

@@ -120,3 +120,86 @@ def test_streamed_gzip_pairs_and_errors(tmp_path):
     open(bad, "wb").write(blob[:len(blob) // 2] + b"\x00" * 64 + blob[len(blob) // 2 + 64:])
     with pytest.raises(OSError):
         run_nat(bad, str(bc), str(tmp_path / "bad_out"), _batch_reads=100)
+
+
+# ---- block-parallel inflate of size-tagged member chains ----
+def _bgzf(data: bytes, block: int = 60000) -> bytes:
+    """BGZF (bgzip) framing: gzip members of <= 64 KiB whose extra subfield 'BC' holds the member size - 1."""
+    import struct
+    import zlib
+
+    out = []
+    for o in list(range(0, len(data), block)) + [None]:  # + the empty EOF block bgzip appends
+        chunk = data[o:o + block] if o is not None else b""
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+def _case(tmp_path, n=30000):
+    bcs = synth.make_barcodes(8, 12, seed=17, min_hamming=4)
+    seq, off, _ = synth.make_ragged_reads(bcs, n, 20, 90, seed=17)
+    seqs = [seq[off[i]:off[i + 1]].tobytes() for i in range(n)]
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    return seqs, str(bc)
+
+
+@pytest.mark.parametrize("kind", ["bgzf", "own_writer", "tagged_then_plain", "plain"])
+def test_parallel_inflate_of_tagged_members(tmp_path, kind):
+    """BGZF input and this library's own .gz output (members tagged with their compressed size) are inflated
+    block-parallel; an ordinary gzip stream — also one that FOLLOWS tagged members in the same file — is read
+    serially from where the chain ends.  The demultiplexed files are the same whatever the framing."""
+    seqs, bc = _case(tmp_path)
+    plain = str(tmp_path / "reads.fastq")
+    _fastq(plain, seqs)
+    raw = open(plain, "rb").read()
+    fq = str(tmp_path / "framed.fastq.gz")
+    if kind == "bgzf":
+        open(fq, "wb").write(_bgzf(raw))
+    elif kind == "plain":
+        open(fq, "wb").write(gzip.compress(raw, 1))
+    else:
+        # this library's writer: demultiplex with gzip output, then feed the largest of ITS outputs back in
+        d0 = str(tmp_path / "first")
+        run_nat(plain, bc, d0, max_error_rate=0.2, gzip_output=True, _batch_reads=7000)
+        big = max((os.path.join(d0, n) for n in os.listdir(d0)), key=os.path.getsize)
+        raw = gzip.open(big, "rb").read()
+        blob = open(big, "rb").read()
+        assert blob.count(b"DX\x04\x00") >= 4  # several members (one per 7000-read batch), each tagged
+        if kind == "tagged_then_plain":
+            extra = b"@tail\nACGTACGTAC\n+\nFFFFFFFFFF\n" * 50
+            blob += gzip.compress(extra, 6)
+            raw += extra
+        open(fq, "wb").write(blob)
+        plain = str(tmp_path / "again.fastq")
+        open(plain, "wb").write(raw)
+    assert gzip.open(fq, "rb").read() == raw  # any gzip reader accepts the framing
+    for T in (1, 5):
+        f = nativeio.FastqFile(fq, T)
+        try:
+            assert f.size == len(raw)
+            assert f.parallel_inflate == (kind != "plain")
+        finally:
+            f.close()
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    run_nat(fq, bc, a, max_error_rate=0.2, gzip_output=False, _batch_reads=9000, output_prefix="p")
+    run_py(plain, bc, b, max_error_rate=0.2, output_prefix="p")
+    _same_tree(a, b)
+
+
+def test_parallel_inflate_rejects_a_corrupt_member(tmp_path):
+    from biodemux_jl_amd import nativeio
+
+    blob = bytearray(_bgzf(b"@r\nACGT\n+\nFFFF\n" * 20000))
+    blob[len(blob) // 2] ^= 0x55
+    fq = str(tmp_path / "bad.fastq.gz")
+    open(fq, "wb").write(bytes(blob))
+    f = nativeio.FastqFile(fq, 4)
+    try:
+        assert f.size == -1
+    finally:
+        f.close()
