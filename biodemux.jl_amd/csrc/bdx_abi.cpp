@@ -41,6 +41,7 @@ BdxTuning read_tuning() {
     t.no_windows = getenv("BDX_NO_WINDOWS") != nullptr;
     t.no_slot = getenv("BDX_NO_SLOT") != nullptr;
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
+    t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     if (const char *e = getenv("BDX_BITPAR_R")) t.bitpar_r = atoi(e);
     if (const char *e = getenv("BDX_GRID")) t.grid = atoll(e);
     if (const char *e = getenv("BDX_DIAG_MIN_B")) t.diag_min_b = atoi(e);
@@ -101,11 +102,27 @@ int plan_generic(bdx_ctx *ctx) {
                 d.max_m, per_thread);
 }
 
+// ---- tiered budgets --------------------------------------------------------------------------
+// Single q-gram seeds are only selective when a barcode's kb + 1 pieces keep >= 8 bases (C2: kb = 2 on 24 nt).
+// The reference's default rate 0.2 allows kb = 4 there, which needs the much costlier two-intact-pieces
+// filter — although nearly every read that carries a barcode carries it with 0..2 errors.  Tier 1 therefore
+// filters with budgets CAPPED at kb1 = m / 8 - 1: it finds, losslessly, every barcode within kb1 operations
+// (exact unit distances).  Both reducers of the reference only ever look at the smallest (and second
+// smallest) score, so whenever tier 1 finds a barcode and no barcode it cannot see could tie or beat it
+// (bdx_bitpar.hip, "tier settle rule"), the read's verdict is final; only the other reads — those without a
+// barcode, or with one beyond kb1 — are filtered again at the full budget (tier 0, in list mode).
+long long tier_cap(const bdx_ctx *ctx, int m) {
+    if (ctx->cur == 0) return (1LL << 40);
+    const int c = m / 8 - 1;
+    return c > 0 ? c : 0;
+}
+
 // ---- bit-parallel pre-filter: eligibility and tables (see bdx_bitpar.hip for the argument) ----
 int build_bitpar_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
-    BdxBitparPlan &bp = ctx->bplan;
+    BdxBitparPlan &bp = ctx->F().bplan;
     bp = BdxBitparPlan{};
+    bp.tier_slo[0] = bp.tier_slo[1] = HUGE_VAL;
     if (c.filter == BDX_FILTER_OFF) return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     // cost domain: every edit operation must cost >= 1 and a match >= 0
@@ -185,12 +202,23 @@ int build_bitpar_tables(bdx_ctx *ctx) {
                 ae = (long long)std::floor(c.max_error_rate * (double)m);
             else
                 ae = (long long)std::floor(c.max_error_rate * (double)(c.has_nindel ? p.bc_len_no_N[b] : m));
-            kb[b] = ae < 0 ? -1 : (int32_t)(ae / cmin);
+            long long kfull = ae < 0 ? -1 : ae / cmin;
+            long long kcap = kfull;
+            if (kcap > tier_cap(ctx, m)) kcap = tier_cap(ctx, m);
+            kb[b] = (int32_t)kcap;
+            if (kcap < kfull) {
+                // the smallest score a barcode tier 1 cannot see may have: (kb1 + 1) operations of cost >= cmin
+                // each, over this barcode's normalisation (computed as the device computes a score)
+                const double norm = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) ? (double)p.bc_len_no_N[b] : (double)m;
+                const double lo = (double)((kcap + 1) * cmin) / norm;
+                if (lo < bp.tier_slo[k]) bp.tier_slo[k] = lo;
+                bp.tier_capped = 1;
+            }
         }
     }
-    HIP_TRY(ctx, ctx->bp_tables.ensure(bytes));
-    HIP_TRY(ctx, hipMemcpy(ctx->bp_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
-    const uint8_t *base = (const uint8_t *)ctx->bp_tables.p;
+    HIP_TRY(ctx, ctx->F().bp_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->F().bp_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)ctx->F().bp_tables.p;
     bp.d_lut = base;
     for (int k = 0; k < npass; ++k) {
         bp.d_peq[k] = (const uint32_t *)(base + o_peq[k]);
@@ -217,10 +245,10 @@ int build_bitpar_tables(bdx_ctx *ctx) {
 // bytes may alias — that only adds sweeps, never removes one.
 int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
     const bdx_config_t &c = ctx->cfg;
-    BdxSeedPlan &sp = alt ? ctx->splan_alt : ctx->splan;
-    DevBuf &tables = alt ? ctx->seed_tables_alt : ctx->seed_tables;
+    BdxSeedPlan &sp = alt ? ctx->F().splan_alt : ctx->F().splan;
+    DevBuf &tables = alt ? ctx->F().seed_tables_alt : ctx->F().seed_tables;
     sp = BdxSeedPlan{};
-    if (!ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed) return BDX_OK;
+    if (!ctx->F().bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed) return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;
     if (c.algorithm == BDX_ALG_SEMIGLOBAL) {
@@ -253,7 +281,8 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
             else if (c.algorithm == BDX_ALG_HAMMING) ae = (long long)std::floor(c.max_error_rate * (double)m);
             else ae = (long long)std::floor(c.max_error_rate * (double)(c.has_nindel ? p.bc_len_no_N[b] : m));
             if (ae < 0) continue;  // can never be recorded: neither seeded nor swept
-            const long long kb = ae / cmin;
+            long long kb = ae / cmin;
+            if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
             bool wild = false;
             for (int i = 0; i < m; ++i) wild |= n_wild && p.bc_bytes[p.bc_off[b] + i] == 'N';
             const long long L = m / (kb + 1);
@@ -348,8 +377,8 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
 // single-piece seeds: it only skips pairs whose unit distance exceeds kb.
 int build_diag_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
-    BdxSeedPlan &sp = ctx->splan;
-    if (sp.enabled || !ctx->bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag)
+    BdxSeedPlan &sp = ctx->F().splan;
+    if (sp.enabled || !ctx->F().bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag)
         return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;
@@ -437,9 +466,9 @@ int build_diag_tables(bdx_ctx *ctx) {
         if (!keys[k].empty()) memcpy(blob.data() + o_keys[k], keys[k].data(), keys[k].size() * 4);
         if (!always[k].empty()) memcpy(blob.data() + o_always[k], always[k].data(), always[k].size() * 2);
     }
-    HIP_TRY(ctx, ctx->seed_tables.ensure(bytes));
-    HIP_TRY(ctx, hipMemcpy(ctx->seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
-    const uint8_t *base = (const uint8_t *)ctx->seed_tables.p;
+    HIP_TRY(ctx, ctx->F().seed_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->F().seed_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)ctx->F().seed_tables.p;
     sp = BdxSeedPlan{};
     sp.diag_flag_coef = coef_keep;
     for (int k = 0; k < 2; ++k) {
@@ -458,14 +487,15 @@ int build_diag_tables(bdx_ctx *ctx) {
 
 // Geometry of the fused kernel for a given typical read length: the largest R whose LDS
 // footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
-bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
-    BdxBitparPlan &bp = ctx->bplan;
+// force_slot: list mode (tier 0 of the tiered budgets) — the reads are scattered, every read is staged into a slot
+bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads, bool force_slot = false) {
+    BdxBitparPlan &bp = ctx->F().bplan;
     if (!bp.enabled) return false;
     if (read_len < 1) read_len = 1;
     // small batches: keep >= ~1024 tiles in flight (4 per CU) before growing the tile
     int r_cap = 256;
     while (r_cap > 16 && n_reads / r_cap < 1024) r_cap >>= 1;
-    if (bp.read_len_hint == read_len && bp.r_cap == r_cap && bp.reads_per_block > 0) return true;
+    if (bp.read_len_hint == read_len && bp.r_cap == r_cap && bp.reads_per_block > 0 && (bp.slot_bytes > 0 || !force_slot)) return true;
     bp.r_cap = r_cap;
     const int forced = ctx->tune.bitpar_r;
     // Pick the R that keeps the most waves resident per CU (the sweep is latency-bound):
@@ -510,38 +540,38 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         if (uhi > ulo) wmax = (int)(uhi - ulo);
         else wmax = 16;
     }
-    const bool slot_mode = (long long)wmax * 2 + 96 <= (long long)read_len && !ctx->tune.no_slot;
+    const bool slot_mode = force_slot || ((long long)wmax * 2 + 96 <= (long long)read_len && !ctx->tune.no_slot);
     const int slot = slot_mode ? ((wmax + 15 + 16 + 15) & ~15) : 0;
     bp.slot_bytes = slot;
     bp.seed_span = slot_mode ? wmax : read_len;
-    if (ctx->splan.enabled && ctx->splan.diag) {
+    if (ctx->F().splan.enabled && ctx->F().splan.diag) {
         // index width for this read length, and the sweep queue for the expected number of flagged pairs
         if (bp.seed_span > 312) {  // the widest index holds 320 positions: weak single seeds if they apply, else the plain sweep
-            ctx->splan = ctx->splan_alt;  // (disabled if weak seeds do not apply either)
-            ctx->splan_alt = BdxSeedPlan{};
-            return size_bitpar(ctx, read_len, n_reads);
+            ctx->F().splan = ctx->F().splan_alt;  // (disabled if weak seeds do not apply either)
+            ctx->F().splan_alt = BdxSeedPlan{};
+            return size_bitpar(ctx, read_len, n_reads, force_slot);
         }
         bp.diag_nw = bp.seed_span <= 152 ? 5 : 10;
         const double L = (double)(bp.seed_span < 32 ? 32 : bp.seed_span);
-        const double flagged = ctx->splan.diag_flag_coef * ((L - 3.0) / 256.0) * ((L - 3.0) / 256.0) / (L + 24.0) +
-                               (double)(ctx->splan.n_always[0] + ctx->splan.n_always[1]);
+        const double flagged = ctx->F().splan.diag_flag_coef * ((L - 3.0) / 256.0) * ((L - 3.0) / 256.0) / (L + 24.0) +
+                               (double)(ctx->F().splan.n_always[0] + ctx->F().splan.n_always[1]);
         bp.diag_qcap = (int)(flagged * 1.3) + 12;  // per read (a sub-batch shares 4..8 reads' worth)
     }
-    const bool diag = ctx->splan.enabled && ctx->splan.diag;
+    const bool diag = ctx->F().splan.enabled && ctx->F().splan.diag;
     const int tries[7] = {256, 128, 64, 32, 16, 8, 4};
     int best_R = 0, best_blocks = 0, best_stage = 0;
     for (int R : tries) {
         if (diag ? R > 32 : R < 16) continue;  // the diagonal variant indexes 8 reads at a time (40 KiB): small tiles
         if (forced && R != forced) continue;
         if (!forced && R > r_cap) continue;
-        if (!forced && !ctx->splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
+        if (!forced && !ctx->F().splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
         size_t st = slot_mode ? (size_t)R * (size_t)slot : (size_t)R * (size_t)read_len + 64;
         st = (st + 15) & ~(size_t)15;
         if (st > (size_t)1 << 20) continue;
         bp.reads_per_block = R;
         bp.stage_bytes = (int)st;
         bp.read_len_hint_for_lds = read_len;
-        const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->splan);
+        const size_t lds = bdx_bitpar_lds_bytes(ctx->dev, bp, ctx->plan, &ctx->F().splan);
         if (lds > LDS_MAX) continue;
         int blocks = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));  // LDS is allocated in 1280-byte granules (measured: 54128 B -> 2 per CU, 51872 B -> 3)
         // Measured on MI355X (tools/probe.py): tile size matters more than residency once 3
@@ -558,9 +588,9 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
     if (best_R && diag && best_blocks < 2) {
         // the index leaves room for one workgroup per CU only (very many barcodes): weak single seeds if they
         // apply, else the plain sweep
-        ctx->splan = ctx->splan_alt;  // (disabled if weak seeds do not apply either)
-        ctx->splan_alt = BdxSeedPlan{};
-        return size_bitpar(ctx, read_len, n_reads);
+        ctx->F().splan = ctx->F().splan_alt;  // (disabled if weak seeds do not apply either)
+        ctx->F().splan_alt = BdxSeedPlan{};
+        return size_bitpar(ctx, read_len, n_reads, force_slot);
     }
     if (best_R) {
         bp.reads_per_block = best_R;
@@ -569,11 +599,11 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads) {
         bp.read_len_hint_for_lds = read_len;
         return true;
     }
-    if (ctx->splan.enabled) {
+    if (ctx->F().splan.enabled) {
         // the seed tables do not fit next to everything else (very many barcodes): keep the
         // sweep filter, drop the seeds, and plan again
-        ctx->splan.enabled = 0;
-        return size_bitpar(ctx, read_len, n_reads);
+        ctx->F().splan.enabled = 0;
+        return size_bitpar(ctx, read_len, n_reads, force_slot);
     }
     bp.reads_per_block = 0;
     bp.read_len_hint = 0;
@@ -804,17 +834,33 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = build_diag_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
-    if (!ctx->splan.enabled) {  // neither: moderately selective single seeds still beat sweeping every pair
+    if (!ctx->F().splan.enabled) {  // neither: moderately selective single seeds still beat sweeping every pair
         rc = build_seed_tables(ctx, false);
         if (rc != BDX_OK) return bail(rc);
-    } else if (ctx->splan.diag) {  // the fallback of size_bitpar when the index does not fit a batch
+    } else if (ctx->F().splan.diag) {  // the fallback of size_bitpar when the index does not fit a batch
         rc = build_seed_tables(ctx, false, true);
         if (rc != BDX_OK) return bail(rc);
     }
-    ctx->path = ctx->bplan.enabled ? (ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
-    ctx->filter_used = ctx->bplan.enabled ? (ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
-    if (ctx->bplan.enabled) {
-        if (ctx->d_maxlen.ensure(256) != hipSuccess) {
+    // tier 1 (capped budgets, strict single seeds) beside a full-budget set that is NOT already strict single seeds
+    {
+        const BdxFilterSet &full = ctx->fs[0];
+        const bool strict_full = full.splan.enabled && !full.splan.diag && full.splan.q >= 7;
+        bool all_known = full.bplan.enabled != 0;
+        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) all_known = all_known && full.bplan.known_ok[k];
+        if (full.bplan.enabled && all_known && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
+            ctx->cur = 1;
+            rc = build_bitpar_tables(ctx);
+            if (rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped) rc = build_seed_tables(ctx, true);
+            ctx->cur = 0;
+            if (rc != BDX_OK) return bail(rc);
+            ctx->tiered = ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped && ctx->fs[1].splan.enabled;
+        }
+    }
+    ctx->path = ctx->F().bplan.enabled ? (ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
+    if (ctx->tiered) ctx->path = "tier1:qgram+bitpar > " + ctx->path;
+    ctx->filter_used = ctx->F().bplan.enabled ? (ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
+    if (ctx->F().bplan.enabled) {
+        if (ctx->d_maxlen.ensure(1024) != hipSuccess) {
             ctx->err = "hipMalloc failed";
             return bail(BDX_E_DEVICE);
         }
@@ -849,9 +895,12 @@ void bdx_destroy(bdx_ctx *ctx) {
         ctx->d_wcnt[k].release();
     }
     ctx->counts_own.release();
-    ctx->bp_tables.release();
-    ctx->seed_tables.release();
-    ctx->seed_tables_alt.release();
+    for (BdxFilterSet &f : ctx->fs) {
+        f.bp_tables.release();
+        f.seed_tables.release();
+        f.seed_tables_alt.release();
+    }
+    ctx->d_tier.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
     ctx->d_seq.release();
@@ -910,7 +959,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     int measured_len = -1;
     if (ctx->dev.need_traceback) {
         // statistics tables are sized from the batch's true maximum read length (a hint is only a hint)
-        HIP_TRY(ctx, ctx->d_maxlen.ensure(256));
+        HIP_TRY(ctx, ctx->d_maxlen.ensure(1024));
         HIP_TRY(ctx, bdx_launch_maxlen((const long long *)d_seq_off, n_reads, (int *)ctx->d_maxlen.p, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(&measured_len, ctx->d_maxlen.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -928,7 +977,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         stp = &st;
     }
     bool filtered = false;
-    if (ctx->bplan.enabled) {
+    int tier_len = 0;  // > 0: tiered budgets apply to this batch (the read length both tiers were planned for)
+    if (ctx->F().bplan.enabled) {
         int len = ctx->user_len_hint;
         if (len <= 0 && measured_len >= 0) len = measured_len > 0 ? measured_len : 1;
         if (len <= 0) {  // measure the batch: one tiny kernel + a 4-byte copy
@@ -939,20 +989,28 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             len = host_len;
         }
         filtered = size_bitpar(ctx, len, n_reads);
+        if (filtered && ctx->tiered) {  // both tiers must be plannable for this batch, else the full budget alone
+            ctx->cur = 1;
+            const bool ok1 = size_bitpar(ctx, len, n_reads);
+            ctx->cur = 0;
+            tier_len = ok1 ? len : 0;
+        }
     }
     if (filtered) {
-        ctx->bplan.d_tile_counter = (int *)((char *)ctx->d_maxlen.p + 64);
-        ctx->bplan.grid_override = ctx->tune.grid;
-        ctx->bplan.dbg = ctx->tune.debug;
         // The fused kernel filters; the exact DP runs at full width in the generic kernel:
         //  * split (trimming / summary / weighted costs / N-scoring / Hamming / exact): every read's
         //    candidate mask (+ column windows) goes through HBM, the generic kernel gives every verdict;
         //  * known-score configs: the fused kernel also gives the verdict of (nearly) every read by
         //    replaying the reducer; the few it cannot settle are listed and evaluated by the generic
-        //    kernel in list mode.
+        //    kernel in list mode;
+        //  * tiered budgets (known-score configs whose full budget is too large for selective single seeds):
+        //    tier 1 — capped budgets, single seeds — runs over the whole batch and settles every read whose
+        //    verdict cannot depend on a barcode beyond the cap; tier 0 — the full budget — then runs in list
+        //    mode over the rest.
         const int npass = ctx->dev.is_dual ? 2 : 1;
         bool split = false;
-        for (int k = 0; k < npass; ++k) split |= !ctx->bplan.known_ok[k];
+        for (int k = 0; k < npass; ++k) split |= !ctx->F().bplan.known_ok[k];
+        const bool tiered = tier_len > 0 && !split;
         if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
@@ -972,17 +1030,38 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             w1 = npass > 1 ? (uint32_t *)ctx->d_wins[1].p : w0;
             n1 = npass > 1 ? (uint8_t *)ctx->d_wcnt[1].p : n0;
         }
+        // scratch words (d_maxlen, 1 KiB): +64 tile queue, +128 hand-over count (+132.. tuning statistics),
+        // +192 tier-0 list length, +256 tile queue of the second launch; one memset clears them all
+        char *scratch = (char *)ctx->d_maxlen.p;
         uint32_t *exc_list = nullptr;
-        unsigned int *exc_count = (unsigned int *)((char *)ctx->d_maxlen.p + 128);
+        unsigned int *exc_count = (unsigned int *)(scratch + 128);
         if (!split) {
             HIP_TRY(ctx, ctx->d_exc.ensure((size_t)n_reads * 4 + 64));
             exc_list = (uint32_t *)ctx->d_exc.p;
         }
-        // one memset clears the tile queue head (+64) and the hand-over count (+128)
-        HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_maxlen.p + 64, 0, 128, ctx->stream));
-        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->bplan, ctx->splan, d_seq_bytes,
+        HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
+        BdxTierArgs t0{0, nullptr, nullptr, nullptr, nullptr};
+        if (tiered) {
+            HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
+            BdxTierArgs t1{1, (uint32_t *)ctx->d_tier.p, (unsigned int *)(scratch + 192), nullptr, nullptr};
+            BdxFilterSet &f1 = ctx->fs[1];
+            f1.bplan.d_tile_counter = (int *)(scratch + 256);
+            f1.bplan.grid_override = ctx->tune.grid;
+            f1.bplan.dbg = ctx->tune.debug;
+            HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
+                                           o, ctx->counts, c0, c1, ctx->stream, nullptr, nullptr, nullptr, nullptr, 0, exc_list,
+                                           exc_count, &t1));
+            // tier 0 walks the list: scattered reads -> slot staging
+            if (!size_bitpar(ctx, tier_len, n_reads, true)) return fail(ctx, BDX_E_DEVICE, "internal: tier 0 cannot be planned in list mode");
+            t0.in_list = (const uint32_t *)ctx->d_tier.p;
+            t0.in_count = (const unsigned int *)(scratch + 192);
+        }
+        ctx->F().bplan.d_tile_counter = (int *)(scratch + 64);
+        ctx->F().bplan.grid_override = ctx->tune.grid;
+        ctx->F().bplan.dbg = ctx->tune.debug;
+        HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
-                                       n1, split ? 1 : 0, exc_list, exc_count));
+                                       n1, split ? 1 : 0, exc_list, exc_count, tiered ? &t0 : nullptr));
         if (split)
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
@@ -993,16 +1072,18 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                                             nullptr, exc_list, exc_count, stp));
 #ifdef BDX_TUNING
         if (ctx->tune.debug & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
-                unsigned int st[4] = {0, 0, 0, 0};
+                unsigned int st[4] = {0, 0, 0, 0}, tl = 0;
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 HIP_TRY(ctx, hipMemcpy(st, exc_count, sizeof(st), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[bdx] handed over %u reads; %u windowed sweeps, %u columns, %u tiles with a fallback read (of %lld reads)\n",
-                        st[0], st[1], st[2], st[3], (long long)n_reads);
+                HIP_TRY(ctx, hipMemcpy(&tl, scratch + 192, sizeof(tl), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[bdx] handed over %u reads; %u windowed sweeps, %u columns, %u tiles with a fallback read; tier 0 list %u (of %lld reads)\n",
+                        st[0], st[1], st[2], st[3], tl, (long long)n_reads);
         }
 #endif
-        ctx->last_blocks = (n_reads + ctx->bplan.reads_per_block - 1) / ctx->bplan.reads_per_block;
-        ctx->path = ctx->splan.enabled ? (ctx->splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
-        ctx->filter_used = ctx->splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
+        ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
+        ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
+        if (tiered) ctx->path = "tier1:qgram+bitpar > " + ctx->path;
+        ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                         ctx->counts, nullptr, nullptr, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -1144,11 +1225,11 @@ const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str()
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;
-    const bool f = ctx->filter_used != BDX_FILTER_OFF && ctx->bplan.reads_per_block > 0;
+    const bool f = ctx->filter_used != BDX_FILTER_OFF && ctx->F().bplan.reads_per_block > 0;
     out->threads_per_block = f ? 256 : ctx->plan.threads;
-    out->lds_bytes_per_block = f ? (int32_t)bdx_bitpar_lds_bytes(ctx->dev, ctx->bplan, ctx->plan, &ctx->splan) : (int32_t)ctx->plan.lds_bytes;
+    out->lds_bytes_per_block = f ? (int32_t)bdx_bitpar_lds_bytes(ctx->dev, ctx->F().bplan, ctx->plan, &ctx->F().splan) : (int32_t)ctx->plan.lds_bytes;
     out->blocks = ctx->last_blocks;
-    out->reads_per_block = f ? ctx->bplan.reads_per_block : ctx->plan.threads;
+    out->reads_per_block = f ? ctx->F().bplan.reads_per_block : ctx->plan.threads;
     out->filter_used = ctx->filter_used;
     out->max_m = ctx->dev.max_m;
     out->launches = ctx->launches;

@@ -69,6 +69,14 @@ struct BitparArgs {
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
+    // tiered budgets (bdx_abi.cpp): tier 1 appends the reads it cannot settle to tier_list; tier 0 then runs in
+    // LIST MODE over exactly those reads (in_list / *in_count; slot staging, as the reads are scattered)
+    int tier;                      // 1: this launch is tier 1 (capped budgets)
+    double tier_slo[2];            //   per pass: smallest score of a barcode beyond its capped budget
+    uint32_t *tier_list;
+    unsigned int *tier_count;
+    const uint32_t *in_list;
+    const unsigned int *in_count;
     int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a
               // skip bit is set: 1 skip stage 2, 2 skip sweeps, 4 skip hit resolve, 8 skip seed scan, 32 skip
               // transcode, 64 skip copy; 128 = sweep statistics (results stay correct)
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *cand = (LDS uint32_t *)take((size_t)R * (cw0 + cw1) * 4);
     LDS int *roff = (LDS int *)take((size_t)(R + 1) * 4);   // stage offset of base 1 of each read (may precede its slot)
     LDS int *rlen = (LDS int *)take((size_t)R * 4);         // read length n
+    LDS uint32_t *rids = (LDS uint32_t *)take((size_t)R * 4);  // index of each read in the batch (list mode: from the list)
     LDS int *wlo = (LDS int *)take((size_t)R * 4);          // first staged base (0-based) of each read
     LDS int *wlen = (LDS int *)take((size_t)R * 4);         // staged bases of each read
     LDS int *win = (LDS int *)take((size_t)R * 4 * 4);      // [pass][first|last][R]
@@ -197,7 +206,13 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     // ---- persistent workgroup: the tables above are loaded once, then the workgroup walks
     // tiles of R consecutive reads (tile = blockIdx.x, + gridDim.x, ...).  Tiles are independent;
     // nothing is exchanged between workgroups, so no placement or ordering is assumed. ----
-    const long long ntiles = (a.n_reads + R - 1) / R;
+    const bool lm = a.in_list != nullptr;  // list mode: the reads named by in_list[0 .. *in_count)
+    long long n_eff = a.n_reads;
+    if (lm) {
+        const long long c = (long long)*a.in_count;
+        n_eff = c < a.n_reads ? c : a.n_reads;
+    }
+    const long long ntiles = (n_eff + R - 1) / R;
     // the tile queue is read one tile ahead: the returning atomic's L2 round trip (1-3 us) overlaps
     // the current tile's work instead of heading every tile (each workgroup over-fetches one index)
     int next_tile = 0;
@@ -236,9 +251,9 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         if (tid < 2) sqn[tid] = 0;
     }
     // ---- this tile's reads [r0, r1): one contiguous span of the packed batch ----
-    const long long r0 = tile * R;
+    const long long r0 = tile * R;  // (list mode: a position in the list)
     long long r1 = r0 + R;
-    if (r1 > a.n_reads) r1 = a.n_reads;
+    if (r1 > n_eff) r1 = n_eff;
     const int nr = (int)(r1 - r0);
     // Two staging modes (chosen on the host from the config's ranges and the read-length hint):
     //  * flat: the tile's reads are one contiguous span of the batch -> one coalesced copy;
@@ -247,8 +262,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     //    union of its pass windows, so HBM traffic and LDS follow the window, not the read.
     const int slot = a.slot_bytes;
     const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
-    const long long span0 = a.off[r0];
-    const long long span1 = a.off[r1];
+    const long long span0 = lm ? 0 : a.off[r0];  // (list mode always stages per-read slots)
+    const long long span1 = lm ? 0 : a.off[r1];
     const uintptr_t g0 = (uintptr_t)(a.seq + span0);
     const uintptr_t g0a = g0 & ~(uintptr_t)15;
     const int head = (int)(g0 - g0a);
@@ -262,8 +277,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
     // per-read lengths, stage offsets and column windows of both passes
     for (int t = ltid; t < nr; t += BS) {
-        const long long ro = a.off[r0 + t];
-        const long long rn = a.off[r0 + t + 1] - ro;
+        const long long rid = lm ? (long long)a.in_list[r0 + t] : r0 + t;
+        rids[t] = (uint32_t)rid;
+        const long long ro = a.off[rid];
+        const long long rn = a.off[rid + 1] - ro;
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
         rlen[t] = n;
         int ulo = 0x7FFFFFFF, uhi = 0;
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int r = idx / cpr, k = idx - r * cpr;
                 const int hd = roff[r] - r * slot + wlo[r];
                 if (16 * k < wlen[r] + hd) {
-                    const uintptr_t src = ((uintptr_t)(a.seq + a.off[r0 + r] + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
+                    const uintptr_t src = ((uintptr_t)(a.seq + a.off[rids[r]] + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
                     *(LDS u32x4 *)(rstage + r * slot + 16 * k) = __builtin_nontemporal_load((GlobalVec16)src);
                 }
             }
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             if (kk < BDX_WCAP) {
                 const int jf_abs = (int)(w.c - (codes + roff[w.r])) + 1;  // 1-based column of sweep column 0
                 const int mm = __builtin_popcount((w.p ? pv1 : pv0)[w.b]);
-                uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((r0 + w.r) * BDX_WCAP + kk) * 3;
+                uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[w.r] * BDX_WCAP + kk) * 3;
                 dst[0] = (uint32_t)w.b;
                 dst[1] = (uint32_t)(jf_abs + w.e_lo - 2 * (mm + w.kbv) - 1);
                 dst[2] = (uint32_t)(jf_abs + w.e_hi);
@@ -898,8 +915,11 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         for (int p = 0; p < npass; ++p) {
             const int cw = p ? cw1 : cw0;
             const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0);
-            uint32_t *dst = a.cand_out[p] + r0 * cw;
-            for (int i = tid; i < nr * cw; i += BS) dst[i] = staged ? cnd[i] : 0xFFFFFFFFu;
+            uint32_t *dst = a.cand_out[p];
+            for (int i = tid; i < nr * cw; i += BS) {
+                const int r = i / cw;
+                dst[(long long)rids[r] * cw + (i - r * cw)] = staged ? cnd[i] : 0xFFFFFFFFu;
+            }
         }
         if (a.wins_out[0]) {
             // Column windows for the exact kernel: every surviving candidate is swept
@@ -947,7 +967,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                     if (e_hi >= 0) {
                         const int kk = __hip_atomic_fetch_add(&wcl[p * R + r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (kk < BDX_WCAP) {
-                            uint32_t *dst = (p ? a.wins_out[1] : a.wins_out[0]) + ((r0 + r) * BDX_WCAP + kk) * 3;
+                            uint32_t *dst = (p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[r] * BDX_WCAP + kk) * 3;
                             dst[0] = (uint32_t)b;
                             dst[1] = (uint32_t)(e_lo - 2 * (mm + kbv) - 1);
                             dst[2] = (uint32_t)e_hi;
@@ -961,7 +981,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             for (int p = 0; p < npass; ++p)
                 for (int t = tid; t < nr; t += BS) {
                     const int c = wcl[p * R + t];
-                    a.wcnt_out[p][r0 + t] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
+                    a.wcnt_out[p][rids[t]] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
                 }
         }
         continue;
@@ -973,7 +993,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     // fit the staging area — are handed to the exact kernel through a list in HBM together with
     // their candidate masks; this kernel holds no DP state at all. ----
     const bool active = ltid < nr;
-    const long long ridx = r0 + ltid;
+    const long long ridx = active ? (long long)rids[ltid] : 0;
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     bool done = false;
@@ -990,7 +1010,31 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             const auto m1 = [&](const int b) { return (int)__builtin_popcount(pv1[b]); };
             classify_known(cfg, m0, m1, rlen[ltid], kn0, kn1, v, p1, p2);
             done = true;
-        } else {
+            if (a.tier) {
+                // Tier settle rule.  The replay saw every barcode b with d*(b) <= its CAPPED budget; a barcode it
+                // did not see scores >= slo (tier_slo of its pass).  Both reducers (:632-713) return the smallest
+                // score — first in file order among ties — and the with_delta one the second smallest as sub_min:
+                //   * min_score < slo (strictly): no unseen barcode can win or tie -> bc, score, raw are final;
+                //   * no_delta: delta = Inf, nothing else to know;
+                //   * with_delta: sub_min is final if the replay's own sub_min <= slo (an unseen barcode cannot be
+                //     smaller); else the true sub_min lies in [slo, replay's], so delta >= fl(slo - min): the pass is a
+                //     match — not ambiguous — if that is >= min_delta (IEEE subtraction is monotone), which settles
+                //     the verdict when nobody asked for the delta value itself.
+                // Anything else (no barcode within the capped budgets at all, a possible tie, an undecided
+                // ambiguity; also reads outside the known-score class or with more than four survivors) goes to
+                // tier 0, which filters the read at the full budgets.
+                const bool nd = cfg.min_delta == 0.0;
+                const auto settled = [&](const PassOut &po, const int cnt, const double slo) {
+                    if (cnt < 1 || !(po.score < slo)) return false;
+                    if (nd) return true;
+                    if (cnt >= 2 && po.sub <= slo) return true;
+                    return a.out.pass_delta == nullptr && (slo - po.score) >= cfg.min_delta && po.status == 1;
+                };
+                bool ok = settled(p1, cnt0, a.tier_slo[0]);
+                if (ok && npass > 1 && p1.status == 1) ok = settled(p2, cnt1, a.tier_slo[1]);
+                done = ok;
+            }
+        } else if (!a.tier) {  // (tier 1 hands every read it cannot settle to tier 0, below)
             for (int p = 0; p < npass; ++p) {
                 const int cw = p ? cw1 : cw0;
                 const LDS uint32_t *cnd = cand + (p ? R * cw0 : 0) + ltid * cw;
@@ -998,6 +1042,19 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 for (int w = 0; w < cw; ++w) dst[w] = staged ? cnd[w] : 0xFFFFFFFFu;
             }
             a.exc_list[atomicAdd(a.exc_count, 1u)] = (uint32_t)ridx;
+        }
+    }
+    if (a.tier) {
+        // unsettled reads -> tier 0's list: one queue reservation per wave (a tile's stage 2 is one wave)
+        const bool hand = active && !done && !BDX_DBG(1);
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(hand);
+        if (mk) {
+            const int lane = tid & 63;
+            const int leader = __builtin_ctzll(mk);
+            unsigned int basek = 0;
+            if (lane == leader) basek = atomicAdd(a.tier_count, (unsigned int)__builtin_popcountll(mk));
+            basek = (unsigned int)__shfl((int)basek, leader, 64);
+            if (hand) a.tier_list[basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)ridx;
         }
     }
     if (done) {
@@ -1096,7 +1153,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)gp.hist_entries * 4) + al(256);
     o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
     o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
-    o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 3 * al((size_t)R * 4) + al((size_t)R * 16);
+    o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 4 * al((size_t)R * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
@@ -1120,9 +1177,25 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1,
                              hipStream_t stream, uint32_t *wins_out0, uint32_t *wins_out1, uint8_t *wcnt_out0,
-                             uint8_t *wcnt_out1, int split, uint32_t *exc_list, unsigned int *exc_count) {
+                             uint8_t *wcnt_out1, int split, uint32_t *exc_list, unsigned int *exc_count,
+                             const BdxTierArgs *tier) {
     if (n_reads <= 0) return hipSuccess;
     BitparArgs a;
+    a.tier = 0;
+    a.tier_slo[0] = a.tier_slo[1] = 0.0;
+    a.tier_list = nullptr;
+    a.tier_count = nullptr;
+    a.in_list = nullptr;
+    a.in_count = nullptr;
+    if (tier) {
+        a.tier = tier->tier1;
+        a.tier_slo[0] = bp.tier_slo[0];
+        a.tier_slo[1] = bp.tier_slo[1];
+        a.tier_list = tier->out_list;
+        a.tier_count = tier->out_count;
+        a.in_list = tier->in_list;
+        a.in_count = tier->in_count;
+    }
     a.cfg = cfg;
     a.seq = d_seq;
     a.off = d_off;

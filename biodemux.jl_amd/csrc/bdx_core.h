@@ -436,6 +436,7 @@ struct PassOut {
     int start, end, raw;
     double score;
     double delta;
+    double sub = __builtin_inf();  // the with_delta reducer's sub_min_score (internal: tier settle rule)
 };
 
 // The two sequential reducers of the reference as one state machine:
@@ -491,6 +492,7 @@ struct Reducer {
         po.raw = braw;
         po.score = min_score;
         po.delta = delta;
+        po.sub = sub_min;
         if (best == 0) return po;                        // :820-821
         po.status = (delta < cfg.min_delta) ? -1 : 1;    // :822-823, :867
         return po;

@@ -38,25 +38,36 @@ struct BdxTuning {
     int bitpar_r = 0;     // BDX_BITPAR_R: forced tile size of the fused kernel
     long long grid = 0;   // BDX_GRID: forced persistent grid
     int diag_min_b = 48;  // BDX_DIAG_MIN_B: barcode threshold of the diagonal filter
+    int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
 };
 
 struct bdx_comm_state;  // bdx_comm.cpp
 
+// One complete filter configuration of the fused kernel: sweep tables + seed tables + launch geometry.
+// A context holds two: fs[0] filters at the config's full operation budgets; fs[1] — "tier 1" — at budgets
+// capped so that single 8-base seeds stay selective (see bdx_abi.cpp, tiered budgets).
+struct BdxFilterSet {
+    BdxBitparPlan bplan{};
+    BdxSeedPlan splan{};
+    // weak single seeds kept beside a two-intact-pieces plan: taken when the latter's index does not fit the
+    // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
+    BdxSeedPlan splan_alt{};
+    DevBuf bp_tables, seed_tables, seed_tables_alt;
+};
+
 struct bdx_ctx {
     bdx_config_t cfg{};
     BdxDevCfg dev{};
     BdxGenericPlan plan{};
-    BdxBitparPlan bplan{};
-    BdxSeedPlan splan{};
+    BdxFilterSet fs[2];
+    int cur = 0;        // the set the table builders / planners below work on
+    int tiered = 0;     // fs[1] is usable: classify runs tier 1 first, tier 0 on the reads it cannot settle
+    BdxFilterSet &F() { return fs[cur]; }
+    const BdxFilterSet &F() const { return fs[cur]; }
     BdxTuning tune{};
-    DevBuf seed_tables;
-    // weak single seeds kept beside a two-intact-pieces plan: taken when the latter's index does not fit the
-    // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
-    BdxSeedPlan splan_alt{};
-    DevBuf seed_tables_alt;
-    DevBuf bp_tables;
     DevBuf d_maxlen;
+    DevBuf d_tier;      // tiered budgets: reads handed from tier 1 to tier 0
     int user_len_hint = 0;  // 0 = measure every device batch
     int filter_used = BDX_FILTER_OFF;
     int device = 0;

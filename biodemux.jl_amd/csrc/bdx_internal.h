@@ -104,6 +104,8 @@ struct BdxBitparPlan {
     long long grid_override;  // > 0: forced persistent grid (tuning, BdxTuning::grid)
     int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
+    int tier_capped;       // tier 1: some barcode's budget was capped below its full budget
+    double tier_slo[2];    //   ... per pass the smallest score a barcode beyond its capped budget can have (else +Inf)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
     int *d_tile_counter;           // device int, zeroed before each launch
     const uint8_t *d_lut;          // device, 256 bytes
@@ -134,6 +136,16 @@ struct BdxSeedPlan {
     const uint32_t *d_dkeys[2];    // per barcode: 2 words, 8 bits per piece key (first 4 bases of the piece)
 };
 
+// Tiered budgets: tier 1 (tier1 = 1) appends the reads it cannot settle to out_list / *out_count; tier 0 then
+// runs over in_list[0 .. *in_count) only (list mode).
+struct BdxTierArgs {
+    int tier1;
+    uint32_t *out_list;
+    unsigned int *out_count;
+    const uint32_t *in_list;
+    const unsigned int *in_count;
+};
+
 // Implemented in bdx_bitpar.hip.
 size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const BdxGenericPlan &gp,
                             const BdxSeedPlan *sp = nullptr);
@@ -141,7 +153,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
                              const BdxSeedPlan &sp, const uint8_t *d_seq, const long long *d_off, long long n_reads, const BdxDevOut &out,
                              unsigned long long *d_counts, uint32_t *cand_out0, uint32_t *cand_out1, hipStream_t stream,
                              uint32_t *wins_out0, uint32_t *wins_out1, uint8_t *wcnt_out0, uint8_t *wcnt_out1, int split,
-                             uint32_t *exc_list, unsigned int *exc_count);
+                             uint32_t *exc_list, unsigned int *exc_count, const BdxTierArgs *tier = nullptr);
 // max read length of a device-resident batch (one tiny kernel; result written to *d_out)
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
 
