@@ -845,9 +845,10 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     {
         const BdxFilterSet &full = ctx->fs[0];
         const bool strict_full = full.splan.enabled && !full.splan.diag && full.splan.q >= 7;
-        bool all_known = full.bplan.enabled != 0;
-        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) all_known = all_known && full.bplan.known_ok[k];
-        if (full.bplan.enabled && all_known && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
+        // (the unit-level API's hand-made windows stay on the plain path)
+        bool plain_windows = true;
+        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) plain_windows = plain_windows && config->pass[k].explicit_window == 0;
+        if (full.bplan.enabled && plain_windows && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
             ctx->cur = 1;
             rc = build_bitpar_tables(ctx);
             if (rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped) rc = build_seed_tables(ctx, true);
@@ -1010,7 +1011,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         const int npass = ctx->dev.is_dual ? 2 : 1;
         bool split = false;
         for (int k = 0; k < npass; ++k) split |= !ctx->F().bplan.known_ok[k];
-        const bool tiered = tier_len > 0 && !split;
+        const bool tiered = tier_len > 0;
         if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
@@ -1049,8 +1050,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
-                                           o, ctx->counts, c0, c1, ctx->stream, nullptr, nullptr, nullptr, nullptr, 0, exc_list,
-                                           exc_count, &t1));
+                                           o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0, n1, split ? 1 : 0, exc_list, exc_count, &t1));
+            if (split)  // the exact kernel answers what tier 1 settles and lists the rest (known-score configs: the fused kernel did)
+                HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o, ctx->counts,
+                                                c0, npass > 1 ? c1 : nullptr, ctx->stream, w0, npass > 1 ? w1 : nullptr, n0,
+                                                npass > 1 ? n1 : nullptr, nullptr, nullptr, stp, &t1, f1.bplan.tier_slo));
             // tier 0 walks the list: scattered reads -> slot staging
             if (!size_bitpar(ctx, tier_len, n_reads, true)) return fail(ctx, BDX_E_DEVICE, "internal: tier 0 cannot be planned in list mode");
             t0.in_list = (const uint32_t *)ctx->d_tier.p;
@@ -1062,10 +1066,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
                                        n1, split ? 1 : 0, exc_list, exc_count, tiered ? &t0 : nullptr));
-        if (split)
+        if (split)  // (tiered: list mode over the reads tier 1 handed on)
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
-                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, nullptr, nullptr, stp));
+                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, tiered ? t0.in_list : nullptr,
+                                            tiered ? t0.in_count : nullptr, stp));
         else
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,

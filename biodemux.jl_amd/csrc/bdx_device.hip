@@ -43,7 +43,28 @@ struct GenericArgs {
     int bc_stage_bytes; // bytes of the barcode staging area (both passes; 0: barcodes not staged)
     int hist_entries;
     BdxDevStats stats;  // rows == 0: no histograms
+    // tiered budgets, split mode (bdx_abi.cpp): this launch evaluated the candidates of tier 1 (capped budgets);
+    // reads whose verdict could depend on a barcode beyond the cap are appended to tier_list instead of being
+    // answered
+    int tier1;
+    double tier_slo[2];
+    uint32_t *tier_list;
+    unsigned int *tier_count;
 };
+
+// Tier settle rule for one pass evaluated over the barcodes tier 1 can see (every b with unit distance <= its
+// capped budget).  A barcode it cannot see scores >= slo; the alignment of a barcode does not depend on the
+// running threshold beyond being accepted or not (in-domain costs, start / end ranges that do not bind for this
+// read — checked by the caller), so the reducers (:632-713) over the visible set give the reference's answer iff
+//   * a winner exists and min_score < slo strictly (no unseen barcode can win, or tie and come first), and
+//   * no_delta, or the visible runner-up is <= slo (then it IS sub_min), or the bound delta >= fl(slo - min) already
+//     proves "not ambiguous" and nobody asked for the delta value.
+__device__ __forceinline__ bool tier_pass_settled(const BdxDevCfg &cfg, const PassOut &po, const double slo, const bool want_delta) {
+    if (po.bc <= 0 || !(po.score < slo)) return false;
+    if (cfg.min_delta == 0.0) return true;
+    if (po.sub <= slo) return true;
+    return !want_delta && po.status == 1 && (slo - po.score) >= cfg.min_delta;
+}
 
 // match_barcode_pass's statistics block (classification.jl:827-865): runs iff the pass returned :match
 __device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p, const int B, const PassOut &po) {
@@ -176,6 +197,36 @@ __global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(co
             classify_one<false, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn, 0x4E,
                                       we0, wc0, we1, wc1);
         }
+    }
+    bool answer = active;
+    if (a.tier1) {  // (workgroup-uniform)
+        bool settled = false;
+        if (active) {
+            const long long rn = a.off[ridx + 1] - a.off[ridx];
+            const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
+            const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
+            const auto free_ranges = [&](const BdxDevPass &P) {  // neither the start nor the end range binds for this read
+                PassWindow w;
+                return !sgm || (pass_window(P, n, w) && w.max_start >= n && w.min_end <= 1);
+            };
+            const bool want_delta = a.out.pass_delta != nullptr;
+            settled = n > 0 && free_ranges(cfg.pass[0]) && tier_pass_settled(cfg, p1, a.tier_slo[0], want_delta);
+            if (settled && cfg.is_dual && p1.status == 1)
+                settled = free_ranges(cfg.pass[1]) && tier_pass_settled(cfg, p2, a.tier_slo[1], want_delta);
+        }
+        const bool hand = active && !settled;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(hand);
+        if (mk) {  // one queue reservation per wave
+            const int lane = tid & 63;
+            const int leader = __builtin_ctzll(mk);
+            unsigned int basek = 0;
+            if (lane == leader) basek = atomicAdd(a.tier_count, (unsigned int)__builtin_popcountll(mk));
+            basek = (unsigned int)__shfl((int)basek, leader, 64);
+            if (hand) a.tier_list[basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)ridx;
+        }
+        answer = active && settled;
+    }
+    if (answer) {
         // outputs (coalesced: consecutive lanes -> consecutive reads)
         if (a.out.bc1) a.out.bc1[ridx] = v.bc1;
         if (a.out.bc2) a.out.bc2[ridx] = v.bc2;
@@ -214,7 +265,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(co
     // DemuxStats scalar counters (classification.jl:942-978), merged like reporting.jl:1-9
     if (a.counts) {
         int slot = -1;
-        if (active) {
+        if (answer) {
             if (v.bc1 > 0)
                 slot = 4 + (v.bc1 - 1) * cfg.counts_stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
             const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
@@ -288,7 +339,8 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               unsigned long long *d_counts, const uint32_t *d_cand0, const uint32_t *d_cand1,
                               hipStream_t stream, const uint32_t *d_wins0, const uint32_t *d_wins1,
                               const uint8_t *d_wcnt0, const uint8_t *d_wcnt1, const uint32_t *d_list,
-                              const unsigned int *d_list_count, const BdxDevStats *stats) {
+                              const unsigned int *d_list_count, const BdxDevStats *stats, const BdxTierArgs *tier,
+                              const double *tier_slo) {
     if (n_reads <= 0) return hipSuccess;
     GenericArgs a;
     a.cfg = cfg;
@@ -309,6 +361,11 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
         a.stats = *stats;
     else
         a.stats = BdxDevStats{};
+    a.tier1 = tier && tier->tier1 ? 1 : 0;
+    a.tier_slo[0] = tier_slo ? tier_slo[0] : 0.0;
+    a.tier_slo[1] = tier_slo ? tier_slo[1] : 0.0;
+    a.tier_list = tier ? tier->out_list : nullptr;
+    a.tier_count = tier ? tier->out_count : nullptr;
     a.cfg.end_only_ok = out.pass_start == nullptr ? 1 : 0;
     a.dp_rows = plan.dp_rows;
     a.stage_bytes = plan.stage_bytes;

@@ -164,5 +164,6 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               const uint32_t *d_cand1, hipStream_t stream, const uint32_t *d_wins0 = nullptr,
                               const uint32_t *d_wins1 = nullptr, const uint8_t *d_wcnt0 = nullptr,
                               const uint8_t *d_wcnt1 = nullptr, const uint32_t *d_list = nullptr,
-                              const unsigned int *d_list_count = nullptr, const BdxDevStats *stats = nullptr);
+                              const unsigned int *d_list_count = nullptr, const BdxDevStats *stats = nullptr,
+                              const BdxTierArgs *tier = nullptr, const double *tier_slo = nullptr);
 hipError_t bdx_generic_set_lds_limit(size_t bytes);

@@ -592,3 +592,52 @@ def test_tiered_budgets_ragged_reads_and_hints():
     seq, off, _ = synth.make_ragged_reads(bcs, 20000, 0, 200, seed=107, sub=0.06, ins=0.02, dele=0.02)
     for hint in (None, 60, 150, 400):
         _all_filters_agree(_c2_config(bcs, max_error_rate=0.2, min_delta=0.05), seq, off, hint=hint)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_error_rate=0.2, trim_side=5),
+    dict(max_error_rate=0.2, trim_side=3, min_delta=0.05),
+    dict(max_error_rate=0.2, summary=True),
+    dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15),             # demo2's costs: weighted, cmin = 1
+    dict(max_error_rate=0.3, mismatch=2, indel=3, trim_side=5),                 # cmin = 2: an unseen barcode costs >= 2 (kb1 + 1)
+    dict(max_error_rate=0.2, matching_algorithm="hamming", min_delta=0.05),
+    dict(max_error_rate=0.2, nindel=2, trim_side=3),                            # N-scoring (no N in these barcodes)
+    dict(max_error_rate=0.2, trim_side=5, barcode_start_range="1:60"),          # a start range that binds for most reads: tier 0
+    dict(max_error_rate=0.2, trim_side=3, barcode_end_range="40:end", min_delta=0.05),
+    dict(max_error_rate=0.2, trim_side=5, ref_search_range="5:end-3"),          # a column window alone does not bind
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_tiered_budgets_split_mode(kw):
+    """Configs outside the known-score class (trimming, summary, weighted costs, Hamming, N-scoring): tier 1 filters at
+    the capped budgets, the exact kernel evaluates its candidates and answers only the reads whose verdict cannot
+    depend on an unseen barcode (and whose start / end ranges do not bind); the rest goes through the full-budget
+    filter and the exact kernel in list mode."""
+    kw = dict(kw)
+    for k in ("barcode_start_range", "barcode_end_range", "ref_search_range"):
+        if k in kw:
+            kw[k] = H.bdx.parse_dynamic_range(kw[k])
+    bcs = synth.make_barcodes(96, 24, seed=111)
+    seq, off, _ = synth.make_ragged_reads(bcs, 25000, 100, 150, seed=112, sub=0.05, ins=0.015, dele=0.015, repeat=dict(frac=0.15))
+    cfg = _c2_config(bcs, **kw)
+    for want_pass in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want_pass)
+        exp = oc.classify(seq, off)
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            got = hc.classify(seq, off)
+            assert hc.kernel_path.startswith(TIER), hc.kernel_path
+            fuzz.assert_same(got, exp, f"tiered split {kw} want_pass={want_pass}")
+            assert np.array_equal(hc.counts, oc.counts)
+    assert 0.2 < (exp["bc1"] > 0).mean() < 0.99
+
+
+def test_tiered_budgets_c4_dual_trim():
+    b1 = synth.make_barcodes(24, 24, seed=1)
+    b2 = synth.make_barcodes(16, 24, seed=2)
+    seq, off, _ = synth.make_reads(b1, 40000, 150, sub=0.05, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True,
+                            bc_seqs2=b2, bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)],
+                            max_error_rate=0.2, trim_side=5, trim_side2=3)
+    for want_pass in (True, False):
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want_pass).classify(seq, off)
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            fuzz.assert_same(hc.classify(seq, off), exp, "C4 tiered")
+            assert hc.kernel_path.startswith(TIER), hc.kernel_path
