@@ -42,6 +42,7 @@ BdxTuning read_tuning() {
     t.no_slot = getenv("BDX_NO_SLOT") != nullptr;
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
+    t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     if (const char *e = getenv("BDX_BITPAR_R")) t.bitpar_r = atoi(e);
     if (const char *e = getenv("BDX_GRID")) t.grid = atoll(e);
     if (const char *e = getenv("BDX_DIAG_MIN_B")) t.diag_min_b = atoi(e);
@@ -70,6 +71,21 @@ int plan_generic(bdx_ctx *ctx) {
     // SimpleScoring barcodes of <= 32 rows run the register-resident DP: no LDS columns at all
     p.reg_rows = (!d.has_nindel && d.algorithm == BDX_ALG_SEMIGLOBAL && !d.force_lds_dp)
                      ? (d.max_m <= 24 ? 24 : (d.max_m <= 32 ? 32 : 0)) : 0;
+    // clean class (bdx_core.h sg_core_clean): costs match >= 0, mismatch / indel >= 1, and barcode_start_range /
+    // barcode_end_range that resolve to 1:n for every read (no offset from either end) — then neither binds
+    p.clean = 0;
+    p.uniform_m = 0;
+    if (p.reg_rows && !ctx->tune.no_clean && d.match >= 0 && d.mismatch >= 1 && d.indel >= 1) {
+        bool free_ranges = true, uniform = true;
+        for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) {
+            const bdx_pass_t &ps = ctx->cfg.pass[k];
+            const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
+            free_ranges = free_ranges && ps.explicit_window == 0 && whole(ps.barcode_start_range) && whole(ps.barcode_end_range);
+            for (int b = 0; b < ps.n_barcodes; ++b) uniform = uniform && (int)(ps.bc_off[b + 1] - ps.bc_off[b]) == p.reg_rows;
+        }
+        p.clean = free_ranges;
+        p.uniform_m = free_ranges && uniform;
+    }
     p.dp_rows = p.reg_rows ? 1 : d.max_m + 1;
     p.dp_rows_fused = d.max_m + 1;
     const size_t per_thread = (size_t)p.dp_rows * 4 * (d.any_traceback ? 2 : 1);
@@ -87,7 +103,8 @@ int plan_generic(bdx_ctx *ctx) {
         p.threads = t;
         // Read staging: aim for two resident workgroups per CU (<= 80 KiB each) when that
         // still leaves room for ~192 B per read; otherwise take what is left of the CU.
-        size_t budget = need < 80 * 1024 ? 80 * 1024 - need : 0;
+        const size_t share = p.clean ? (LDS_MAX / 3) & ~(size_t)1279 : 80 * 1024;  // clean class: three workgroups per CU (<= 168 VGPRs)
+        size_t budget = need < share ? share - need : 0;
         if (budget < (size_t)t * 192) budget = LDS_MAX - need;
         size_t stage = budget > 64 * 1024 ? 64 * 1024 : budget;
         stage &= ~(size_t)15;

@@ -308,6 +308,92 @@ __device__ __forceinline__ AlignOut sg_core_reg(const Bytes<STAGED> q, const int
     return res;  // :444
 }
 
+// "Clean class" variant of the register DP: SimpleScoring with match >= 0 and mismatch, indel
+// >= 1, and start / end ranges that bind for no read (the host checks both: BdxDevCfg::clean_ok).  There the
+// reference's banded cut-off loop records exactly what a plain column-by-column DP over all m rows records —
+// cells <= allowed_error only depend on cells <= allowed_error, which lie inside fact..lact with their true values;
+// stale cells and cells outside the band are > allowed_error on both sides and never win a comparison — so no
+// fact / lact / band bookkeeping and no per-row predicates are needed: 11 VALU operations per cell with origins,
+// 6 without, against ~27 of the predicated form, and no mask registers to spill.  Same origin rule (deletion, then
+// substitution if strictly less, then insertion if strictly less, :310-321), same last row without a horizontal
+// move (:213/:229: its recorded value is min(del, sub)), same recording and early exit (:417-436).
+// Checked against the line-faithful core by orc_selftest_clean_class (oracle; 0 disagreements in 4 M cases).
+// UM: every barcode of the config has exactly M rows (the last row is static); else row m is picked per lane.
+template <bool TB, int M, bool STAGED, bool ENDPOS, bool UM>
+__device__ __forceinline__ AlignOut sg_core_clean(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
+                                                  const int n, const int ae, const Costs c, const int trim_side,
+                                                  int first, int last, const int jlo = -0x40000000,
+                                                  const int jhi = 0x40000000) {
+    AlignOut res{BDX_INF32, -1, -1};
+    if (m == 0 || n == 0) return res;  // :250-252
+    int DP[M + 1], OG[M + 1], QB[M + 1];
+#pragma unroll
+    for (int i = 1; i <= M; ++i) {  // :278-283
+        DP[i] = c.indel * i;
+        OG[i] = 1 - i;
+        QB[i] = (UM || i <= m) ? q[i - 1] : 0x100;  // rows beyond m never match and are never looked at
+    }
+    if (jlo > first) first = jlo;  // restricted run, DESIGN.md §3.2
+    if (jhi < last) last = jhi;
+    // the read's bytes arrive a 32-bit word at a time (aligned; one load per four columns)
+    const uintptr_t rbase = (uintptr_t)r.p;
+    uint32_t word = 0;
+    int wpos = -1;
+    for (int j = first; j <= last; ++j) {  // :287
+        const uintptr_t ad = rbase + (uintptr_t)(j - 1);
+        const int wi = (int)(ad >> 2);
+        if (wi != wpos) {
+            wpos = wi;
+            if constexpr (STAGED)
+                word = *(const LDS uint32_t *)(ad & ~(uintptr_t)3);
+            else
+                word = *(const uint32_t *)(ad & ~(uintptr_t)3);
+        }
+        const int rj = (int)((word >> (8 * (int)(ad & 3))) & 0xFFu);
+        int prev = 0, prev_o = j, diag = 0, diag_o = j;  // row 0: value 0, origin j (:288, :308)
+        int vm = BDX_INF32, om = -1;
+#pragma unroll
+        for (int i = 1; i <= M; ++i) {
+            const int old = DP[i], old_o = OG[i];
+            const int ins = old + c.indel;                                    // :183
+            const int del = prev + c.indel;                                   // :184
+            const int sub = diag + (QB[i] == rj ? c.match : c.mismatch);      // :185
+            int o = prev_o;
+            if (TB) o = sub < del ? diag_o : o;                               // :310-316
+            const int b2 = sub < del ? sub : del;
+            if (UM ? (i == M) : (i == m)) {  // the last row: no horizontal move
+                vm = b2;
+                if (TB) om = o;
+            }
+            if (TB) o = ins < b2 ? old_o : o;                                 // :317-320
+            const int nv = ins < b2 ? ins : b2;                               // :332
+            DP[i] = nv;
+            if (TB) OG[i] = o;
+            prev = nv;
+            prev_o = o;
+            diag = old;
+            diag_o = old_o;
+            // rows are a serial chain; keep the scheduler from hoisting every row's independent operations (ins, the
+            // comparisons with rj) to the column head: that triples the live registers and spills
+            if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (vm <= ae) {  // :417 (j >= min_end_pos holds for every column: the end range does not bind)
+            if (vm == 0 && (!TB || trim_side == 5)) return AlignOut{0, TB ? om : -1, (TB || ENDPOS) ? j : -1};  // :420-430
+            if (TB) {  // :142-153
+                if (vm < res.raw || (vm == res.raw && trim_side == 3 && om > res.start)) {
+                    res.raw = vm;
+                    res.start = om;
+                    res.end = j;
+                }
+            } else if (vm < res.raw) {
+                res.raw = vm;
+                if (ENDPOS) res.end = j;
+            }
+        }
+    }
+    return res;  // :444
+}
+
 // hamming_align, classification.jl:557-625.  Scores of one call share the divisor m, so the
 // reference's Float64 `score < best_score` / `==` are decided on the integer numerators.
 template <bool STAGED>
@@ -501,7 +587,7 @@ struct Reducer {
 
 // match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
 // reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
-template <bool STAGED, int REGM = 0>
+template <bool STAGED, int REGM = 0, bool CLEAN = false, bool UM = false>
 __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPass &P, const Bytes<STAGED> bcb,
                                             const LDS uint32_t *bc_off, const LDS int *bc_nn,
                                             const Bytes<STAGED> r, const int n, LDS int *DP, LDS int *OG,
@@ -571,6 +657,12 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             if (cfg.has_nindel) {
                 a = need_tb ? sg_core<true, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
                             : sg_core<false, true, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
+            } else if (REGM > 0 && CLEAN) {
+                // clean class (see sg_core_clean): same three output forms as below
+                const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
+                a = !need_tb ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
+                    : end_only ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, true, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
+                               : sg_core_clean<true, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi);
             } else if (REGM > 0) {
                 // With trim_side == 5 and nobody asking for the start position, the alignment's END is all that is
                 // observable (keep_start = end + 1, :914): the origin half of the DP is dropped.  Same values, same
@@ -656,7 +748,7 @@ struct KnownPass {
     int count;
 };
 
-template <bool STAGED, int REGM = 0>
+template <bool STAGED, int REGM = 0, bool CLEAN = false, bool UM = false>
 __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<STAGED> bcb0,
                                              const Bytes<STAGED> bcb1, const LDS uint32_t *off0,
                                              const LDS uint32_t *off1, const LDS int *nn0, const LDS int *nn1,
@@ -674,14 +766,14 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
     const auto m0 = [&](const int b) { return (int)off0[b + 1] - (int)off0[b]; };
     const auto m1 = [&](const int b) { return (int)off1[b + 1] - (int)off1[b]; };
     p1 = kn0.use ? run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count)
-                 : run_pass<STAGED, REGM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode, went0, wcount0);  // :875
+                 : run_pass<STAGED, REGM, CLEAN, UM>(cfg, cfg.pass[0], bcb0, off0, nn0, r, n, DP, OG, S, cand0, ncode, went0, wcount0);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.use ? run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count)
-                     : run_pass<STAGED, REGM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode, went1, wcount1);
+                     : run_pass<STAGED, REGM, CLEAN, UM>(cfg, cfg.pass[1], bcb1, off1, nn1, r, n, DP, OG, S, cand1, ncode, went1, wcount1);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

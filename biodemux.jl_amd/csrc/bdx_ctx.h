@@ -38,6 +38,7 @@ struct BdxTuning {
     int bitpar_r = 0;     // BDX_BITPAR_R: forced tile size of the fused kernel
     long long grid = 0;   // BDX_GRID: forced persistent grid
     int diag_min_b = 48;  // BDX_DIAG_MIN_B: barcode threshold of the diagonal filter
+    int no_clean = 0;     // BDX_NO_CLEAN: exact kernel's register DP always in its predicated by-construction form
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
 };

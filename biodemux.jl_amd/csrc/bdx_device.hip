@@ -87,8 +87,10 @@ __device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p,
 //   [barcode bytes pass0|pass1][hist: int[hist_entries]][read bytes: stage_bytes]
 // REGM > 0: the exact DP of SimpleScoring barcodes up to REGM rows runs register-resident
 // (sg_core_reg); the kernel then needs no DP/origin columns in LDS.
-template <int BS, int REGM>
-__global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(const GenericArgs a) {
+// CLEAN: the clean-class register DP (sg_core_clean) — no predicated rows, <= 168 VGPRs, three workgroups per CU;
+// UM: every barcode has exactly REGM rows.
+template <int BS, int REGM, bool CLEAN = false, bool UM = false>
+__global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_generic_kernel(const GenericArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
@@ -189,13 +191,13 @@ __global__ __launch_bounds__(BS, (BS == 256 ? 2 : 1)) void bdx_generic_kernel(co
         if (staged) {
             Bytes<true> r{rstage + head + (ro - span0)};
             Bytes<true> q0{bcs}, q1{bcs + bytes0};
-            classify_one<true, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn, 0x4E, we0,
-                                     wc0, we1, wc1);
+            classify_one<true, REGM, CLEAN, UM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn,
+                                                0x4E, we0, wc0, we1, wc1);
         } else {
             Bytes<false> r{a.seq + ro};
             Bytes<false> q0{cfg.pass[0].bc_bytes}, q1{cfg.pass[1].bc_bytes};
-            classify_one<false, REGM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn, 0x4E,
-                                      we0, wc0, we1, wc1);
+            classify_one<false, REGM, CLEAN, UM>(cfg, q0, q1, off0, off1, nn0, nn1, r, n, DP, OG, BS, c0, c1, v, p1, p2, nokn, nokn,
+                                                 0x4E, we0, wc0, we1, wc1);
         }
     }
     bool answer = active;
@@ -319,9 +321,9 @@ hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_o
     return hipGetLastError();
 }
 
-template <int BS, int REGM>
+template <int BS, int REGM, bool CLEAN = false, bool UM = false>
 static hipError_t generic_attr(size_t bytes) {
-    return hipFuncSetAttribute((const void *)bdx_generic_kernel<BS, REGM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipFuncSetAttribute((const void *)bdx_generic_kernel<BS, REGM, CLEAN, UM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 hipError_t bdx_generic_set_lds_limit(size_t bytes) {
@@ -331,6 +333,10 @@ hipError_t bdx_generic_set_lds_limit(size_t bytes) {
     if ((e = generic_attr<64, 0>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<256, 24>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<256, 32>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 24, true, true>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 24, true, false>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 32, true, true>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 32, true, false>(bytes)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -375,7 +381,17 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     if (d_list && blocks > 1024) blocks = 1024;  // list mode: the hand-overs are few; the grid strides
     const dim3 grid((unsigned)blocks), block((unsigned)plan.threads);
-    if (plan.reg_rows == 24 && plan.threads == 256) {
+    if (plan.reg_rows == 24 && plan.threads == 256 && plan.clean) {
+        if (plan.uniform_m)
+            hipLaunchKernelGGL((bdx_generic_kernel<256, 24, true, true>), grid, block, plan.lds_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((bdx_generic_kernel<256, 24, true, false>), grid, block, plan.lds_bytes, stream, a);
+    } else if (plan.reg_rows == 32 && plan.threads == 256 && plan.clean) {
+        if (plan.uniform_m)
+            hipLaunchKernelGGL((bdx_generic_kernel<256, 32, true, true>), grid, block, plan.lds_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((bdx_generic_kernel<256, 32, true, false>), grid, block, plan.lds_bytes, stream, a);
+    } else if (plan.reg_rows == 24 && plan.threads == 256) {
         hipLaunchKernelGGL((bdx_generic_kernel<256, 24>), grid, block, plan.lds_bytes, stream, a);
     } else if (plan.reg_rows == 32 && plan.threads == 256) {
         hipLaunchKernelGGL((bdx_generic_kernel<256, 32>), grid, block, plan.lds_bytes, stream, a);

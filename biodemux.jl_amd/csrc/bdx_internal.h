@@ -78,6 +78,8 @@ struct BdxDevStats {
 struct BdxGenericPlan {
     int threads;         // 64 / 128 / 256
     int reg_rows;        // 24 / 32: register-resident exact DP (no DP columns in LDS); 0: LDS columns
+    int clean;           // register DP in its clean-class form (sg_core_clean): in-domain costs, start / end ranges "1:end"
+    int uniform_m;       //   ... and every barcode has exactly reg_rows rows
     int dp_rows;         // generic kernel: max_m + 1, or 1 in register mode
     int dp_rows_fused;   // fused kernel's in-kernel exact stage always keeps LDS columns: max_m + 1
     int stage_bytes;     // LDS bytes reserved for staged read bytes (0 = read from HBM/L2 directly)

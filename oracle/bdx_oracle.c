@@ -1121,6 +1121,129 @@ int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 
     return bad;
 }
 
+/* ---- model of the HIP "clean class" DP (csrc/bdx_core.h sg_core_clean), test-only -----------------------
+ * Claim: SimpleScoring with match >= 0 and mismatch, indel >= 1, and for this read neither the
+ * start nor the end range binds (max_start_pos >= n, min_end_pos <= 1; the column window first:last may be any
+ * sub-range, also a restricted one).  Then the reference's banded cut-off loop (:287-442) records exactly what a
+ * plain column-by-column semi-global DP over ALL m rows records: a cell <= allowed_error only depends on cells
+ * <= allowed_error, those are inside fact..lact with their true values (Ukkonen; D[i][j] >= D[i-1][j-1]), stale
+ * cells and cells outside the band are > allowed_error on both sides and never win a comparison, so values,
+ * origins (deletion, then substitution if strictly less, then insertion if strictly less, :310-321) and the
+ * recorded (score, start, end) agree.  Row m takes no horizontal move (:213/:229): its recorded value is
+ * min(del, sub).  orc_selftest_clean_class checks the claim against the line-faithful core. */
+static orc_align_t clean_dp(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                            int64_t mismatch, int64_t indel, int32_t output_mode, int32_t trim_side, int64_t first,
+                            int64_t last, int64_t norm, int64_t col_lo, int64_t col_hi) {
+    const int tb = output_mode == ORC_OUT_TRACEBACK;
+    res_t result = init_result();
+    if (m == 0 || n == 0) return finalize_result(output_mode, result, norm);
+    const int64_t ae = (int64_t)floor(max_error * (double)norm);
+    int64_t D[64], O[64];
+    for (int64_t i = 1; i <= m; i++) {
+        D[i] = indel * i;
+        O[i] = 1 - i;
+    }
+    if (col_lo > first) first = col_lo;
+    if (col_hi < last) last = col_hi;
+    for (int64_t j = first; j <= last; j++) {
+        int64_t prev = 0, prev_o = j, diag = 0, diag_o = j, vm = INF_INT, om = -1;
+        for (int64_t i = 1; i <= m; i++) {
+            const int64_t old = D[i], old_o = O[i];
+            const int64_t ins = old + indel, del = prev + indel;
+            const int64_t sub = diag + (q0[i - 1] == r0[j - 1] ? match : mismatch);
+            int64_t b2 = del, o = prev_o;
+            if (sub < b2) {
+                b2 = sub;
+                o = diag_o;
+            }
+            if (i == m) { /* the last row has no horizontal move */
+                vm = b2;
+                om = o;
+            }
+            int64_t nv = b2;
+            if (ins < nv) {
+                nv = ins;
+                o = old_o;
+            }
+            D[i] = nv;
+            O[i] = o;
+            prev = nv;
+            prev_o = o;
+            diag = old;
+            diag_o = old_o;
+        }
+        if (vm <= ae) { /* :417 with j >= min_end_pos always */
+            if (vm == 0 && (!tb || trim_side == 5)) { /* :420-430 */
+                result.score = 0;
+                if (tb) {
+                    result.start = om;
+                    result.end = j;
+                }
+                return finalize_result(output_mode, result, norm);
+            }
+            result = tb ? update_result_traceback(trim_side, result, vm, j, om) : update_result_scoreonly(result, vm);
+        }
+    }
+    return finalize_result(output_mode, result, norm);
+}
+
+int64_t orc_selftest_clean_class(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[6] = "ACGTN";
+    static const double RATES[9] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5, 1.0};
+    uint8_t q[40], r[260];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 1 + (int64_t)(st_next(&s) % 32);
+        int64_t n = (int64_t)(st_next(&s) % 250);
+        const int lowc = (st_next(&s) % 5) == 0; /* low-complexity pairs: many ties */
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : 4)];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : ((st_next(&s) % 50) ? 4 : 5))];
+        int copies = (int)(st_next(&s) % 3);
+        for (int cpy = 0; cpy < copies && n > 0; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 5) r[pos++] = (uint8_t)AL[st_next(&s) % 4];
+                else if (u < 8) continue;
+                else if (u < 11) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        double rate = RATES[st_next(&s) % 9];
+        int64_t mismatch = 1 + (int64_t)(st_next(&s) % 3), indel = 1 + (int64_t)(st_next(&s) % 3);
+        int64_t match = (st_next(&s) % 8) == 0 ? 1 : 0;
+        int32_t mode = (int32_t)(st_next(&s) % 2);
+        int32_t trim = mode ? (int32_t)((int[]){0, 3, 5}[st_next(&s) % 3]) : 0;
+        int64_t first = 1, last = n;
+        if (n > 0 && (st_next(&s) % 3) == 0) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        const int64_t max_start = n + (int64_t)(st_next(&s) % 3) * 40; /* non-binding */
+        const int64_t min_end = 1 - (int64_t)(st_next(&s) % 2);
+        double used = (st_next(&s) % 3) ? rate : rate * (double)(st_next(&s) % 100) / 100.0;
+        /* sometimes a restricted column range: both sides get the same one */
+        int64_t clo = INT64_MIN, chi = INT64_MAX;
+        if (n > 0 && (st_next(&s) % 4) == 0) {
+            clo = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            chi = clo + (int64_t)(st_next(&s) % (uint64_t)(n - clo + 1));
+        }
+        orc_align_t ref = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, 0, 0, mode, trim, first,
+                                               last, max_start, min_end, m, clo, chi);
+        orc_align_t got = clean_dp(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, clo, chi);
+        if (got.raw != ref.raw || got.start != ref.start || got.end != ref.end) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = ref.raw;
+                first_bad[4] = got.raw; first_bad[5] = ref.start; first_bad[6] = got.start; first_bad[7] = mode * 10 + trim;
+            }
+            bad++;
+        }
+    }
+    return bad;
+}
+
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
     static const char AL[6] = "ACGTN";
     static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};

@@ -165,6 +165,7 @@ int64_t orc_unit_distance(const uint8_t *q, int64_t m, const uint8_t *r, int64_t
 int64_t orc_selftest_known_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad);
+int64_t orc_selftest_clean_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 
 #ifdef __cplusplus
 }

@@ -42,3 +42,12 @@ def test_register_dp_formulation_equals_the_faithful_core():
     fb = (C.c_int64 * 8)()
     bad = H.orc.lib().orc_selftest_cone(20260515, 300_000, fb)
     assert bad == 0, f"first disagreement (iter, m, n, full.raw, model.raw, full.start, model.start, 1000*plain + mode*10+trim): {list(fb)}"
+
+
+def test_clean_class_full_dp_equals_the_cut_off_loop():
+    """with in-domain SimpleScoring costs and start / end ranges that do not bind, a plain DP over
+    all m rows records what the reference's banded cut-off loop records — values, origins under every tie rule,
+    early exits, restricted column ranges, tightened thresholds (the model is csrc/bdx_core.h sg_core_clean)."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_clean_class(20260515, 400_000, fb)
+    assert bad == 0, list(fb)
