@@ -456,7 +456,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int mm = __builtin_popcount((w.p ? pv1 : pv0)[w.b]);
                 uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[w.r] * BDX_WCAP + kk) * 3;
                 dst[0] = (uint32_t)w.b;
-                dst[1] = (uint32_t)(jf_abs + w.e_lo - 2 * (mm + w.kbv) - 1);
+                // :semiglobal: first column of the restricted run; :hamming: first START position
+                dst[1] = (uint32_t)(jf_abs + w.e_lo - (sg ? 2 * (mm + w.kbv) + 1 : mm - 1));
                 dst[2] = (uint32_t)(jf_abs + w.e_hi);
             }
         }
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         if (kk < BDX_WCAP) {
                             uint32_t *dst = (p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[r] * BDX_WCAP + kk) * 3;
                             dst[0] = (uint32_t)b;
-                            dst[1] = (uint32_t)(e_lo - 2 * (mm + kbv) - 1);
+                            dst[1] = (uint32_t)(e_lo - (sg ? 2 * (mm + kbv) + 1 : mm - 1));
                             dst[2] = (uint32_t)e_hi;
                         }
                     } else {

@@ -400,13 +400,18 @@ template <bool STAGED>
 __device__ __forceinline__ AlignOut hamming_dev(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
                                                 const int n, const int allowed, const int first,
                                                 const int last, const int max_start, const int min_end,
-                                                const int trim_side, const int ncode) {
+                                                const int trim_side, const int ncode,
+                                                const int jlo = -0x40000000, const int jhi = 0x40000000) {
     AlignOut best{BDX_INF32, -1, -1};
-    const int sf = first > 1 ? first : 1;  // :570
+    int sf = first > 1 ? first : 1;  // :570
     int sl = last < max_start ? last : max_start;
     if (n - m + 1 < sl) sl = n - m + 1;  // :571
     if (sl < sf) return best;            // :573-576
     if (m == 0) return best;             // 0/0 = NaN never beats Inf (:607-613)
+    // restricted run: an occurrence with <= allowed mismatches ENDS at a column whose unit distance is within the
+    // budget, i.e. inside the hand-over window [jlo + m - 1, jhi] -> only the starts jlo .. jhi - m + 1 can be accepted
+    if (jlo > sf) sf = jlo;
+    if (jhi - m + 1 < sl) sl = jhi - m + 1;
     for (int j = sf; j <= sl; ++j) {     // :581
         const int end_pos = j + m - 1;
         if (end_pos < min_end) continue;  // :584-586
@@ -630,28 +635,28 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         const Bytes<STAGED> q = bcb.at(o);
         AlignOut a;
         double score;
+        // column restriction of this candidate (split mode hands over up to BDX_WCAP entries
+        // {barcode, first column, last column} per read and pass; none -> the whole window)
+        int cjlo = -0x40000000, cjhi = 0x40000000;
+        if (wcount <= BDX_WCAP) {
+            // several entries of one barcode (separately swept occurrences) are united
+            bool any_entry = false;
+            for (int e = 0; e < wcount; ++e)
+                if ((int)went[3 * e] == b) {
+                    const int lo_e = (int)went[3 * e + 1], hi_e = (int)went[3 * e + 2];
+                    cjlo = any_entry ? (lo_e < cjlo ? lo_e : cjlo) : lo_e;
+                    cjhi = any_entry ? (hi_e > cjhi ? hi_e : cjhi) : hi_e;
+                    any_entry = true;
+                }
+        }
         if (cfg.algorithm == BDX_ALG_HAMMING) {
             const int allowed = (int)__builtin_floor(red.rate * (double)m);  // :567
-            a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side, ncode);
+            a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side, ncode, cjlo, cjhi);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :607
         } else if (cfg.algorithm == BDX_ALG_EXACT) {
             a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : 0.0;
         } else {
-            // column restriction of this candidate (split mode hands over up to BDX_WCAP entries
-            // {barcode, first column, last column} per read and pass; none -> the whole window)
-            int cjlo = -0x40000000, cjhi = 0x40000000;
-            if (wcount <= BDX_WCAP) {
-                // several entries of one barcode (separately swept occurrences) are united
-                bool any_entry = false;
-                for (int e = 0; e < wcount; ++e)
-                    if ((int)went[3 * e] == b) {
-                        const int lo_e = (int)went[3 * e + 1], hi_e = (int)went[3 * e + 2];
-                        cjlo = any_entry ? (lo_e < cjlo ? lo_e : cjlo) : lo_e;
-                        cjhi = any_entry ? (hi_e > cjhi ? hi_e : cjhi) : hi_e;
-                        any_entry = true;
-                    }
-            }
             const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476
             const int ae = (int)__builtin_floor(red.rate * (double)norm);  // :254
             if (cfg.has_nindel) {
