@@ -1032,8 +1032,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
-        const bool windows = split && (ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL || ctx->dev.algorithm == BDX_ALG_HAMMING) &&
-                             !ctx->tune.no_windows;
+        const bool windows = split && !ctx->tune.no_windows;
         for (int k = 0; k < npass; ++k) {
             HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
             if (windows) {

@@ -454,14 +454,20 @@ __device__ __forceinline__ bool bytes_equal(const Bytes<STAGED> q, const int m, 
 template <bool STAGED>
 __device__ __forceinline__ AlignOut exact_dev(const Bytes<STAGED> q, const int m, const Bytes<STAGED> r,
                                               const int n, const int first, const int last,
-                                              const int max_start, const int min_end, const int trim_side) {
+                                              const int max_start, const int min_end, const int trim_side,
+                                              const int jlo = -0x40000000, const int jhi = 0x40000000) {
     AlignOut none{BDX_INF32, -1, -1};
     const int sf = first > 1 ? first : 1;  // :490
     int sl = last < max_start ? last : max_start;
     if (n - m + 1 < sl) sl = n - m + 1;  // :491
     if (sl < sf) return none;            // :493-495
+    // restricted run: every occurrence that starts inside sf..sl starts inside jlo .. jhi - m + 1 (the filter's
+    // hand-over window); both scans below only ever ACCEPT such an occurrence, and an occurrence outside sf..sl
+    // can only turn the answer into "none" when no occurrence inside precedes it in scan order — in which case
+    // the restricted scan finds nothing and says "none" as well.
+    const int rlo = jlo > 1 ? jlo : 1, rhi = jhi - m + 1;
     if (trim_side == 3) {                // :499-515: only the first findprev hit is examined
-        for (int s = sl; s >= 1; --s) {
+        for (int s = (sl < rhi ? sl : rhi); s >= rlo; --s) {
             if (bytes_equal<STAGED>(q, m, r, s)) {
                 if (s >= sf && s + m - 1 >= min_end) return AlignOut{0, s, s + m - 1};
                 return none;
@@ -470,7 +476,8 @@ __device__ __forceinline__ AlignOut exact_dev(const Bytes<STAGED> q, const int m
         return none;
     }
     // :517-547: leftmost hit; hits that end before min_end_pos are skipped and the scan goes on
-    for (int s = sf; s <= n - m + 1; ++s) {
+    const int top = n - m + 1 < rhi ? n - m + 1 : rhi;
+    for (int s = (sf > rlo ? sf : rlo); s <= top; ++s) {
         if (bytes_equal<STAGED>(q, m, r, s)) {
             if (s > sl) return none;
             if (s + m - 1 >= min_end) return AlignOut{0, s, s + m - 1};
@@ -654,7 +661,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             a = hamming_dev<STAGED>(q, m, r, n, allowed, jf, jl, max_start, min_end, trim_side, ncode, cjlo, cjhi);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :607
         } else if (cfg.algorithm == BDX_ALG_EXACT) {
-            a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side);
+            a = exact_dev<STAGED>(q, m, r, n, jf, jl, max_start, min_end, trim_side, cjlo, cjhi);
             score = a.raw >= BDX_INF32 ? __builtin_inf() : 0.0;
         } else {
             const int norm = cfg.has_nindel ? bc_nn[b] : m;               // :460 / :476
