@@ -155,12 +155,14 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     for (int i = 0; i < 256; ++i) code_of[i] = -1;
     int K = 0;
     size_t cand_words = 0;
+    size_t wb = 4;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
         cand_words += (size_t)(p.n_barcodes + 31) / 32;
         for (int b = 0; b < p.n_barcodes; ++b) {
             const uint32_t m = p.bc_off[b + 1] - p.bc_off[b];
-            if (m > 32) return BDX_OK;  // one 32-bit word per barcode
+            if (m > 64) return BDX_OK;  // one sweep word per barcode: 32 bits, or 64 for barcodes of 33..64 nt
+            if (m > 32) wb = 8;
             for (uint32_t i = 0; i < m; ++i) {
                 const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
                 if (code_of[ch] < 0) {
@@ -176,16 +178,18 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     std::vector<uint8_t> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)(code_of[i] < 0 ? K : code_of[i]);
     size_t bytes = 256;
+    bp.word_bytes = (int)wb;
     size_t o_peq[2] = {0, 0}, o_pv[2] = {0, 0}, o_kb[2] = {0, 0};
     for (int k = 0; k < npass; ++k) {
         const int B = c.pass[k].n_barcodes;
         bp.bpad[k] = 32;  // power of two >= B: peq row address = code << log2(4*bpad)
         while (bp.bpad[k] < B) bp.bpad[k] <<= 1;
-        if ((size_t)bp.ncodes * bp.bpad[k] * 4 > 48 * 1024) return BDX_OK;
+        if ((size_t)bp.ncodes * bp.bpad[k] * wb > 48 * 1024) return BDX_OK;
+        bytes = (bytes + 7) & ~(size_t)7;
         o_peq[k] = bytes;
-        bytes += (size_t)bp.ncodes * bp.bpad[k] * 4;
+        bytes += (size_t)bp.ncodes * bp.bpad[k] * wb;
         o_pv[k] = bytes;
-        bytes += (size_t)B * 4;
+        bytes += (size_t)B * wb;
         o_kb[k] = bytes;
         bytes += (size_t)B * 4;
     }
@@ -193,23 +197,31 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     memcpy(blob.data(), lut.data(), 256);
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
-        uint32_t *peq = (uint32_t *)(blob.data() + o_peq[k]);
-        uint32_t *pv = (uint32_t *)(blob.data() + o_pv[k]);
+        uint8_t *peq = blob.data() + o_peq[k];
+        uint8_t *pv = blob.data() + o_pv[k];
         int32_t *kb = (int32_t *)(blob.data() + o_kb[k]);
+        const int bits = (int)wb * 8;
+        const auto put = [&](uint8_t *dst, size_t idx, uint64_t v) {
+            if (wb == 8)
+                ((uint64_t *)dst)[idx] = v;
+            else
+                ((uint32_t *)dst)[idx] = (uint32_t)v;
+        };
         for (int b = 0; b < p.n_barcodes; ++b) {
             const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
-            const int shift = 32 - m;
-            const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
-            const uint32_t pad = ~rows;  // virtual rows below the barcode: match everything, D stays 0
-            pv[b] = rows;
+            const int shift = bits - m;
+            const uint64_t all = bits == 64 ? ~0ULL : 0xFFFFFFFFULL;
+            const uint64_t rows = m == bits ? all : (((1ULL << m) - 1ULL) << shift);
+            const uint64_t pad = ~rows & all;  // virtual rows below the barcode: match everything, D stays 0
+            put(pv, (size_t)b, rows);
             for (int code = 0; code < bp.ncodes; ++code) {
-                uint32_t mask = pad;
+                uint64_t mask = pad;
                 for (int i = 0; i < m; ++i) {
                     const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
                     const bool wild = n_wild && ch == 'N';
-                    if (wild || (code < K && code_of[ch] == code)) mask |= 1u << (shift + i);
+                    if (wild || (code < K && code_of[ch] == code)) mask |= 1ULL << (shift + i);
                 }
-                peq[(size_t)code * bp.bpad[k] + b] = mask;
+                put(peq, (size_t)code * bp.bpad[k] + b, mask);
             }
             // allowed_error at the initial threshold, exactly as the device computes it
             long long ae;
@@ -238,8 +250,8 @@ int build_bitpar_tables(bdx_ctx *ctx) {
     const uint8_t *base = (const uint8_t *)ctx->F().bp_tables.p;
     bp.d_lut = base;
     for (int k = 0; k < npass; ++k) {
-        bp.d_peq[k] = (const uint32_t *)(base + o_peq[k]);
-        bp.d_pvinit[k] = (const uint32_t *)(base + o_pv[k]);
+        bp.d_peq[k] = base + o_peq[k];
+        bp.d_pvinit[k] = base + o_pv[k];
         bp.d_kb[k] = (const int32_t *)(base + o_kb[k]);
     }
     // known-score class (config level): SimpleScoring with unit costs, ScoreOnly output.
@@ -395,7 +407,8 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
 int build_diag_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
     BdxSeedPlan &sp = ctx->F().splan;
-    if (sp.enabled || !ctx->F().bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag)
+    if (sp.enabled || !ctx->F().bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag ||
+        ctx->F().bplan.word_bytes == 8)  // (the diagonal variant has 32-bit sweep words)
         return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;

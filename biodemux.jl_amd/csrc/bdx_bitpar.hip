@@ -26,6 +26,7 @@
 // are flattened (pair = read * B + barcode) so lanes stay busy for any B (96 = 1.5 waves).
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "bdx_core.h"
 
@@ -41,8 +42,8 @@ struct BitparArgs {
     int stage_bytes;     // capacity of EACH of the two staging areas (raw bytes, codes)
     int hist_entries;
     const uint8_t *lut;  // 256 bytes: byte -> symbol code
-    const uint32_t *peq[2];
-    const uint32_t *pvinit[2];
+    const void *peq[2];     // [ncodes][bpad] sweep words: uint32_t, or uint64_t for barcodes of 33..64 nt (W64)
+    const void *pvinit[2];  // [B]
     const int32_t *kb[2];
     int ncodes;
     int bpad[2];
@@ -92,9 +93,15 @@ struct BitparArgs {
 // The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
 // VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
 // are short and barrier-separated, so throughput follows the number of resident waves closely.
-template <int BS, int R, bool SEED, bool DIAG, int NW = 5>
+// W64: 64-bit sweep words (barcodes of 33..64 nt; every 64-bit operation is two VALU instructions) — the plain
+// sweep and the single-seed variant; the diagonal variant stays 32-bit.
+template <int BS, int R, bool SEED, bool DIAG, int NW = 5, bool W64 = false>
 __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     static_assert(!DIAG || SEED, "the diagonal variant is a seeded variant");
+    static_assert(!DIAG || !W64, "the diagonal variant has 32-bit sweep words");
+    using WT = typename std::conditional<W64, unsigned long long, uint32_t>::type;
+    constexpr int WB = W64 ? 8 : 4;  // bytes per sweep word
+    const auto popw = [](const WT x) __attribute__((always_inline)) { return W64 ? (int)__builtin_popcountll((unsigned long long)x) : (int)__builtin_popcount((uint32_t)x); };
     constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
     // NW (DIAG): position words per 4-mer key: 5 for reads of <= 152 staged bases, 10 for <= 312
     constexpr int SBMAX = NW <= 5 ? 8 : 4;           // 40 KiB of index either way
@@ -123,10 +130,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *sbm = (LDS uint32_t *)take(HASH ? (size_t)a.seed_bm_words * 4 : 0);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
     LDS unsigned char *lut = take(256);
-    LDS uint32_t *peq0 = (LDS uint32_t *)take((size_t)a.ncodes * a.bpad[0] * 4);
-    LDS uint32_t *peq1 = (LDS uint32_t *)take(cfg.is_dual ? (size_t)a.ncodes * a.bpad[1] * 4 : 0);
-    LDS uint32_t *pv0 = (LDS uint32_t *)take((size_t)B0 * 4);
-    LDS uint32_t *pv1 = (LDS uint32_t *)take((size_t)B1 * 4);
+    LDS WT *peq0 = (LDS WT *)take((size_t)a.ncodes * a.bpad[0] * WB);
+    LDS WT *peq1 = (LDS WT *)take(cfg.is_dual ? (size_t)a.ncodes * a.bpad[1] * WB : 0);
+    LDS WT *pv0 = (LDS WT *)take((size_t)B0 * WB);
+    LDS WT *pv1 = (LDS WT *)take((size_t)B1 * WB);
     LDS int *kb0 = (LDS int *)take((size_t)B0 * 4);
     LDS int *kb1 = (LDS int *)take((size_t)B1 * 4);
     LDS uint32_t *cand = (LDS uint32_t *)take((size_t)R * (cw0 + cw1) * 4);
@@ -171,16 +178,16 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
 
     // ---- tables -> LDS ----
     for (int i = tid; i < B0; i += BS) {
-        pv0[i] = a.pvinit[0][i];
+        pv0[i] = ((const WT *)a.pvinit[0])[i];
         kb0[i] = a.kb[0][i];
     }
-    for (int i = tid; i < a.ncodes * a.bpad[0]; i += BS) peq0[i] = a.peq[0][i];
+    for (int i = tid; i < a.ncodes * a.bpad[0]; i += BS) peq0[i] = ((const WT *)a.peq[0])[i];
     if (cfg.is_dual) {
         for (int i = tid; i < B1; i += BS) {
-            pv1[i] = a.pvinit[1][i];
+            pv1[i] = ((const WT *)a.pvinit[1])[i];
             kb1[i] = a.kb[1][i];
         }
-        for (int i = tid; i < a.ncodes * a.bpad[1]; i += BS) peq1[i] = a.peq[1][i];
+        for (int i = tid; i < a.ncodes * a.bpad[1]; i += BS) peq1[i] = ((const WT *)a.peq[1])[i];
     }
     for (int i = tid; i < 256; i += BS) lut[i] = a.lut[i];
     for (int i = tid; i < a.hist_entries; i += BS) hist[i] = 0;
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     struct Sweep {
         const LDS unsigned char *c;
         const LDS unsigned char *pq;
-        uint32_t Pv, Mv;
+        WT Pv, Mv;
         int score, best, ncol, r, b, p;
         int e_lo, e_hi, kbv;  // tracked sweeps (split mode of the seeded variants): first / last column j with score <= kbv
     };
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.r = r;
         w.b = b;
         w.Pv = (p ? pv1 : pv0)[b];
-        w.score = __builtin_popcount(w.Pv);  // = barcode length m
+        w.score = popw(w.Pv);  // = barcode length m
         w.kbv = (p ? kb1 : kb0)[b];
         w.best = w.score;
         if (!sg) {
@@ -427,12 +434,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.pq = (const LDS unsigned char *)((p ? peq1 : peq0) + b);
     };
     auto step = [&](Sweep &w, const int j, const int sh) __attribute__((always_inline)) {
-        const uint32_t Eq = *(const LDS uint32_t *)(w.pq + ((uint32_t)w.c[j] << sh));
-        const uint32_t Xv = Eq | w.Mv;
-        const uint32_t Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
-        uint32_t Ph = w.Mv | ~(Xh | w.Pv);
-        uint32_t Mh = w.Pv & Xh;
-        w.score += (int)(Ph >> 31) - (int)(Mh >> 31);
+        const WT Eq = *(const LDS WT *)(w.pq + ((uint32_t)w.c[j] << sh));
+        const WT Xv = Eq | w.Mv;
+        const WT Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
+        WT Ph = w.Mv | ~(Xh | w.Pv);
+        WT Mh = w.Pv & Xh;
+        w.score += (int)(Ph >> (8 * WB - 1)) - (int)(Mh >> (8 * WB - 1));
         Ph += Ph;  // << 1 as an add: full-rate on gfx950, shifts are not
         Mh += Mh;
         w.Pv = Mh | ~(Xv | Ph);
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             const int kk = __hip_atomic_fetch_add(&wcl[w.p * R + w.r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (kk < BDX_WCAP) {
                 const int jf_abs = (int)(w.c - (codes + roff[w.r])) + 1;  // 1-based column of sweep column 0
-                const int mm = __builtin_popcount((w.p ? pv1 : pv0)[w.b]);
+                const int mm = popw((w.p ? pv1 : pv0)[w.b]);
                 uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[w.r] * BDX_WCAP + kk) * 3;
                 dst[0] = (uint32_t)w.b;
                 // :semiglobal: first column of the restricted run; :hamming: first START position
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                             const int p = (int)((e >> 15) & 1u);
                             const int b = (int)(e & 0x7FFFu) - 1;
                             const int kk = (p ? kb1 : kb0)[b];
-                            const int mm = __builtin_popcount((p ? pv1 : pv0)[b]);
+                            const int mm = popw((p ? pv1 : pv0)[b]);
                             const int diag = prel - (int)(a.seed_hash_in_lds ? shps[slot] : a.seed_hash_ps[slot]);
                             int lo = diag - kk - 1, hi = diag + mm + kk + 1;  // [lo, hi) relative to the staged base
                             if (lo < 0) lo = 0;
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         const int P = (int)(meta & 255u), L = (int)(meta >> 8);
                         const uint32_t k0 = dk[2 * b], k1 = dk[2 * b + 1];
                         kk = (p ? kb1 : kb0)[b];
-                        mm = __builtin_popcount((p ? pv1 : pv0)[b]);
+                        mm = popw((p ? pv1 : pv0)[b]);
                         const LDS uint32_t *oc = occ + (size_t)rl * 256 * NW;
                         uint32_t SU[NW + 1];
 #pragma unroll
@@ -1007,8 +1014,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             const LDS uint32_t *e1 = slots + (1 * R + ltid) * 4;
             const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt0};
             const KnownPass kn1{true, e1[0], e1[1], e1[2], e1[3], cnt1};
-            const auto m0 = [&](const int b) { return (int)__builtin_popcount(pv0[b]); };
-            const auto m1 = [&](const int b) { return (int)__builtin_popcount(pv1[b]); };
+            const auto m0 = [&](const int b) { return popw(pv0[b]); };
+            const auto m1 = [&](const int b) { return popw(pv1[b]); };
             classify_known(cfg, m0, m1, rlen[ltid], kn0, kn1, v, p1, p2);
             done = true;
             if (a.tier) {
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 }
 
-template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5>
+template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5, bool W64 = false>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream, long long grid_override) {
     // the attribute is per device: one flag per device of this process.  Contexts of several OS threads may
     // launch concurrently: setting the attribute twice is harmless, the flag itself must not be a data race.
@@ -1123,7 +1130,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>,
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, W64>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
@@ -1138,7 +1145,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     if (grid_override > 0) blocks = grid_override;
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
+    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, W64>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1152,8 +1159,9 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     const int cw0 = cfg.pass[0].cand_words, cw1 = cfg.is_dual ? cfg.pass[1].cand_words : 0;
     size_t o = 0;
     o += al((size_t)gp.hist_entries * 4) + al(256);
-    o += al((size_t)bp.ncodes * bp.bpad[0] * 4) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * 4 : 0);
-    o += 2 * (al((size_t)B0 * 4) + al((size_t)B1 * 4));
+    const size_t wb = bp.word_bytes == 8 ? 8 : 4;
+    o += al((size_t)bp.ncodes * bp.bpad[0] * wb) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * wb : 0);
+    o += al((size_t)B0 * wb) + al((size_t)B1 * wb) + al((size_t)B0 * 4) + al((size_t)B1 * 4);
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 4 * al((size_t)R * 4) + al((size_t)R * 16);
     o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
@@ -1211,8 +1219,8 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
         a.pvinit[k] = bp.d_pvinit[k];
         a.kb[k] = bp.d_kb[k];
         a.bpad[k] = bp.bpad[k];
-        a.bshift[k] = 2;
-        while ((4 << (a.bshift[k] - 2)) < bp.bpad[k] * 4) a.bshift[k]++;
+        a.bshift[k] = 2;  // log2 of a peq row in bytes: bpad (a power of two) sweep words
+        while ((1 << a.bshift[k]) < bp.bpad[k] * (bp.word_bytes == 8 ? 8 : 4)) a.bshift[k]++;
     }
     a.ncodes = bp.ncodes;
     a.dbg = bp.dbg;
@@ -1268,7 +1276,11 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
         }
 #undef BDX_LAUNCH_D
     }
-#define BDX_LAUNCH_R(RR) return seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override) : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override)
+#define BDX_LAUNCH_R(RR)                                                                                                  \
+    return bp.word_bytes == 8 ? (seed ? launch_one<256, RR, true, false, 5, true>(a, lds, n_reads, stream, bp.grid_override)    \
+                                      : launch_one<256, RR, false, false, 5, true>(a, lds, n_reads, stream, bp.grid_override)) \
+                              : (seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override)                    \
+                                      : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override))
     switch (bp.reads_per_block) {
         case 256:
             BDX_LAUNCH_R(256);

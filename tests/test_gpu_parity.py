@@ -641,3 +641,41 @@ def test_tiered_budgets_c4_dual_trim():
         with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
             fuzz.assert_same(hc.classify(seq, off), exp, "C4 tiered")
             assert hc.kernel_path.startswith(TIER), hc.kernel_path
+
+
+# ---- barcodes of 33..64 nt: 64-bit sweep words (no drop to the unfiltered kernel) ----
+@pytest.mark.parametrize("lens,kw", [
+    ([40], dict(max_error_rate=0.1)),
+    ([64], dict(max_error_rate=0.2, min_delta=0.05)),
+    ([33, 40, 48, 56, 64], dict(max_error_rate=0.15, trim_side=3)),
+    ([20, 24, 32, 33, 47, 64], dict(max_error_rate=0.2, trim_side=5, min_delta=0.03)),   # mixed with short barcodes
+    ([48], dict(max_error_rate=0.12, matching_algorithm="hamming")),
+    ([36, 60], dict(max_error_rate=0.25, mismatch=1, indel=2, summary=True)),
+], ids=lambda v: ",".join(map(str, v)) if isinstance(v, list) else ",".join(f"{k}={x}" for k, x in v.items()))
+def test_long_barcodes_use_the_filtered_path(lens, kw):
+    rng = np.random.Generator(np.random.PCG64(121))
+    ls = rng.choice(lens, size=72)
+    bcs = synth.make_barcodes(72, 24, seed=122, lengths=ls, min_hamming=8)
+    seq, off, _ = synth.make_ragged_reads(bcs, 15000, 80, 220, seed=123, sub=0.04, ins=0.01, dele=0.01, repeat=dict(frac=0.1))
+    cfg = _c2_config(bcs, **kw)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "bitpar", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"long barcodes {lens} {kw} filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+            if flt != "off":
+                assert "bitpar" in hc.kernel_path, hc.kernel_path
+    assert (exp["bc1"] > 0).mean() > 0.25
+
+
+def test_barcodes_beyond_64_nt_still_classify_exactly():
+    """65 nt and more: outside the sweep's domain, the unfiltered exact kernel answers (slow, but exact)."""
+    bcs = synth.make_barcodes(6, 24, seed=124, lengths=[70, 66, 80, 65, 72, 90], min_hamming=10)
+    seq, off, _ = synth.make_ragged_reads(bcs, 1500, 100, 260, seed=125, sub=0.04)
+    cfg = _c2_config(bcs, max_error_rate=0.15, trim_side=3)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        fuzz.assert_same(hc.classify(seq, off), exp, "barcodes > 64 nt")
+        assert hc.kernel_path == "generic"
