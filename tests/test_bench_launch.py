@@ -36,6 +36,6 @@ def test_workload_table_covers_the_survey_configs():
     wl = bench.build_workload("C4", 2000, 0)
     assert wl["cfg"].is_dual and wl["algo_bytes"] == 174 and wl["outputs"] == ("bc1", "bc2", "keep_start", "keep_end")
     wl = bench.build_workload("C5", 50, 0)
-    assert wl["algo_bytes"] == 10012 and len(wl["seq"]) == 50 * 10000
+    assert wl["algo_bytes"] == 212 and wl["survey_bytes"] == 10012 and len(wl["seq"]) == 50 * 10000
     wl = bench.build_workload("C2d", 1000, 0)
     assert wl["cfg"].max_error_rate == 0.2 and wl["algo_bytes"] == 162
