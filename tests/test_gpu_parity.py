@@ -85,6 +85,19 @@ def test_fuzz_many_barcodes_vs_oracle(seed):
                 assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_fuzz_tiers_vs_oracle(seed):
+    """Random configs in and around the tiered budgets' domain (fuzz.random_case_tiers)."""
+    cfg, seq, off = fuzz.random_case_tiers(seed, n_reads=1200)
+    for want_pass in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want_pass)
+        exp = oc.classify(seq, off)
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"seed {seed} pass outputs {want_pass} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+
+
 def _c2_config(bcs, **kw):
     base = dict(bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"bc{i + 1}" for i in range(len(bcs))],
                 max_error_rate=0.1)

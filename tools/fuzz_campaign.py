@@ -51,6 +51,27 @@ for seed in range(lo2, hi2):
 print(f"many-barcode seeds {lo2}..{hi2 - 1}: paths {paths2}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
+# the tiered budgets' domain and its borders
+lo3, hi3 = int(os.environ.get("SEED3_LO", "9000")), int(os.environ.get("SEED3_HI", "9300"))
+paths3 = {}
+t0 = time.time()
+for seed in range(lo3, hi3):
+    cfg, seq, off = fuzz.random_case_tiers(seed)
+    for want in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want)
+        exp = oc.classify(seq, off)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                got = hc.classify(seq, off)
+                paths3[hc.kernel_path] = paths3.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"tier seed {seed} want_pass {want} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), f"tier seed {seed} counters"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"tier seeds {lo3}..{hi3 - 1}: paths {paths3}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
 def stress(name, bcs, seq, off, **kw):
     global bad
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
@@ -76,8 +97,8 @@ s, o, _ = synth.make_reads(b, 3000, 80, seed=4)
 stress("B=3000 m=16 (beyond the filter's barcode limit)", b, s, o, max_error_rate=0.13)
 b = synth.make_barcodes(12, 48, seed=5, min_hamming=12)
 s, o, _ = synth.make_reads(b, 4000, 200, seed=5)
-stress("m=48 (generic path)", b, s, o, max_error_rate=0.15)
-stress("m=48 trim5 (generic path)", b, s, o, max_error_rate=0.15, trim_side=5)
+stress("m=48 (64-bit sweep words)", b, s, o, max_error_rate=0.15)
+stress("m=48 trim5 (64-bit sweep words)", b, s, o, max_error_rate=0.15, trim_side=5)
 b = synth.make_barcodes(4, 300, seed=6, min_hamming=60)
 s, o, _ = synth.make_reads(b, 600, 700, seed=6)
 stress("m=300 (LDS-limited geometry)", b, s, o, max_error_rate=0.1, trim_side=3)
