@@ -692,3 +692,68 @@ def test_barcodes_beyond_64_nt_still_classify_exactly():
     with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
         fuzz.assert_same(hc.classify(seq, off), exp, "barcodes > 64 nt")
         assert hc.kernel_path == "generic"
+
+
+# ---- full BASELINE sizes: independent kernel paths must agree on EVERY read (the oracle checks a sample) ----
+def _device_run(cfg, seq, off, outputs, env=None, monkeypatch=None):
+    import torch
+
+    if env:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    n = len(off) - 1
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_out = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in outputs}
+    with H.bdx.HipClassifier(cfg) as hc:  # the developer switches are read here, once
+        if env:
+            for k in env:
+                monkeypatch.delenv(k)
+        hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, **{k: v.data_ptr() for k, v in d_out.items()})
+        hc.sync()
+        return {k: v.cpu().numpy() for k, v in d_out.items()}, hc.counts, hc.kernel_path
+
+
+def test_c2d_full_size_tiers_vs_full_budget(monkeypatch):
+    """C2 at the reference's default rate 0.2, 10 M reads: the tiered run (single seeds at capped budgets, then two
+    intact pieces in list mode) and the run that filters every read at the full budget are different kernels and
+    different algorithms — all 10 M verdicts and the counters must be identical; a strided sample equals the oracle."""
+    n = 10_000_000
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, n, 150)
+    cfg = _c2_config(bcs, max_error_rate=0.2)
+    a, ca, pa = _device_run(cfg, seq, off, ("bc1",))
+    b, cb, pb = _device_run(cfg, seq, off, ("bc1",), env={"BDX_NO_TIER": "1"}, monkeypatch=monkeypatch)
+    assert pa.startswith(TIER) and not pb.startswith(TIER), (pa, pb)
+    assert np.array_equal(a["bc1"], b["bc1"]) and np.array_equal(ca, cb)
+    idx = np.arange(0, n, 100)
+    sseq = seq.reshape(n, 150)[idx].reshape(-1)
+    soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
+    assert np.array_equal(a["bc1"][idx], exp["bc1"])
+
+
+def test_c4_full_size_paths_agree(monkeypatch):
+    """BASELINE config 4 at 10 M reads: tiered + clean-class exact kernel vs. full budget + by-construction register
+    DP: bc1, bc2 and both trim coordinates of every read, and the counters; a strided sample equals the oracle."""
+    n = 10_000_000
+    b1 = synth.make_barcodes(24, 24, seed=synth.SEED + 1)
+    b2 = synth.make_barcodes(16, 24, seed=synth.SEED + 2)
+    seq, off, _ = synth.make_reads(b1, n, 150, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True,
+                            bc_seqs2=b2, bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)],
+                            max_error_rate=0.2, trim_side=5, trim_side2=3)
+    outs = ("bc1", "bc2", "keep_start", "keep_end")
+    a, ca, pa = _device_run(cfg, seq, off, outs)
+    b, cb, pb = _device_run(cfg, seq, off, outs, env={"BDX_NO_TIER": "1", "BDX_NO_CLEAN": "1"}, monkeypatch=monkeypatch)
+    assert pa.startswith(TIER) and not pb.startswith(TIER), (pa, pb)
+    for k in outs:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(ca, cb)
+    idx = np.arange(0, n, 250)
+    sseq = seq.reshape(n, 150)[idx].reshape(-1)
+    soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
+    for k in outs:
+        assert np.array_equal(a[k][idx], exp[k]), k
