@@ -345,6 +345,10 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
         const double false_pairs = 150.0 * (double)pieces.size() / space;
         sp.rcap = 8;
         while (sp.rcap < 64 && (double)sp.rcap < 4.0 + 4.0 * false_pairs) sp.rcap *= 2;
+        // queues: the planted pair plus the chance pairs, with slack for the spread between the reads of a tile
+        sp.qmul = sp.rcap >= 16 ? 8 : 4;
+        const int want = (int)std::ceil((1.0 + false_pairs) * 1.5 + 1.0);  // (C2: 4 — one more entry per read would cost the fourth workgroup per CU)
+        if (want > sp.qmul) sp.qmul = want > 48 ? 48 : want;
     }
     sp.bm_words = (1 << sp.bm_log2) / 32;
     sp.hash_log2 = 8;
@@ -881,7 +885,13 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
         if (full.bplan.enabled && plain_windows && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
             ctx->cur = 1;
             rc = build_bitpar_tables(ctx);
-            if (rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped) rc = build_seed_tables(ctx, true);
+            if (rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped) {
+                rc = build_seed_tables(ctx, true);
+                // very many barcodes: moderately selective 8-base seeds (a dozen chance pairs per read) still beat
+                // the full-budget filter by far
+                if (rc == BDX_OK && !ctx->fs[1].splan.enabled) rc = build_seed_tables(ctx, false);
+                if (rc == BDX_OK && ctx->fs[1].splan.enabled && ctx->fs[1].splan.q < 8) ctx->fs[1].splan.enabled = 0;
+            }
             ctx->cur = 0;
             if (rc != BDX_OK) return bail(rc);
             ctx->tiered = ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped && ctx->fs[1].splan.enabled;

@@ -54,6 +54,7 @@ struct BitparArgs {
     const uint32_t *dkeys[2];  //   ... and the 8-bit keys of its pieces (2 words)
     int diag_kmax, diag_qcap;
     int seed_rcap;         // sweep records per read (power of two, sized to the expected seeded barcodes)
+    int seed_qmul;         // sweep-record queue entries per read (the hit queue has twice as many)
     int seed_hash_in_lds;  // 0: the hash table is probed in L2 (large barcode sets)
     int seed_n_always[2];
     const uint32_t *seed_bitmap;
@@ -112,8 +113,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const int tid = threadIdx.x;
     const int RCAP = SEED ? a.seed_rcap : 8;
     const int RCAP_LOG2 = 31 - __builtin_clz(RCAP);
-    const int SQCAP = (SEED && a.seed_rcap >= 16) ? 16 * R : 8 * R;  // capacity of the seed-hit queue
-    const int PQCAP = DIAG ? a.diag_qcap * SB : (SEED ? (a.seed_rcap >= 16 ? 8 * R : 4 * R) : 4 * R);  // capacity of the sweep-record queue
+    // queue capacities per read follow the expected number of seeded (read, barcode) pairs (seed_qmul, >= 4: sized
+    // on the host from the piece count; very many barcodes seed ~10 pairs per read by chance)
+    const int SQCAP = SEED && !DIAG ? 2 * a.seed_qmul * R : 8 * R;  // capacity of the seed-hit queue
+    const int PQCAP = DIAG ? a.diag_qcap * SB : (SEED ? a.seed_qmul * R : 4 * R);  // capacity of the sweep-record queue
     const int npass = cfg.is_dual ? 2 : 1;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
@@ -1175,7 +1178,8 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     } else if (sp && sp->enabled) {
         o += al((size_t)sp->bm_words * 4) + al((size_t)(bp.stage_bytes >> 2) + 32);
         if (sp->hash_in_lds) o += al((size_t)4 << sp->hash_log2) + al((size_t)1 << sp->hash_log2);
-        o += al((size_t)(sp->rcap >= 16 ? 16 : 8) * R * 4) + al((size_t)(sp->rcap >= 16 ? 16 : 8) * R) + 3 * al((size_t)R * sp->rcap * 4);
+        const size_t sq = (size_t)2 * (sp->qmul >= 4 ? sp->qmul : 4) * R;  // hit-queue entries
+        o += al(sq * 4) + al(sq) + 3 * al((size_t)R * sp->rcap * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
     }
     o += al(32);
@@ -1244,6 +1248,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.seed_bm_words = sp.bm_words;
     a.seed_bm_log2 = sp.bm_log2;
     a.seed_rcap = sp.rcap > 0 ? sp.rcap : 8;
+    a.seed_qmul = sp.qmul >= 4 ? sp.qmul : 4;
     a.diag_kmax = sp.diag_kmax;
     a.diag_qcap = bp.diag_qcap > 0 ? bp.diag_qcap : 64;
     for (int k = 0; k < 2; ++k) {

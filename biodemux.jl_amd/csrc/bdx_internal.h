@@ -124,6 +124,7 @@ struct BdxSeedPlan {
     int bm_words;          // bitmap words (hashed: bit index = (key * 0x9E3779B1) >> (32 - bm_log2))
     int bm_log2;
     int rcap;              // sweep records per read (power of two)
+    int qmul;              // sweep-record queue entries per read (the hit queue has twice as many)
     int hash_in_lds;       // hash table small enough to live in LDS
     int hash_log2;         // hash slots = 1 << hash_log2; entry = key << 16 | pass << 15 | (barcode + 1)
     int n_always[2];       // barcodes swept unconditionally (wildcards / too-short pieces)
