@@ -895,6 +895,12 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
             ctx->cur = 0;
             if (rc != BDX_OK) return bail(rc);
             ctx->tiered = ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped && ctx->fs[1].splan.enabled;
+            // with_delta and a min_delta beyond the score of an unseen barcode: not even a perfect match can be
+            // proven unambiguous at the capped budgets (only a visible runner-up could settle a read) — tier 1
+            // would be a pass over the whole batch for next to nothing
+            if (ctx->tiered && config->min_delta != 0.0)
+                for (int k = 0; k < (config->is_dual ? 2 : 1); ++k)
+                    if (!(ctx->fs[1].bplan.tier_slo[k] >= config->min_delta)) ctx->tiered = 0;
         }
     }
     ctx->path = ctx->F().bplan.enabled ? (ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";

@@ -550,7 +550,7 @@ TIER = "tier1:qgram+bitpar > "
     dict(max_error_rate=0.2),                                  # no_delta: settled as soon as tier 1 finds a barcode
     dict(max_error_rate=0.2, min_delta=0.05),                  # with_delta: 1/24 < 0.05 <= 2/24 ...
     dict(max_error_rate=0.2, min_delta=0.1),
-    dict(max_error_rate=0.17, min_delta=0.2),                  # min_delta above everything tier 1 can prove: mostly tier 0
+    dict(max_error_rate=0.17, min_delta=0.12),                 # min_delta just below the score of an unseen barcode (3/24): only perfect matches settle
     dict(max_error_rate=0.25),                                 # kb = 6: the full budget is the plain sweep
     dict(max_error_rate=0.13, min_delta=0.04),
 ], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
@@ -611,7 +611,7 @@ def test_tiered_budgets_ragged_reads_and_hints():
     dict(max_error_rate=0.2, trim_side=5),
     dict(max_error_rate=0.2, trim_side=3, min_delta=0.05),
     dict(max_error_rate=0.2, summary=True),
-    dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15),             # demo2's costs: weighted, cmin = 1
+    dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.1),              # demo2's costs: weighted, cmin = 1
     dict(max_error_rate=0.3, mismatch=2, indel=3, trim_side=5),                 # cmin = 2: an unseen barcode costs >= 2 (kb1 + 1)
     dict(max_error_rate=0.2, matching_algorithm="hamming", min_delta=0.05),
     dict(max_error_rate=0.2, nindel=2, trim_side=3),                            # N-scoring (no N in these barcodes)
@@ -757,3 +757,52 @@ def test_c4_full_size_paths_agree(monkeypatch):
     exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
     for k in outs:
         assert np.array_equal(a[k][idx], exp[k]), k
+
+
+# ---- stress shapes at the borders of the fast paths' domain (formerly only in tools/fuzz_campaign.py) ----
+def _stress_cases():
+    b1500 = synth.make_barcodes(1500, 20, seed=3, min_hamming=5)
+    s1500 = synth.make_reads(b1500, 6000, 100, seed=3)[:2]
+    b3000 = synth.make_barcodes(3000, 16, seed=4, min_hamming=4)
+    s3000 = synth.make_reads(b3000, 2000, 80, seed=4)[:2]
+    b300 = synth.make_barcodes(4, 300, seed=6, min_hamming=60)
+    s300 = synth.make_reads(b300, 600, 700, seed=6)[:2]
+    b1 = synth.make_barcodes(1, 24, seed=7)
+    s1 = synth.make_reads(b1, 5, 150, seed=7)[:2]
+    b96 = synth.make_barcodes(96, 24)
+    s96 = synth.make_reads(b96, 70001, 150, seed=8)[:2]
+    small = (s96[0][:150 * 3000], s96[1][:3001])
+    return {
+        "B1500_rate0.1": (b1500, s1500, dict(max_error_rate=0.1)),
+        "B1500_rate0.2_tiered": (b1500, s1500, dict(max_error_rate=0.2)),
+        "B1500_trim3_delta": (b1500, s1500, dict(max_error_rate=0.1, trim_side=3, min_delta=0.06)),
+        "B3000_beyond_the_barcode_limit": (b3000, s3000, dict(max_error_rate=0.13)),
+        "m300_lds_limited": (b300, s300, dict(max_error_rate=0.1, trim_side=3)),
+        "B1_5reads": (b1, s1, dict(max_error_rate=0.2)),
+        "70001_reads_ragged_last_tile": (b96, s96, dict(max_error_rate=0.1)),
+        "negative_match_cost": (b96[:12], small, dict(max_error_rate=0.2, match=-1, mismatch=2, indel=3)),
+        "nine_symbol_alphabet": (["ACGTRYKMSWACGTRYKMSW", "RYKMSWBDHVACGTACGTAC"], small, dict(max_error_rate=0.2)),
+        "min_delta_beyond_an_unseen_barcode": (b96, small, dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15)),
+    }
+
+
+@pytest.mark.parametrize("name", ["B1500_rate0.1", "B1500_rate0.2_tiered", "B1500_trim3_delta", "B3000_beyond_the_barcode_limit",
+                                  "m300_lds_limited", "B1_5reads", "70001_reads_ragged_last_tile", "negative_match_cost",
+                                  "nine_symbol_alphabet", "min_delta_beyond_an_unseen_barcode"])
+def test_stress_shapes(name):
+    bcs, (seq, off), kw = _stress_cases()[name]
+    cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
+                            ids=[str(i) for i in range(len(bcs))], **kw)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            fuzz.assert_same(hc.classify(seq, off), exp, f"{name} filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+            path = hc.kernel_path
+    if name in ("B3000_beyond_the_barcode_limit", "m300_lds_limited", "negative_match_cost", "nine_symbol_alphabet"):
+        assert path == "generic"
+    if name == "B1500_rate0.2_tiered":
+        assert path.startswith(TIER)
+    if name == "min_delta_beyond_an_unseen_barcode":  # tier 1 could prove nothing: it is not built
+        assert not path.startswith(TIER) and "bitpar" in path
