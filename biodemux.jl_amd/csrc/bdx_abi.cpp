@@ -881,7 +881,14 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
         const bool strict_full = full.splan.enabled && !full.splan.diag && full.splan.q >= 7;
         // (the unit-level API's hand-made windows stay on the plain path)
         bool plain_windows = true;
-        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) plain_windows = plain_windows && config->pass[k].explicit_window == 0;
+        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) {
+            plain_windows = plain_windows && config->pass[k].explicit_window == 0;
+            // N-scoring with real wildcards: position-dependent indel costs — "an alignment's result does not depend on
+            // the running threshold" is only argued (and fuzzed) for uniform costs; such configs stay on one tier
+            if (config->algorithm == BDX_ALG_SEMIGLOBAL && config->has_nindel)
+                for (uint32_t i = 0; i < config->pass[k].bc_off[config->pass[k].n_barcodes]; ++i)
+                    if (config->pass[k].bc_bytes[i] == 'N') plain_windows = false;
+        }
         if (full.bplan.enabled && plain_windows && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
             ctx->cur = 1;
             rc = build_bitpar_tables(ctx);

@@ -117,18 +117,19 @@ def random_case_tiers(seed: int, n_reads: int = 1500):
     B = int(rng.integers(16, 161))
     lo = int([12, 16, 20, 24, 24, 28, 32, 40, 48, 64][int(rng.integers(0, 10))])
     hi = lo if rng.random() < 0.5 else min(64, lo + int(rng.integers(1, 17)))
-    bcs = _rand_barcodes(rng, B, lo, hi, False)
+    with_n = rng.random() < 0.15  # N in barcodes: a wildcard under N-scoring and :hamming, a literal fifth symbol otherwise
+    bcs = _rand_barcodes(rng, B, lo, hi, with_n)
     dual = rng.random() < 0.3
-    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 64)), lo, hi, False) if dual else []
+    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 64)), lo, hi, with_n) if dual else []
     unit = rng.random() < 0.6
     rate = float([0.13, 0.15, 0.17, 0.2, 0.2, 0.22, 0.25, 0.3][int(rng.integers(0, 8))])
     md = float([0.0, 0.0, 0.02, 0.04, 0.05, 0.08, 0.1, 0.13, 0.2][int(rng.integers(0, 9))])
     rngs = ["1:end"] * 6 + ["5:end-3", "1:120", "1:60", "20:end", "end-80:end"]
     kw = dict(
-        bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
+        bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
         max_error_rate=rate, min_delta=md, match=0,
         mismatch=1 if unit else int(rng.integers(1, 4)), indel=1 if unit else int(rng.integers(1, 4)),
-        nindel=(int(rng.integers(1, 3)) if rng.random() < 0.1 else None),
+        nindel=(int(rng.integers(1, 3)) if rng.random() < (0.6 if with_n else 0.1) else None),
         ref_search_range=H.bdx.parse_dynamic_range(rngs[int(rng.integers(0, len(rngs)))]),
         barcode_start_range=H.bdx.parse_dynamic_range(rngs[int(rng.integers(0, len(rngs)))] if rng.random() < 0.2 else "1:end"),
         barcode_end_range=H.bdx.parse_dynamic_range(rngs[int(rng.integers(0, len(rngs)))] if rng.random() < 0.2 else "1:end"),
@@ -137,15 +138,18 @@ def random_case_tiers(seed: int, n_reads: int = 1500):
         matching_algorithm=alg,
     )
     if dual:
-        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[len(b) for b in bcs2], ids2=[f"b{i}" for i in range(len(bcs2))],
-                  trim_side2=[None, None, 3, 5][int(rng.integers(0, 4))])
+        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[sum(c != "N" for c in b) for b in bcs2],
+                  ids2=[f"b{i}" for i in range(len(bcs2))], trim_side2=[None, None, 3, 5][int(rng.integers(0, 4))])
     cfg = H.bdx.DemuxConfig(**kw)
     max_len = int([100, 150, 150, 180, 250][int(rng.integers(0, 5))])
     max_len = max(max_len, hi + 20)
     second = (bcs2, max_len // 2, None) if dual else None
     repeat = dict(frac=0.3) if rng.random() < 0.3 else None
     err = float([0.02, 0.04, 0.06, 0.08][int(rng.integers(0, 4))])
-    seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 2 if rng.random() < 0.5 else max_len, max_len, seed=seed,
+    plant = [b.replace("N", "ACGT"[int(rng.integers(0, 4))]) for b in bcs]
+    if second is not None:
+        second = ([b.replace("N", "C") for b in bcs2], second[1], second[2])
+    seq, off, _ = synth.make_ragged_reads(plant, n_reads, max_len // 2 if rng.random() < 0.5 else max_len, max_len, seed=seed,
                                           plant_frac=0.85, sub=err, ins=err / 3, dele=err / 3, n_rate=0.003,
                                           plant_hi=(max_len // 3 if dual else None), second=second, repeat=repeat)
     return cfg, seq, off
