@@ -1094,6 +1094,18 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             exc_list = (uint32_t *)ctx->d_exc.p;
         }
         HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
+        // restricted runs of passes that only report score (+ end) through the clean-class DP start m + kb columns before
+        // the first end column (orc_selftest_clean_short_lookback); everything else keeps 2 (m + kb) + 1
+        int short_lb[2] = {0, 0};
+        for (int k = 0; k < npass; ++k) {
+            const int ts = ctx->dev.pass[k].trim_side;
+            short_lb[k] = ctx->plan.clean && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !ctx->dev.need_traceback &&
+                          (ts == 0 || (ts == 5 && o.pass_start == nullptr));
+        }
+        for (BdxFilterSet &f : ctx->fs) {
+            f.bplan.short_lb[0] = short_lb[0];
+            f.bplan.short_lb[1] = short_lb[1];
+        }
         BdxTierArgs t0{0, nullptr, nullptr, nullptr, nullptr};
         if (tiered) {
             HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));

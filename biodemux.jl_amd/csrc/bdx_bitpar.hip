@@ -71,6 +71,8 @@ struct BitparArgs {
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
+    int short_lb[2]; // per pass: the exact kernel only reports score (+ end) through the clean-class DP: its restricted
+                     // run may start m + kb columns before the first end column instead of 2 (m + kb) + 1
     // tiered budgets (bdx_abi.cpp): tier 1 appends the reads it cannot settle to tier_list; tier 0 then runs in
     // LIST MODE over exactly those reads (in_list / *in_count; slot staging, as the reads are scattered)
     int tier;                      // 1: this launch is tier 1 (capped budgets)
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 uint32_t *dst = (w.p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[w.r] * BDX_WCAP + kk) * 3;
                 dst[0] = (uint32_t)w.b;
                 // :semiglobal: first column of the restricted run; :hamming: first START position
-                dst[1] = (uint32_t)(jf_abs + w.e_lo - (sg ? 2 * (mm + w.kbv) + 1 : mm - 1));
+                dst[1] = (uint32_t)(jf_abs + w.e_lo - (sg ? (a.short_lb[w.p] ? mm + w.kbv : 2 * (mm + w.kbv) + 1) : mm - 1));
                 dst[2] = (uint32_t)(jf_abs + w.e_hi);
             }
         }
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                         if (kk < BDX_WCAP) {
                             uint32_t *dst = (p ? a.wins_out[1] : a.wins_out[0]) + ((long long)rids[r] * BDX_WCAP + kk) * 3;
                             dst[0] = (uint32_t)b;
-                            dst[1] = (uint32_t)(e_lo - (sg ? 2 * (mm + kbv) + 1 : mm - 1));
+                            dst[1] = (uint32_t)(e_lo - (sg ? (a.short_lb[p] ? mm + kbv : 2 * (mm + kbv) + 1) : mm - 1));
                             dst[2] = (uint32_t)e_hi;
                         }
                     } else {
@@ -1229,6 +1231,8 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.ncodes = bp.ncodes;
     a.dbg = bp.dbg;
     a.slot_bytes = bp.slot_bytes;
+    a.short_lb[0] = bp.short_lb[0];
+    a.short_lb[1] = bp.short_lb[1];
     a.ncode = bp.ncode_N;
     a.split = split;
     a.exc_list = exc_list;

@@ -104,6 +104,7 @@ struct BdxBitparPlan {
     int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
     long long grid_override;  // > 0: forced persistent grid (tuning, BdxTuning::grid)
+    int short_lb[2];       // per launch and pass: short lookback of the restricted runs (score / end-only clean-class passes)
     int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
     int tier_capped;       // tier 1: some barcode's budget was capped below its full budget

@@ -1244,6 +1244,73 @@ int64_t orc_selftest_clean_class(uint64_t seed, int64_t iters, int64_t *first_ba
     return bad;
 }
 
+/* Short lookback of the clean class: when only the SCORE and the END column of the best alignment
+ * are observable (ScoreOnly, or traceback with trim_side 5 whose start nobody reads), the clean-class DP restricted
+ * to  e_lo - (m + kb) .. e_hi  ([e_lo, e_hi] = first / last column with unit distance <= kb) returns the same
+ * (score, end) as the reference's full run: a cell <= allowed_error is the end of a path of <= m + kb columns that
+ * starts at row 0, so it is exact once the run started m + kb columns earlier; the 2(m + kb) + 1 columns of the
+ * general restricted run (§3.2) are only needed for the ORIGINS under ties. */
+int64_t orc_selftest_clean_short_lookback(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[6] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[260];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 2 + (int64_t)(st_next(&s) % 31);
+        int64_t n = (int64_t)(st_next(&s) % 250);
+        const int lowc = (st_next(&s) % 5) == 0;
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : 4)];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : ((st_next(&s) % 50) ? 4 : 5))];
+        int copies = (int)(st_next(&s) % 3);
+        for (int cpy = 0; cpy < copies && n > 0; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 5) r[pos++] = (uint8_t)AL[st_next(&s) % 4];
+                else if (u < 8) continue;
+                else if (u < 11) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        double rate = RATES[st_next(&s) % 8];
+        int64_t mismatch = 1 + (int64_t)(st_next(&s) % 3), indel = 1 + (int64_t)(st_next(&s) % 3);
+        int64_t match = (st_next(&s) % 8) == 0 ? 1 : 0;
+        int32_t mode = (int32_t)(st_next(&s) % 2);
+        int32_t trim = mode ? 5 : 0; /* ScoreOnly, or traceback with trim_side 5 (only the end is compared) */
+        int64_t first = 1, last = n;
+        if (n > 0 && (st_next(&s) % 3) == 0) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        int64_t ae0 = (int64_t)floor(rate * (double)m);
+        int64_t cmin = mismatch < indel ? mismatch : indel;
+        int64_t kb = ae0 < 0 ? -1 : ae0 / cmin;
+        if ((st_next(&s) % 3) == 0 && kb > 0) kb = (int64_t)(st_next(&s) % (uint64_t)(kb + 1)); /* a capped budget (tier 1) */
+        double used = (st_next(&s) % 3) ? rate : rate * (double)(st_next(&s) % 100) / 100.0;
+        orc_align_t full = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, 0, 0, mode, trim, first,
+                                                last, n, 1, m, INT64_MIN, INT64_MAX);
+        int64_t e_lo = 0, e_hi = 0;
+        int64_t f = first < 1 ? 1 : first, l = last > n ? n : last;
+        int found = (n > 0 && l >= f && kb >= 0) ? (int)unit_cols(q, m, r, f, l, 0, kb, &e_lo, &e_hi) : 0;
+        if (!found) continue; /* (the barcode is not a candidate at this budget) */
+        orc_align_t got = clean_dp(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, e_lo - (m + kb), e_hi);
+        /* with a capped budget the full run may record an alignment of more than kb operations outside the window:
+         * the claim (and the tier settle rule) is about results within the budget */
+        int64_t ops_bound = kb * cmin; /* an alignment of <= kb operations may cost up to kb * max cost; compare when the full result is within kb * cmin */
+        if (full.raw > ops_bound) continue;
+        if (got.raw != full.raw || (mode && got.end != full.end)) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = full.raw;
+                first_bad[4] = got.raw; first_bad[5] = full.end; first_bad[6] = got.end; first_bad[7] = mode * 10 + trim;
+            }
+            bad++;
+        }
+    }
+    return bad;
+}
+
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
     static const char AL[6] = "ACGTN";
     static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};

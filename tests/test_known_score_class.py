@@ -51,3 +51,11 @@ def test_clean_class_full_dp_equals_the_cut_off_loop():
     fb = (C.c_int64 * 8)()
     bad = H.orc.lib().orc_selftest_clean_class(20260515, 400_000, fb)
     assert bad == 0, list(fb)
+
+
+def test_clean_class_short_lookback_for_score_and_end():
+    """Score-only and end-only passes of the clean class: a restricted run that starts m + kb columns before the first
+    end column (instead of 2 (m + kb) + 1) returns the reference's score and end column — also with a capped budget."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_clean_short_lookback(20260515, 400_000, fb)
+    assert bad == 0, list(fb)
