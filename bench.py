@@ -299,7 +299,7 @@ def main():
                     if "hbm_read_bytes_corrected" in e:
                         tot += e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
                         src.append(kname)
-                    c = e.get("counters_per_dispatch", {})
+                    c = e.get("counters_per_step", {})
                     if "bitpar" in kname and c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
                         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES cycles
                         # summed over the 32 shader engines
@@ -330,7 +330,7 @@ def main():
                        "allreduce": allreduce_via,
                        "matched_fraction": float(counts[1]) / max(float(counts[0]), 1.0), "gen_seconds": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per step (all kernels of one classify call)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * n,
                          "kernel_ms_avg": kern_ms_avg, "algorithmic_bytes_per_read": algo,
                          "survey_bytes_per_read": wl.get("survey_bytes", algo),
