@@ -780,8 +780,12 @@ int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
             const size_t new_bytes = bdx_stats_words(ctx, p, w, want) * 8;
             DevBuf nb;
             HIP_TRY(ctx, nb.ensure(new_bytes));
-            HIP_TRY(ctx, hipMemset(nb.p, 0, new_bytes));
-            if (old_bytes) HIP_TRY(ctx, hipMemcpy(nb.p, ctx->st_tab[p][w].p, old_bytes, hipMemcpyDeviceToDevice));
+            hipError_t e1 = hipMemset(nb.p, 0, new_bytes);
+            if (e1 == hipSuccess && old_bytes) e1 = hipMemcpy(nb.p, ctx->st_tab[p][w].p, old_bytes, hipMemcpyDeviceToDevice);
+            if (e1 != hipSuccess) {
+                nb.release();
+                return fail(ctx, BDX_E_DEVICE, "growing the statistics tables failed: %s", hipGetErrorString(e1));
+            }
             ctx->st_tab[p][w].release();
             ctx->st_tab[p][w] = nb;  // row-major by key: the old table is a prefix of the new one
         }

@@ -424,15 +424,14 @@ class HipClassifier:
     def stats_tables(self, reduced: bool = False) -> dict:
         """The DemuxStats histograms the device collected (summary = true): ``{pass: {"pos" | "len" | "raw":
         (int64[rows, n_barcodes], key0)}}`` — row r of a table holds key r + key0 (bdx_stats_shape / bdx_get_stats).
-        ``reduced`` reads the tables summed over the ranks by allreduce_counts()."""
+        ``reduced`` reads the tables summed over the ranks by allreduce_counts() (rows a later batch appended to the
+        per-rank tables since then read as zero)."""
         out = {}
         for p in range(2 if self.cfg.is_dual else 1):
             out[p] = {}
             for name, w in STATS_WHICH.items():
                 rows, key0, nb = C.c_int64(), C.c_int64(), C.c_int64()
                 self._check(self.lib.bdx_stats_shape(self.h, p, w, C.byref(rows), C.byref(key0), C.byref(nb)))
-                if reduced and name != "raw":  # the reduced tables have the height the ranks agreed on
-                    pass
                 tab = np.zeros((max(rows.value, 0), max(nb.value, 0)), dtype=np.int64)
                 if tab.size or rows.value:
                     buf = np.zeros(max(tab.size, 1), dtype=np.int64)
