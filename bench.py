@@ -287,7 +287,7 @@ def main():
     # rocprofv3 --pmc summary of this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # x2 correction on FETCH_SIZE — MI355X_MICROARCH.md §HBM), produced by tools/summarize_prof.py.
     traffic, traffic_src = None, None
-    valu = None  # from the same committed profile: what actually bounds the kernel
+    valu = None  # from the same committed profile, per kernel: what actually bounds the path
     try:
         tagged = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
                         if f.endswith("_pmc.json") and f"_{args.config}_" in f)
@@ -300,13 +300,13 @@ def main():
                         tot += e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
                         src.append(kname)
                     c = e.get("counters_per_step", {})
-                    if "bitpar" in kname and c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
-                        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES cycles
-                        # summed over the 32 shader engines
-                        valu = {"kernel": kname,
-                                "valu_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["SQ_BUSY_CYCLES"] / 32), 3),
-                                "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
-                                "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
+                    if c.get("SQ_INSTS_VALU", 0.0) / n >= 1.0 and c.get("SQ_WAVE_CYCLES"):
+                        # VALU wave-instructions per read of the batch (all of the kernel's launches in one step) and the
+                        # fraction of its waves' lifetime spent issuing; peak issue = 1024 SIMDs x 1 wave-instruction / 2 cycles
+                        valu = (valu or []) + [{
+                            "kernel": kname, "launches_per_step": e.get("meta", {}).get("dispatches_per_step"),
+                            "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
+                            "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}]
                 if src:
                     traffic, traffic_src = tot, f"profiles/{tagged[-1]} ({' + '.join(src)})"
     except Exception:
