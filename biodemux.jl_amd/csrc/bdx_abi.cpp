@@ -150,7 +150,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         if (c.match < 0 || cmin < 1) return BDX_OK;
     }
     const bool n_wild = (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel) || c.algorithm == BDX_ALG_HAMMING;
-    // alphabet = distinct barcode bytes (<= 7), everything else shares the "other" code
+    // alphabet = distinct barcode bytes (<= 15: the IUPAC letters), everything else shares the "other" code
     int code_of[256];
     for (int i = 0; i < 256; ++i) code_of[i] = -1;
     int K = 0;
@@ -166,7 +166,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
             for (uint32_t i = 0; i < m; ++i) {
                 const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
                 if (code_of[ch] < 0) {
-                    if (K == 7) return BDX_OK;
+                    if (K == 15) return BDX_OK;
                     code_of[ch] = K++;
                 }
             }

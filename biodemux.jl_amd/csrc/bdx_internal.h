@@ -102,7 +102,7 @@ struct BdxBitparPlan {
     int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
     int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
-    int ncodes;            // symbol codes incl. the trailing "other" code (<= 8)
+    int ncodes;            // symbol codes incl. the trailing "other" code (<= 16)
     long long grid_override;  // > 0: forced persistent grid (tuning, BdxTuning::grid)
     int short_lb[2];       // per launch and pass: short lookback of the restricted runs (score / end-only clean-class passes)
     int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)

@@ -781,14 +781,15 @@ def _stress_cases():
         "B1_5reads": (b1, s1, dict(max_error_rate=0.2)),
         "70001_reads_ragged_last_tile": (b96, s96, dict(max_error_rate=0.1)),
         "negative_match_cost": (b96[:12], small, dict(max_error_rate=0.2, match=-1, mismatch=2, indel=3)),
-        "nine_symbol_alphabet": (["ACGTRYKMSWACGTRYKMSW", "RYKMSWBDHVACGTACGTAC"], small, dict(max_error_rate=0.2)),
+        "fourteen_symbol_alphabet": (["ACGTRYKMSWACGTRYKMSW", "RYKMSWBDHVACGTACGTAC"], small, dict(max_error_rate=0.2)),
+        "seventeen_symbol_alphabet": (["ACGTRYKMSWBDHVNEFACG", "ACGTACGTACGTACGTACGT"], small, dict(max_error_rate=0.2, trim_side=3)),
         "min_delta_beyond_an_unseen_barcode": (b96, small, dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15)),
     }
 
 
 @pytest.mark.parametrize("name", ["B1500_rate0.1", "B1500_rate0.2_tiered", "B1500_trim3_delta", "B3000_beyond_the_barcode_limit",
                                   "m300_lds_limited", "B1_5reads", "70001_reads_ragged_last_tile", "negative_match_cost",
-                                  "nine_symbol_alphabet", "min_delta_beyond_an_unseen_barcode"])
+                                  "fourteen_symbol_alphabet", "seventeen_symbol_alphabet", "min_delta_beyond_an_unseen_barcode"])
 def test_stress_shapes(name):
     bcs, (seq, off), kw = _stress_cases()[name]
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
@@ -800,8 +801,10 @@ def test_stress_shapes(name):
             fuzz.assert_same(hc.classify(seq, off), exp, f"{name} filter {flt} [{hc.kernel_path}]")
             assert np.array_equal(hc.counts, oc.counts)
             path = hc.kernel_path
-    if name in ("B3000_beyond_the_barcode_limit", "m300_lds_limited", "negative_match_cost", "nine_symbol_alphabet"):
+    if name in ("B3000_beyond_the_barcode_limit", "m300_lds_limited", "negative_match_cost", "seventeen_symbol_alphabet"):
         assert path == "generic"
+    if name == "fourteen_symbol_alphabet":  # IUPAC letters are literals for the reference; up to 15 symbols stay filtered
+        assert "bitpar" in path
     if name == "B1500_rate0.2_tiered":
         assert path.startswith(TIER)
     if name == "min_delta_beyond_an_unseen_barcode":  # tier 1 could prove nothing: it is not built
