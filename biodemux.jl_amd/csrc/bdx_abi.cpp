@@ -93,7 +93,7 @@ int plan_generic(bdx_ctx *ctx) {
     size_t bc_total = 0;
     for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) bc_total += ctx->cfg.pass[k].bc_off[ctx->cfg.pass[k].n_barcodes];
     p.bc_stage_bytes = bc_total <= 32 * 1024 ? (int)((bc_total + 15) & ~(size_t)15) : 0;
-    p.hist_entries = d.n_counts <= 4096 ? d.n_counts : 0;
+    p.hist_entries = d.n_counts <= 2048 ? d.n_counts : 2048;  // LDS histogram: the scalars + the first per-barcode slots (>= 4)
     const size_t fixed = (size_t)(B0 + 1 + B1 + 1 + B0 + B1) * 4 + 16 + (size_t)p.bc_stage_bytes + 16 +
                          (size_t)p.hist_entries * 4 + 16;
     const int tries[3] = {256, 128, 64};
@@ -172,7 +172,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
             }
         }
     }
-    if (cand_words > 64) return BDX_OK;
+    if (cand_words > 128) return BDX_OK;  // <= 4096 barcodes per config (both passes together)
     bp.ncodes = K + 1;
     bp.ncode_N = code_of['N'] >= 0 ? code_of['N'] : 255;
     std::vector<uint8_t> lut(256);
@@ -184,7 +184,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         const int B = c.pass[k].n_barcodes;
         bp.bpad[k] = 32;  // power of two >= B: peq row address = code << log2(4*bpad)
         while (bp.bpad[k] < B) bp.bpad[k] <<= 1;
-        if ((size_t)bp.ncodes * bp.bpad[k] * wb > 48 * 1024) return BDX_OK;
+        if ((size_t)bp.ncodes * bp.bpad[k] * wb > 96 * 1024) return BDX_OK;  // the table lives in LDS
         bytes = (bytes + 7) & ~(size_t)7;
         o_peq[k] = bytes;
         bytes += (size_t)bp.ncodes * bp.bpad[k] * wb;
@@ -325,7 +325,7 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
     }
     if (pieces.empty()) return BDX_OK;
     if ((int)(always[0].size() + always[1].size()) * 4 > total_bc) return BDX_OK;  // seeding would not pay
-    if (pieces.size() > 8192) return BDX_OK;
+    if (pieces.size() > 16384) return BDX_OK;
     // selectivity: expected seed-hit pairs per read of ~150 bases must be well below B
     const double space = std::pow(4.0, q);
     const double expected = 150.0 * (double)pieces.size() / space + 1.0 + (double)(always[0].size() + always[1].size());
@@ -634,9 +634,14 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads, bool force_slot 
         return true;
     }
     if (ctx->F().splan.enabled) {
-        // the seed tables do not fit next to everything else (very many barcodes): keep the
-        // sweep filter, drop the seeds, and plan again
-        ctx->F().splan.enabled = 0;
+        // the seed tables do not fit next to everything else (very many barcodes): the two-intact-pieces index
+        // gives way to the weak single seeds kept beside it; those give way to the plain sweep; plan again
+        if (ctx->F().splan.diag && ctx->F().splan_alt.enabled) {
+            ctx->F().splan = ctx->F().splan_alt;
+            ctx->F().splan_alt = BdxSeedPlan{};
+        } else {
+            ctx->F().splan.enabled = 0;
+        }
         return size_bitpar(ctx, read_len, n_reads, force_slot);
     }
     bp.reads_per_block = 0;

@@ -1106,19 +1106,18 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         int slot = -1;
         if (v.bc1 > 0) slot = 4 + (v.bc1 - 1) * cfg.counts_stride2 + (v.bc2 > 0 ? v.bc2 - 1 : 0);
         const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
-        if (a.hist_entries > 0) {
-            __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot >= 0) __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            atomicAdd(&a.counts[0], 1ULL);
-            atomicAdd(&a.counts[cls], 1ULL);
-            if (slot >= 0) atomicAdd(&a.counts[slot], 1ULL);
-        }
+        // the four scalar counters (and as many per-barcode slots as the LDS histogram holds) are accumulated in LDS;
+        // slots beyond it (very many barcodes) go to HBM directly — different addresses, little contention
+        __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (slot >= 0 && slot < a.hist_entries)
+            __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (slot >= 0)
+            atomicAdd(&a.counts[slot], 1ULL);
     }
     }  // tile loop
 
-    if (a.counts && a.hist_entries > 0) {
+    if (a.counts) {
         __syncthreads();
         for (int i = tid; i < a.hist_entries; i += BS) {
             const int h = hist[i];

@@ -764,7 +764,9 @@ def _stress_cases():
     b1500 = synth.make_barcodes(1500, 20, seed=3, min_hamming=5)
     s1500 = synth.make_reads(b1500, 6000, 100, seed=3)[:2]
     b3000 = synth.make_barcodes(3000, 16, seed=4, min_hamming=4)
-    s3000 = synth.make_reads(b3000, 2000, 80, seed=4)[:2]
+    s3000 = synth.make_reads(b3000, 700, 80, seed=4)[:2]
+    b5000 = synth.make_barcodes(5000, 16, seed=14, min_hamming=4)
+    s5000 = synth.make_reads(b5000, 300, 80, seed=14)[:2]
     b300 = synth.make_barcodes(4, 300, seed=6, min_hamming=60)
     s300 = synth.make_reads(b300, 600, 700, seed=6)[:2]
     b1 = synth.make_barcodes(1, 24, seed=7)
@@ -776,7 +778,9 @@ def _stress_cases():
         "B1500_rate0.1": (b1500, s1500, dict(max_error_rate=0.1)),
         "B1500_rate0.2_tiered": (b1500, s1500, dict(max_error_rate=0.2)),
         "B1500_trim3_delta": (b1500, s1500, dict(max_error_rate=0.1, trim_side=3, min_delta=0.06)),
-        "B3000_beyond_the_barcode_limit": (b3000, s3000, dict(max_error_rate=0.13)),
+        "B3000": (b3000, s3000, dict(max_error_rate=0.13)),
+        "B3000_trim5_delta": (b3000, s3000, dict(max_error_rate=0.13, trim_side=5, min_delta=0.07)),
+        "B5000_beyond_the_barcode_limit": (b5000, s5000, dict(max_error_rate=0.13)),
         "m300_lds_limited": (b300, s300, dict(max_error_rate=0.1, trim_side=3)),
         "B1_5reads": (b1, s1, dict(max_error_rate=0.2)),
         "70001_reads_ragged_last_tile": (b96, s96, dict(max_error_rate=0.1)),
@@ -787,7 +791,8 @@ def _stress_cases():
     }
 
 
-@pytest.mark.parametrize("name", ["B1500_rate0.1", "B1500_rate0.2_tiered", "B1500_trim3_delta", "B3000_beyond_the_barcode_limit",
+@pytest.mark.parametrize("name", ["B1500_rate0.1", "B1500_rate0.2_tiered", "B1500_trim3_delta", "B3000", "B3000_trim5_delta",
+                                  "B5000_beyond_the_barcode_limit",
                                   "m300_lds_limited", "B1_5reads", "70001_reads_ragged_last_tile", "negative_match_cost",
                                   "fourteen_symbol_alphabet", "seventeen_symbol_alphabet", "min_delta_beyond_an_unseen_barcode"])
 def test_stress_shapes(name):
@@ -801,7 +806,9 @@ def test_stress_shapes(name):
             fuzz.assert_same(hc.classify(seq, off), exp, f"{name} filter {flt} [{hc.kernel_path}]")
             assert np.array_equal(hc.counts, oc.counts)
             path = hc.kernel_path
-    if name in ("B3000_beyond_the_barcode_limit", "m300_lds_limited", "negative_match_cost", "seventeen_symbol_alphabet"):
+    if name in ("B3000", "B3000_trim5_delta"):
+        assert "bitpar" in path, path
+    if name in ("B5000_beyond_the_barcode_limit", "m300_lds_limited", "negative_match_cost", "seventeen_symbol_alphabet"):
         assert path == "generic"
     if name == "fourteen_symbol_alphabet":  # IUPAC letters are literals for the reference; up to 15 symbols stay filtered
         assert "bitpar" in path
