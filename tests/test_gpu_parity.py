@@ -760,6 +760,7 @@ def test_c4_full_size_paths_agree(monkeypatch):
 
 
 # ---- stress shapes at the borders of the fast paths' domain (formerly only in tools/fuzz_campaign.py) ----
+@functools.lru_cache(maxsize=1)
 def _stress_cases():
     b1500 = synth.make_barcodes(1500, 20, seed=3, min_hamming=5)
     s1500 = synth.make_reads(b1500, 6000, 100, seed=3)[:2]
