@@ -238,6 +238,13 @@ def test_c2_full_size_properties():
         hc.classify_device(d_rev.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1b.data_ptr())
         hc.sync()
         assert torch.equal(d_bc1.flip(0), d_bc1b)
+    # an independent path over ALL 10 M reads: the plain sweep of every (read, barcode) pair (no seeds, no windows)
+    d_bc1c = torch.empty(n, dtype=torch.int32, device=dev)
+    with H.bdx.HipClassifier(cfg, filter="bitpar") as hp:
+        hp.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, bc1=d_bc1c.data_ptr())
+        hp.sync()
+        assert hp.kernel_path == "bitpar+verify"
+        assert torch.equal(d_bc1, d_bc1c) and np.array_equal(hp.counts, counts)
     # planted barcodes are recovered (sanity of the workload itself)
     planted = truth > 0
     assert (bc1[planted] == truth[planted]).mean() > 0.9
