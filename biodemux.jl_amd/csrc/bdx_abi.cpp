@@ -43,6 +43,7 @@ BdxTuning read_tuning() {
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
+    t.no_window_upload = getenv("BDX_NO_WINDOW_UPLOAD") != nullptr;
     if (const char *e = getenv("BDX_BITPAR_R")) t.bitpar_r = atoi(e);
     if (const char *e = getenv("BDX_GRID")) t.grid = atoll(e);
     if (const char *e = getenv("BDX_DIAG_MIN_B")) t.diag_min_b = atoi(e);
@@ -526,6 +527,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads, bool force_slot 
     BdxBitparPlan &bp = ctx->F().bplan;
     if (!bp.enabled) return false;
     if (read_len < 1) read_len = 1;
+    if (ctx->dev.vlen) force_slot = true;  // window upload: only each read's window is there
     // small batches: keep >= ~1024 tiles in flight (4 per CU) before growing the tile
     int r_cap = 256;
     while (r_cap > 16 && n_reads / r_cap < 1024) r_cap >>= 1;
@@ -828,6 +830,143 @@ int init_stats(bdx_ctx *ctx) {
 
 }  // namespace
 
+
+// ---- host entry point: shared tail (device outputs, launch, download) and the window upload ----------
+static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d_off, int64_t n_reads, const bdx_outputs_t *out) {
+    // int32 outputs: bc1 bc2 keep_start keep_end (n each), pass_start pass_end pass_raw pass_bc (2n each)
+    const size_t n = (size_t)n_reads;
+    HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
+    HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
+    int32_t *bi = (int32_t *)ctx->d_out_i32.p;
+    bdx_outputs_t d{};
+    d.bc1 = bi;
+    d.bc2 = out->bc2 ? bi + n : nullptr;
+    d.keep_start = out->keep_start ? bi + 2 * n : nullptr;
+    d.keep_end = out->keep_end ? bi + 3 * n : nullptr;
+    d.pass_start = out->pass_start ? bi + 4 * n : nullptr;
+    d.pass_end = out->pass_end ? bi + 6 * n : nullptr;
+    d.pass_raw = out->pass_raw ? bi + 8 * n : nullptr;
+    d.pass_bc = out->pass_bc ? bi + 10 * n : nullptr;
+    d.pass_score = out->pass_score ? (double *)ctx->d_out_f64.p : nullptr;
+    d.pass_delta = out->pass_delta ? (double *)ctx->d_out_f64.p + 2 * n : nullptr;
+    int rc = bdx_classify_device(ctx, d_seq, d_off, n_reads, &d);
+    if (rc != BDX_OK) return rc;
+    auto back = [&](void *h, const void *dv, size_t bytes) -> hipError_t {
+        if (!h || !dv) return hipSuccess;
+        return hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIP_TRY(ctx, back(out->bc1, d.bc1, n * 4));
+    HIP_TRY(ctx, back(out->bc2, d.bc2, n * 4));
+    HIP_TRY(ctx, back(out->keep_start, d.keep_start, n * 4));
+    HIP_TRY(ctx, back(out->keep_end, d.keep_end, n * 4));
+    HIP_TRY(ctx, back(out->pass_start, d.pass_start, n * 8));
+    HIP_TRY(ctx, back(out->pass_end, d.pass_end, n * 8));
+    HIP_TRY(ctx, back(out->pass_raw, d.pass_raw, n * 8));
+    HIP_TRY(ctx, back(out->pass_bc, d.pass_bc, n * 8));
+    HIP_TRY(ctx, back(out->pass_score, d.pass_score, n * 16));
+    HIP_TRY(ctx, back(out->pass_delta, d.pass_delta, n * 16));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BDX_OK;
+}
+
+// Host mirror of the device's per-read window arithmetic (bdx_core.h resolve_range / pass_window and the per-read
+// setup of bdx_bitpar.hip): the 0-based half-open byte range [ulo, uhi) of a read of n code units that ANY pass may
+// touch — final_search_range first:last per pass (classification.jl:795-809), + max_m - 1 beyond the last start
+// position for :hamming / :exact.
+static void host_union_window(const BdxDevCfg &cfg, long long n_ll, long long &ulo, long long &uhi) {
+    const long long n = n_ll > (1LL << 30) ? (1LL << 30) : n_ll;
+    const auto resolve = [&](const BdxDevRange &dr, long long &first, long long &last) {
+        const long long s = dr.start_from_end ? n + dr.start_offset : dr.start_offset;
+        const long long e = dr.end_from_end ? n + dr.end_offset : dr.end_offset;
+        const long long a = s > 1 ? s : 1;
+        long long b = e < n ? e : n;
+        if (b < a) b = a - 1;
+        first = a;
+        last = b;
+    };
+    ulo = (1LL << 40);
+    uhi = 0;
+    const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
+    for (int p = 0; p < (cfg.is_dual ? 2 : 1); ++p) {
+        const BdxDevPass &P = cfg.pass[p];
+        long long first, last;
+        bool ok = true;
+        if (P.explicit_window) {
+            first = P.win_first > 1 ? P.win_first : 1;
+            last = P.win_last < n ? P.win_last : n;
+        } else {
+            long long rf, rl, bf, bl, ef, el;
+            resolve(P.ref_search, rf, rl);
+            resolve(P.bc_start, bf, bl);
+            resolve(P.bc_end, ef, el);
+            first = rf > bf ? rf : bf;
+            if (first < 1) first = 1;
+            last = rl < el ? rl : el;
+            if (n < last) last = n;
+            if (first > last || first > bl || last < ef) ok = false;  // :805-807
+        }
+        const long long f = ok ? (first > 1 ? first : 1) : 1;
+        const long long l = ok ? (last < n ? last : n) : 0;
+        if (l >= f) {
+            long long h = sgm ? l : l + cfg.max_m - 1;
+            if (h > n) h = n;
+            if (f - 1 < ulo) ulo = f - 1;
+            if (h > uhi) uhi = h;
+        }
+    }
+    if (uhi <= ulo) ulo = uhi = 0;
+}
+
+// 1: not worth it (the caller uploads the whole reads); 0: classified through the window upload; < 0: error
+static int classify_host_windows(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t *seq_off, int64_t n_reads,
+                                 const bdx_outputs_t *out) {
+    if (ctx->tune.no_window_upload) return 1;
+    const int64_t total = seq_off[n_reads] - seq_off[0];
+    if (total < (int64_t)n_reads * 512) return 1;  // short reads: nothing to save
+    const size_t n = (size_t)n_reads;
+    ctx->h_coff.resize(n + 1);
+    ctx->h_vlen.resize(n);
+    ctx->h_vlo.resize(n);
+    int64_t wbytes = 0;
+    long long maxlen = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const long long len = seq_off[i + 1] - seq_off[i];
+        if (len < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
+        long long ulo, uhi;
+        host_union_window(ctx->dev, len, ulo, uhi);
+        ctx->h_coff[i] = wbytes;
+        ctx->h_vlen[i] = (int32_t)(len > (1LL << 30) ? (1LL << 30) : len);
+        ctx->h_vlo[i] = (int32_t)ulo;
+        wbytes += uhi - ulo;
+        if (len > maxlen) maxlen = len;
+    }
+    ctx->h_coff[n] = wbytes;
+    if (wbytes * 2 + (int64_t)n_reads * 16 > total) return 1;  // the windows are most of the reads anyway
+    ctx->h_win.resize((size_t)wbytes + 64);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t len_w = ctx->h_coff[i + 1] - ctx->h_coff[i];
+        if (len_w > 0) memcpy(ctx->h_win.data() + ctx->h_coff[i], seq_bytes + seq_off[i] + ctx->h_vlo[i], (size_t)len_w);
+    }
+    HIP_TRY(ctx, ctx->d_seq.ensure((size_t)wbytes + 64));
+    HIP_TRY(ctx, ctx->d_off.ensure((n + 1) * 8));
+    HIP_TRY(ctx, ctx->d_vlen.ensure(n * 4));
+    HIP_TRY(ctx, ctx->d_vlo.ensure(n * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_seq.p, ctx->h_win.data(), (size_t)wbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off.p, ctx->h_coff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_vlen.p, ctx->h_vlen.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_vlo.p, ctx->h_vlo.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->dev.vlen = (const int32_t *)ctx->d_vlen.p;
+    ctx->dev.vlo = (const int32_t *)ctx->d_vlo.p;
+    ctx->virt_maxlen = (int)(maxlen > (1LL << 30) ? (1LL << 30) : (maxlen < 1 ? 1 : maxlen));
+    const int rc = run_and_download(ctx, (const uint8_t *)ctx->d_seq.p, (const int64_t *)ctx->d_off.p, n_reads, out);
+    ctx->dev.vlen = nullptr;  // (run_and_download has synchronised the stream)
+    ctx->dev.vlo = nullptr;
+    ctx->virt_maxlen = 0;
+    for (BdxFilterSet &f : ctx->fs) f.bplan.read_len_hint = 0;  // the slot geometry was forced: plan afresh for ordinary batches
+    if (rc == BDX_OK) ctx->window_uploads += 1;
+    return rc == BDX_OK ? 0 : rc;
+}
+
 extern "C" {
 
 int32_t bdx_abi_version(void) { return BDX_ABI_VERSION; }
@@ -970,6 +1109,8 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->d_off.release();
     ctx->d_out_i32.release();
     ctx->d_out_f64.release();
+    ctx->d_vlen.release();
+    ctx->d_vlo.release();
     bdx_comm_release(ctx);
     ctx->counts_sum.release();
     for (int p = 0; p < 2; ++p)
@@ -1020,12 +1161,16 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     BdxDevStats st{};
     const BdxDevStats *stp = nullptr;
     int measured_len = -1;
-    if (ctx->dev.need_traceback) {
+    if (ctx->dev.need_traceback && ctx->virt_maxlen > 0) {
+        measured_len = ctx->virt_maxlen;  // window upload: the host has seen every length
+    } else if (ctx->dev.need_traceback) {
         // statistics tables are sized from the batch's true maximum read length (a hint is only a hint)
         HIP_TRY(ctx, ctx->d_maxlen.ensure(1024));
         HIP_TRY(ctx, bdx_launch_maxlen((const long long *)d_seq_off, n_reads, (int *)ctx->d_maxlen.p, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(&measured_len, ctx->d_maxlen.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->dev.need_traceback) {
         int rc = bdx_stats_reserve(ctx, (long long)measured_len + ctx->dev.max_m + 2);
         if (rc != BDX_OK) return rc;
         for (int p = 0; p < 2; ++p) {
@@ -1042,7 +1187,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     bool filtered = false;
     int tier_len = 0;  // > 0: tiered budgets apply to this batch (the read length both tiers were planned for)
     if (ctx->F().bplan.enabled) {
-        int len = ctx->user_len_hint;
+        int len = ctx->virt_maxlen > 0 ? ctx->virt_maxlen : ctx->user_len_hint;
         if (len <= 0 && measured_len >= 0) len = measured_len > 0 ? measured_len : 1;
         if (len <= 0) {  // measure the batch: one tiny kernel + a 4-byte copy
             int host_len = 0;
@@ -1185,47 +1330,21 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
     const int64_t base = seq_off[0];
     const int64_t total = seq_off[n_reads] - base;
     if (total < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
+    {
+        // Window upload: when the passes only look at a short column window of long reads (ONT-style reads with the
+        // barcodes at an end, C5), copy just each read's window — the union over the passes of final_search_range
+        // (+ m - 1 for :hamming / :exact), resolved exactly like the device does — instead of the whole read:
+        // 10 kbp reads with "1:200" move 212 B per read over PCIe instead of 10 KB.
+        int rcw = classify_host_windows(ctx, seq_bytes, seq_off, n_reads, out);
+        if (rcw != 1) return rcw;  // 0 done, < 0 error, 1: ordinary upload below
+    }
     // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));
     HIP_TRY(ctx, ctx->d_off.ensure((size_t)(n_reads + 1) * 8));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_seq.p, seq_bytes + base, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off.p, seq_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    // int32 outputs: bc1 bc2 keep_start keep_end (n each), pass_start pass_end pass_raw pass_bc (2n each)
-    const size_t n = (size_t)n_reads;
-    HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
-    HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
-    int32_t *bi = (int32_t *)ctx->d_out_i32.p;
-    bdx_outputs_t d{};
-    d.bc1 = bi;
-    d.bc2 = out->bc2 ? bi + n : nullptr;
-    d.keep_start = out->keep_start ? bi + 2 * n : nullptr;
-    d.keep_end = out->keep_end ? bi + 3 * n : nullptr;
-    d.pass_start = out->pass_start ? bi + 4 * n : nullptr;
-    d.pass_end = out->pass_end ? bi + 6 * n : nullptr;
-    d.pass_raw = out->pass_raw ? bi + 8 * n : nullptr;
-    d.pass_bc = out->pass_bc ? bi + 10 * n : nullptr;
-    d.pass_score = out->pass_score ? (double *)ctx->d_out_f64.p : nullptr;
-    d.pass_delta = out->pass_delta ? (double *)ctx->d_out_f64.p + 2 * n : nullptr;
     // kernel sees the byte base shifted by -base so that off[i] addresses read i
-    const uint8_t *d_seq_rebased = (const uint8_t *)ctx->d_seq.p - base;
-    int rc = bdx_classify_device(ctx, d_seq_rebased, (const int64_t *)ctx->d_off.p, n_reads, &d);
-    if (rc != BDX_OK) return rc;
-    auto back = [&](void *h, const void *dv, size_t bytes) -> hipError_t {
-        if (!h || !dv) return hipSuccess;
-        return hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    };
-    HIP_TRY(ctx, back(out->bc1, d.bc1, n * 4));
-    HIP_TRY(ctx, back(out->bc2, d.bc2, n * 4));
-    HIP_TRY(ctx, back(out->keep_start, d.keep_start, n * 4));
-    HIP_TRY(ctx, back(out->keep_end, d.keep_end, n * 4));
-    HIP_TRY(ctx, back(out->pass_start, d.pass_start, n * 8));
-    HIP_TRY(ctx, back(out->pass_end, d.pass_end, n * 8));
-    HIP_TRY(ctx, back(out->pass_raw, d.pass_raw, n * 8));
-    HIP_TRY(ctx, back(out->pass_bc, d.pass_bc, n * 8));
-    HIP_TRY(ctx, back(out->pass_score, d.pass_score, n * 16));
-    HIP_TRY(ctx, back(out->pass_delta, d.pass_delta, n * 16));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return BDX_OK;
+    return run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)ctx->d_off.p, n_reads, out);
 }
 
 // Page-locked host memory for the buffers handed to bdx_classify_host (reads, offsets, outputs): the
@@ -1301,6 +1420,8 @@ int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts) {
 }
 
 const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str() : ""; }
+
+int64_t bdx_window_uploads(const bdx_ctx *ctx) { return ctx ? ctx->window_uploads : 0; }
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;

@@ -274,8 +274,9 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     //    union of its pass windows, so HBM traffic and LDS follow the window, not the read.
     const int slot = a.slot_bytes;
     const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
-    const long long span0 = lm ? 0 : a.off[r0];  // (list mode always stages per-read slots)
-    const long long span1 = lm ? 0 : a.off[r1];
+    const bool virt = cfg.vlen != nullptr;  // window upload: per-read slots as well (the host plans slot staging)
+    const long long span0 = (lm || virt) ? 0 : a.off[r0];  // (list mode always stages per-read slots)
+    const long long span1 = (lm || virt) ? 0 : a.off[r1];
     const uintptr_t g0 = (uintptr_t)(a.seq + span0);
     const uintptr_t g0a = g0 & ~(uintptr_t)15;
     const int head = (int)(g0 - g0a);
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     for (int t = ltid; t < nr; t += BS) {
         const long long rid = lm ? (long long)a.in_list[r0 + t] : r0 + t;
         rids[t] = (uint32_t)rid;
-        const long long ro = a.off[rid];
-        const long long rn = a.off[rid + 1] - ro;
+        const long long ro = a.off[rid] - (virt ? (long long)cfg.vlo[rid] : 0);  // where position 0 of the read would be
+        const long long rn = virt ? (long long)cfg.vlen[rid] : a.off[rid + 1] - a.off[rid];
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
         rlen[t] = n;
         int ulo = 0x7FFFFFFF, uhi = 0;
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
                 const int r = idx / cpr, k = idx - r * cpr;
                 const int hd = roff[r] - r * slot + wlo[r];
                 if (16 * k < wlen[r] + hd) {
-                    const uintptr_t src = ((uintptr_t)(a.seq + a.off[rids[r]] + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
+                    const long long rb = a.off[rids[r]] - (virt ? (long long)cfg.vlo[rids[r]] : 0);
+                    const uintptr_t src = ((uintptr_t)(a.seq + rb + wlo[r]) & ~(uintptr_t)15) + 16u * (unsigned)k;
                     *(LDS u32x4 *)(rstage + r * slot + 16 * k) = __builtin_nontemporal_load((GlobalVec16)src);
                 }
             }

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "bdx_internal.h"
 
@@ -38,6 +39,7 @@ struct BdxTuning {
     int bitpar_r = 0;     // BDX_BITPAR_R: forced tile size of the fused kernel
     long long grid = 0;   // BDX_GRID: forced persistent grid
     int diag_min_b = 48;  // BDX_DIAG_MIN_B: barcode threshold of the diagonal filter
+    int no_window_upload = 0;  // BDX_NO_WINDOW_UPLOAD: the host entry point always uploads whole reads
     int no_clean = 0;     // BDX_NO_CLEAN: exact kernel's register DP always in its predicated by-construction form
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
@@ -80,6 +82,13 @@ struct bdx_ctx {
     unsigned long long *counts = nullptr;
     // staging for the host entry point
     DevBuf d_seq, d_off, d_out_i32, d_out_f64;
+    // window upload (host entry point, long reads with short column windows): per-read true lengths / window starts
+    DevBuf d_vlen, d_vlo;
+    int virt_maxlen = 0;     // > 0 while a window-upload batch is being classified: its longest read
+    int64_t window_uploads = 0;
+    std::vector<uint8_t> h_win;    // host staging of the compacted windows
+    std::vector<int64_t> h_coff;
+    std::vector<int32_t> h_vlen, h_vlo;
     // candidate masks (filtered paths)
     DevBuf d_cand[2];
     DevBuf d_wins[2], d_wcnt[2];  // split mode: column windows for the exact kernel

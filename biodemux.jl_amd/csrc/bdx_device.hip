@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_gen
         const uintptr_t g0a = g0 & ~(uintptr_t)15;
         head = (int)(g0 - g0a);
         const long long need = (span1 - span0) + head;
-        staged = bc_staged && a.stage_bytes > 0 && need + 16 <= (long long)a.stage_bytes;
+        staged = bc_staged && a.stage_bytes > 0 && need + 16 <= (long long)a.stage_bytes && cfg.vlen == nullptr;
         if (staged) {  // coalesced 16-B copy of the contiguous span, each HBM byte fetched once
             const int nvec = (int)((need + 15) >> 4);
             const GlobalVec16 src = (GlobalVec16)g0a;
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_gen
     Verdict v{0, 0, -1, -1};
     PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     if (active) {
-        const long long ro = a.off[ridx];
-        const long long rn = a.off[ridx + 1] - ro;
+        // (window upload: ro is where position 0 of the read WOULD be; only window columns are ever touched)
+        const long long ro = a.off[ridx] - (cfg.vlen ? (long long)cfg.vlo[ridx] : 0);
+        const long long rn = cfg.vlen ? (long long)cfg.vlen[ridx] : a.off[ridx + 1] - a.off[ridx];
         const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
         const uint32_t *c0 = a.cand0 ? a.cand0 + ridx * cfg.pass[0].cand_words : nullptr;
         const uint32_t *c1 = a.cand1 ? a.cand1 + ridx * cfg.pass[1].cand_words : nullptr;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_gen
     if (a.tier1) {  // (workgroup-uniform)
         bool settled = false;
         if (active) {
-            const long long rn = a.off[ridx + 1] - a.off[ridx];
+            const long long rn = cfg.vlen ? (long long)cfg.vlen[ridx] : a.off[ridx + 1] - a.off[ridx];
             const int n = (int)(rn > (1LL << 30) ? (1LL << 30) : rn);
             const bool sgm = cfg.algorithm == BDX_ALG_SEMIGLOBAL;
             const auto free_ranges = [&](const BdxDevPass &P) {  // neither the start nor the end range binds for this read

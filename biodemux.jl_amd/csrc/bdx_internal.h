@@ -52,6 +52,11 @@ struct BdxDevCfg {
     int any_traceback;  // origin array needed (trim or summary in any pass)
     int counts_stride2; // max(1, B2 when dual)
     int n_counts;
+    // "window upload" of the host entry point (long reads with short column windows): seq / off hold only each
+    // read's window bytes; vlen[i] is the read's true length, vlo[i] the 0-based position its first uploaded byte
+    // stands for.  Position p of read i lives at seq[off[i] + p - vlo[i]].  NULL: ordinary batches.
+    const int32_t *vlen;
+    const int32_t *vlo;
     BdxDevPass pass[2];
 };
 

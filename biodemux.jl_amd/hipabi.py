@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
+    "bdx_window_uploads",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
 BDX_COMM_ID_BYTES = 128
@@ -209,6 +210,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_stats_shape.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.bdx_get_stats.restype = C.c_int32
     L.bdx_get_stats.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64]
+    L.bdx_window_uploads.restype = C.c_int64
+    L.bdx_window_uploads.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -439,6 +442,11 @@ class HipClassifier:
                     tab = buf[:tab.size].reshape(tab.shape)
                 out[p][name] = (tab, int(key0.value))
         return out
+
+    @property
+    def window_uploads(self) -> int:
+        """classify() calls that uploaded only each read's column window (long reads, short windows)."""
+        return int(self.lib.bdx_window_uploads(self.h))
 
     @property
     def kernel_path(self) -> str:

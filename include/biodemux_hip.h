@@ -254,6 +254,13 @@ void bdx_host_free(void *p);
  * two-intact-pieces ("diagonal") seeds in front of the sweep.  All paths give identical results. */
 const char *bdx_kernel_path(const bdx_ctx *ctx);
 
+/* How many bdx_classify_host calls went through the WINDOW UPLOAD: when the passes only look at a short column
+ * window of long reads (ref_search_range "1:200" on 10 kbp reads), the host entry point copies just each read's
+ * window to the device (the union over the passes of final_search_range, classification.jl:795-809, resolved per
+ * read exactly like the kernels do) instead of the whole read.  Results are identical; PCIe traffic follows the
+ * window. */
+int64_t bdx_window_uploads(const bdx_ctx *ctx);
+
 typedef struct {
     int32_t threads_per_block;
     int32_t lds_bytes_per_block;

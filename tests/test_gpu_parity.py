@@ -489,6 +489,58 @@ def test_long_ragged_reads_with_windows(kw):
     assert (exp["bc1"] > 0).mean() > 0.1
 
 
+@pytest.mark.parametrize("kw", [
+    dict(ref_search_range="1:200"),
+    dict(ref_search_range="end-300:end", trim_side=5),
+    dict(ref_search_range="40:260", barcode_start_range="30:end", barcode_end_range="1:300", trim_side=3),
+    dict(ref_search_range="1:150", matching_algorithm="hamming", max_error_rate=0.1),
+    dict(ref_search_range="end-180:end", matching_algorithm="exact"),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_window_upload_of_the_host_entry_point(kw, monkeypatch):
+    """bdx_classify_host copies only each read's column window to the device when that saves most of the bytes.
+    Same results as the oracle and as the whole-read upload, including reads shorter than the window, empty reads and
+    the device-side statistics (positions are positions of the whole read)."""
+    bcs = synth.make_barcodes(24, 20, seed=131, min_hamming=6)
+    seq0, off0, _ = synth.make_ragged_reads(bcs, 1200, 1500, 5000, seed=131, plant_lo=0, plant_hi=None)
+    rng = np.random.Generator(np.random.PCG64(132))
+    reads = []
+    for i in range(1200):
+        r = seq0[off0[i]:off0[i + 1]].copy()
+        n = len(r)
+        b = np.frombuffer(bcs[int(rng.integers(0, 24))].encode(), dtype=np.uint8)
+        for pos in (int(rng.integers(0, 170)), n - 200 + int(rng.integers(0, 175))):
+            r[pos:pos + 20] = b
+        reads.append(r.tobytes().decode())
+    for i in range(0, 1200, 97):  # short and empty reads in between
+        reads[i] = reads[i][:int(rng.integers(0, 260))]
+    reads[5] = ""
+    seq, off = H.bdx.pack_reads(reads)
+    kw = dict(kw)
+    rngs = {k: H.bdx.parse_dynamic_range(kw.pop(k)) for k in ("ref_search_range", "barcode_start_range", "barcode_end_range") if k in kw}
+    cfg = _c2_config(bcs, **{"max_error_rate": 0.15, **kw}, summary=True, **rngs)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    assert (exp["bc1"] > 0).mean() > 0.2
+    for flt in ("auto", "off", "bitpar"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            assert hc.window_uploads == 1, hc.kernel_path
+            fuzz.assert_same(got, exp, f"window upload, filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+            tabs = hc.stats_tables()
+            got2 = hc.classify(seq[:off[300]], off[:301])  # a second, smaller batch through the same context
+            fuzz.assert_same(got2, {k: v[:300] if v.shape[0] == 1200 else v[:600] for k, v in exp.items()}, "second batch")
+    monkeypatch.setenv("BDX_NO_WINDOW_UPLOAD", "1")
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        fuzz.assert_same(hc.classify(seq, off), exp, "whole-read upload")
+        assert hc.window_uploads == 0
+        ref_tabs = hc.stats_tables()
+    for p_ in ref_tabs:
+        for k in ref_tabs[p_]:
+            assert tabs[p_][k][1] == ref_tabs[p_][k][1] and np.array_equal(tabs[p_][k][0], ref_tabs[p_][k][0]), k
+            assert ref_tabs[p_][k][0].sum() > 0
+
+
 def test_long_reads_dual_windows():
     b1 = synth.make_barcodes(12, 20, seed=41, min_hamming=6)
     b2 = synth.make_barcodes(10, 20, seed=42, min_hamming=6)
