@@ -446,9 +446,18 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         const WT Xh = (((Eq & w.Pv) + w.Pv) ^ w.Pv) | Eq;
         WT Ph = w.Mv | ~(Xh | w.Pv);
         WT Mh = w.Pv & Xh;
-        w.score += (int)(Ph >> (8 * WB - 1)) - (int)(Mh >> (8 * WB - 1));
-        Ph += Ph;  // << 1 as an add: full-rate on gfx950, shifts are not
-        Mh += Mh;
+        // << 1 as an add whose carry-out is the bit of the barcode's last row (the patterns are top-aligned):
+        // v_add_co + v_addc instead of two shifts and a three-operand add (shifts and v_add3 issue at 2/3 rate)
+        WT cp, cm;
+        if constexpr (W64) {
+            Ph = __builtin_addcll(Ph, Ph, 0ull, &cp);
+            Mh = __builtin_addcll(Mh, Mh, 0ull, &cm);
+        } else {
+            Ph = __builtin_addc(Ph, Ph, 0u, &cp);
+            Mh = __builtin_addc(Mh, Mh, 0u, &cm);
+        }
+        w.score += (int)cp;
+        w.score -= (int)cm;
         w.Pv = Mh | ~(Xv | Ph);
         w.Mv = Ph & Xv;
         w.best = w.score < w.best ? w.score : w.best;

@@ -19,6 +19,8 @@ dev = torch.device("cuda:0")
 
 def run(name, cfg, seq, off, check=3000, outs=("bc1",), reps=3):
     check = int(os.environ.get("CHECK", check))  # reads compared with the oracle (all of `outs`)
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        return
     n = len(off) - 1
     d_seq = torch.from_numpy(seq).to(dev)
     d_off = torch.from_numpy(off).to(dev)
