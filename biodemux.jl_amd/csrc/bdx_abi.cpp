@@ -43,7 +43,10 @@ BdxTuning read_tuning() {
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
+    t.no_band = getenv("BDX_NO_BAND") != nullptr;
     t.no_window_upload = getenv("BDX_NO_WINDOW_UPLOAD") != nullptr;
+    t.seed_hash_l2 = getenv("BDX_SEED_HASH_L2") != nullptr;
+    if (const char *e = getenv("BDX_SEED_BM_LOG2")) t.seed_bm_log2 = atoi(e);
     if (const char *e = getenv("BDX_BITPAR_R")) t.bitpar_r = atoi(e);
     if (const char *e = getenv("BDX_GRID")) t.grid = atoll(e);
     if (const char *e = getenv("BDX_DIAG_MIN_B")) t.diag_min_b = atoi(e);
@@ -202,6 +205,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         uint8_t *pv = blob.data() + o_pv[k];
         int32_t *kb = (int32_t *)(blob.data() + o_kb[k]);
         const int bits = (int)wb * 8;
+        bp.kb_uniform[k] = -2;  // (unset)
         const auto put = [&](uint8_t *dst, size_t idx, uint64_t v) {
             if (wb == 8)
                 ((uint64_t *)dst)[idx] = v;
@@ -236,6 +240,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
             long long kcap = kfull;
             if (kcap > tier_cap(ctx, m)) kcap = tier_cap(ctx, m);
             kb[b] = (int32_t)kcap;
+            bp.kb_uniform[k] = bp.kb_uniform[k] == -2 ? (int)kcap : (bp.kb_uniform[k] == (int)kcap ? (int)kcap : -1);
             if (kcap < kfull) {
                 // the smallest score a barcode tier 1 cannot see may have: (kb1 + 1) operations of cost >= cmin
                 // each, over this barcode's normalisation (computed as the device computes a score)
@@ -351,10 +356,12 @@ int build_seed_tables(bdx_ctx *ctx, bool strict, bool alt = false) {
         const int want = (int)std::ceil((1.0 + false_pairs) * 1.5 + 1.0);  // (C2: 4 — one more entry per read would cost the fourth workgroup per CU)
         if (want > sp.qmul) sp.qmul = want > 48 ? 48 : want;
     }
+    if (ctx->tune.seed_bm_log2 > 0) sp.bm_log2 = ctx->tune.seed_bm_log2 < 2 * q ? ctx->tune.seed_bm_log2 : 2 * q;
     sp.bm_words = (1 << sp.bm_log2) / 32;
     sp.hash_log2 = 8;
     while ((1u << sp.hash_log2) < pieces.size() * 2) sp.hash_log2++;
     sp.hash_in_lds = ((size_t)5 << sp.hash_log2) <= 8 * 1024;  // larger tables are probed in L2 (a few probes per read)
+    if (ctx->tune.seed_hash_l2) sp.hash_in_lds = 0;
     std::vector<uint32_t> bitmap(sp.bm_words, 0), hash((size_t)1 << sp.hash_log2, 0);
     std::vector<uint8_t> hash_ps((size_t)1 << sp.hash_log2, 0);
     const uint32_t hmask = (1u << sp.hash_log2) - 1;
@@ -720,6 +727,8 @@ int upload_tables(bdx_ctx *ctx) {
     d.nindel = c.has_nindel ? c.nindel : 0;
     d.need_traceback = c.need_traceback != 0;
     d.force_lds_dp = ctx->tune.lds_dp;
+    d.band_kb[0] = d.band_kb[1] = -1;
+    d.band_lb[0] = d.band_lb[1] = 0;
     d.max_m = 1;
     d.any_traceback = d.need_traceback;
     const int npass = d.is_dual ? 2 : 1;
@@ -1260,6 +1269,20 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f.bplan.short_lb[0] = short_lb[0];
             f.bplan.short_lb[1] = short_lb[1];
         }
+        // diagonal-band DP of the exact kernel (sg_core_band): clean class, every barcode of the config with the same
+        // number of rows and of the pass with the same budget, column windows handed over by tracked sweeps
+        const auto band_cfg = [&](const BdxFilterSet &f) {
+            BdxDevCfg dv = ctx->dev;
+            for (int k = 0; k < npass; ++k) {
+                const int kb = f.bplan.kb_uniform[k];
+                const bool on = windows && f.splan.enabled && ctx->plan.clean && ctx->plan.uniform_m && !ctx->tune.no_band &&
+                                ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && kb >= 0 && kb <= 4;
+                dv.band_kb[k] = on ? kb : -1;
+                if (on) ctx->band_launches += 1;
+                dv.band_lb[k] = short_lb[k] ? ctx->dev.max_m + kb : 2 * (ctx->dev.max_m + kb) + 1;
+            }
+            return dv;
+        };
         BdxTierArgs t0{0, nullptr, nullptr, nullptr, nullptr};
         if (tiered) {
             HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
@@ -1271,7 +1294,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
                                            o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0, n1, split ? 1 : 0, exc_list, exc_count, &t1));
             if (split)  // the exact kernel answers what tier 1 settles and lists the rest (known-score configs: the fused kernel did)
-                HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o, ctx->counts,
+                HIP_TRY(ctx, bdx_launch_generic(band_cfg(f1), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o, ctx->counts,
                                                 c0, npass > 1 ? c1 : nullptr, ctx->stream, w0, npass > 1 ? w1 : nullptr, n0,
                                                 npass > 1 ? n1 : nullptr, nullptr, nullptr, stp, &t1, f1.bplan.tier_slo));
             // tier 0 walks the list: scattered reads -> slot staging
@@ -1286,7 +1309,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
                                        n1, split ? 1 : 0, exc_list, exc_count, tiered ? &t0 : nullptr));
         if (split)  // (tiered: list mode over the reads tier 1 handed on)
-            HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+            HIP_TRY(ctx, bdx_launch_generic(band_cfg(ctx->F()), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
                                             npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, tiered ? t0.in_list : nullptr,
                                             tiered ? t0.in_count : nullptr, stp));
@@ -1422,6 +1445,8 @@ int32_t bdx_set_counts_buffer(bdx_ctx *ctx, void *d_counts) {
 const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str() : ""; }
 
 int64_t bdx_window_uploads(const bdx_ctx *ctx) { return ctx ? ctx->window_uploads : 0; }
+
+int64_t bdx_band_launches(const bdx_ctx *ctx) { return ctx ? ctx->band_launches : 0; }
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;

@@ -394,6 +394,134 @@ __device__ __forceinline__ AlignOut sg_core_clean(const Bytes<STAGED> q, const i
     return res;  // :444
 }
 
+// Diagonal-band form of the clean-class DP, for candidates whose end columns are known: the fused
+// kernel's tracked sweep delivers [e_lo, e_hi] = first / last column with unit distance <= kb.  An alignment of <= kb
+// operations ending in row M at a column je of that window only touches cells with |(je - j) - (M - i)| <= kb, i.e.
+// the diagonals  j - i  in  [e_lo - M - kb, e_hi - M + kb]; everything the reference records (values, origins, ties:
+// every predecessor that attains a minimum on a recorded path lies in the band with its true value, the others only
+// grow) is reproduced by a DP over the H >= (e_hi - e_lo + 1) + 2 kb diagonals below  dtop = e_hi + kb - M.
+// Columns are walked relative to the lane's own anchor — step k is column  e_hi + kb - (M + H - 2) + k  — so the rows
+// of a step are the same for every lane (k - H + 2 .. k + 1, clipped to 1 .. M): the whole DP is straight-line code
+// over statically indexed registers, M x H cells instead of (columns x M), no per-row predicates, no infinities
+// (cells outside the band are simply not read).  When the band crosses the first column of the pass window the rows it
+// held one step earlier take the reference's initial column (indel * i, origin 1 - i, :278-283); steps before that
+// compute garbage that nothing reads.  Every barcode has exactly M rows (UM kernels).
+// Model and proof by enumeration: oracle band_dp / orc_selftest_band_class.
+// One out-of-line copy per (TB, M, H) and kernel — the body is long straight-line code, the call sites are many
+// (two passes x staged / unstaged reads): the barcode (4 bytes per word) and the read words travel in vector registers.
+typedef uint32_t bdx_u32x4 __attribute__((ext_vector_type(4)));
+template <bool TB, int M, int H>
+__device__ __attribute__((noinline)) AlignOut sg_core_band(const bdx_u32x4 qa, const bdx_u32x4 qb, const bdx_u32x4 sa,
+                                                           const bdx_u32x4 sb, const bdx_u32x4 sc, const bdx_u32x4 sd,
+                                                           const int j0, const int ae, const uint32_t costs /* match | mismatch << 8 | indel << 16 | trim_side << 24 */,
+                                                           const int first, const int e_lo, const int e_hi) {
+    static_assert(M <= 32 && (M + H + 2) / 4 + 1 <= 16, "barcode / read words do not fit the register arguments");
+    constexpr int K = M + H - 2;
+    const uint32_t QW[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const uint32_t S[16] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w, sc.x, sc.y, sc.z, sc.w, sd.x, sd.y, sd.z, sd.w};
+    struct { int match, mismatch, indel; } c{(int)(costs & 255u), (int)((costs >> 8) & 255u), (int)((costs >> 16) & 255u)};
+    const int trim_side = (int)(costs >> 24);
+    int QB[M + 1];
+    QB[0] = 0;
+#pragma unroll
+    for (int i = 1; i <= M; ++i) QB[i] = (int)((QW[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu);
+    AlignOut res{BDX_INF32, -1, -1};
+    int DP[M + 1], OG[M + 1];
+#pragma unroll
+    for (int i = 0; i <= M; ++i) {
+        DP[i] = 0;
+        OG[i] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        const int j = j0 + k;
+        const int ra = k - H + 2, rb = k + 1;
+        const int lo = ra < 1 ? 1 : ra, hi = rb > M ? M : rb;
+        if (j == first) {
+#pragma unroll
+            for (int i = ra - 1; i <= rb - 1; ++i)
+                if (i >= 1 && i <= M) {
+                    DP[i] = c.indel * i;
+                    if (TB) OG[i] = 1 - i;
+                }
+        }
+        const int rj = (int)((S[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        int prev = 0, prev_o = j, diag = 0, diag_o = j;  // row 0: value 0, origin j (:288, :308)
+        if (lo > 1) {
+            diag = DP[lo - 1];  // (lo - 1, j - 1): the band's top diagonal
+            diag_o = OG[lo - 1];
+        }
+        int vm = BDX_INF32, om = -1;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) {
+            const int old = DP[i], old_o = OG[i];
+            const int sub = diag + (QB[i] == rj ? c.match : c.mismatch);  // :185
+            int b2 = sub, o = diag_o;
+            if (i > lo || lo == 1) {  // the deletion input lies in the band (or is row 0)
+                const int del = prev + c.indel;  // :184
+                if (TB) o = sub < del ? diag_o : prev_o;  // :310-316
+                b2 = sub < del ? sub : del;
+            }
+            if (i == M) {  // the last row: no horizontal move; its stored value is never read
+                vm = b2;
+                om = o;
+            } else {
+                int nv = b2;
+                if (i != rb) {  // (i, j - 1) lies in the band
+                    const int ins = old + c.indel;  // :183
+                    if (TB) o = ins < b2 ? old_o : o;  // :317-320
+                    nv = ins < b2 ? ins : b2;
+                }
+                DP[i] = nv;
+                if (TB) OG[i] = o;
+                prev = nv;
+                prev_o = o;
+            }
+            diag = old;
+            diag_o = old_o;
+        }
+        if (hi == M) {
+            if (j >= e_lo && j <= e_hi && vm <= ae) {  // :417 (j >= min_end_pos: the end range does not bind)
+                if (vm == 0 && (!TB || trim_side == 5)) return AlignOut{0, TB ? om : -1, j};  // :420-430
+                if (TB) {  // :142-153
+                    if (vm < res.raw || (vm == res.raw && trim_side == 3 && om > res.start)) {
+                        res.raw = vm;
+                        res.start = om;
+                        res.end = j;
+                    }
+                } else if (vm < res.raw) {
+                    res.raw = vm;
+                    res.end = j;
+                }
+            }
+        }
+    }
+    return res;
+}
+
+// the read's bytes of the band's columns j0 .. j0 + M + H - 2, as words whose byte k is column j0 + k (bytes in front
+// of the read are never used: clamped addresses)
+template <int NS, bool STAGED>
+__device__ __forceinline__ void band_fetch(const Bytes<STAGED> r, const int j0, uint32_t (&S)[NS]) {
+    const long long rbase = (long long)(uintptr_t)r.p;
+    const long long ad0 = rbase + (long long)(j0 - 1);
+    const long long lo_ok = rbase & ~3LL;
+    const long long a0 = ad0 & ~3LL;
+    const uint32_t sh = (uint32_t)(ad0 & 3LL);
+    uint32_t W[NS + 1];
+#pragma unroll
+    for (int w = 0; w <= NS; ++w) {
+        long long aw = a0 + 4 * w;
+        aw = aw < lo_ok ? lo_ok : aw;
+        if constexpr (STAGED)
+            W[w] = *(const LDS uint32_t *)(uintptr_t)aw;
+        else
+            W[w] = *(const uint32_t *)(uintptr_t)aw;
+    }
+#pragma unroll
+    for (int w = 0; w < NS; ++w) S[w] = __builtin_amdgcn_alignbyte(W[w + 1], W[w], sh);
+}
+
 // hamming_align, classification.jl:557-625.  Scores of one call share the divisor m, so the
 // reference's Float64 `score < best_score` / `==` are decided on the integer numerators.
 template <bool STAGED>
@@ -672,6 +800,53 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             } else if (REGM > 0 && CLEAN) {
                 // clean class (see sg_core_clean): same three output forms as below
                 const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
+                if constexpr (UM) {
+                    // diagonal band (sg_core_band): the tracked sweep's end columns are known and the band fits
+                    const int pidx = (&P == &cfg.pass[1]) ? 1 : 0;
+                    const int kbb = cfg.band_kb[pidx];
+                    const int e_lo = cjlo + cfg.band_lb[pidx], e_hi = cjhi;
+                    const int need = kbb >= 0 && wcount <= BDX_WCAP && cjhi < 0x40000000 ? (e_hi - e_lo + 1) + 2 * kbb : 0x7FFF;
+                    if (need <= 17 && n > 0 && cfg.match < 256 && cfg.mismatch < 256 && cfg.indel < 256) {
+                        constexpr int MM = REGM > 0 ? REGM : 4;
+                        // the barcode's bytes, four per word (the barcode tables are word-aligned only by chance)
+                        uint32_t QW[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int i = 0; i < MM; ++i) QW[i >> 2] |= (uint32_t)q[i] << (8 * (i & 3));
+                        const bdx_u32x4 qa = {QW[0], QW[1], QW[2], QW[3]}, qb4 = {QW[4], QW[5], QW[6], QW[7]};
+                        const bool tbf = need_tb && !end_only;
+                        const uint32_t costs = (uint32_t)c.match | ((uint32_t)c.mismatch << 8) | ((uint32_t)c.indel << 16) | ((uint32_t)trim_side << 24);
+                        uint32_t S[16];
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) S[w] = 0;
+                        // one band width per wave: the straight-line bodies are long, a wave should run only one
+                        if (__builtin_amdgcn_ballot_w64(need > 9) == 0ull) {
+                            constexpr int HH = 9, NS = (MM + HH + 2) / 4 + 1;
+                            const int j0 = e_hi + kbb - (MM + HH - 2);
+                            uint32_t T[NS];
+                            band_fetch<NS, STAGED>(r, j0, T);
+#pragma unroll
+                            for (int w = 0; w < NS; ++w) S[w] = T[w];
+                            const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
+                            a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
+                                    : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
+                        } else if constexpr (MM > 24) {
+                            goto no_band;  // (the 17-diagonal body of 32-row barcodes does not stay in registers)
+                        } else {
+                            constexpr int HH = 17, NS = (MM + HH + 2) / 4 + 1;
+                            const int j0 = e_hi + kbb - (MM + HH - 2);
+                            uint32_t T[NS];
+                            band_fetch<NS, STAGED>(r, j0, T);
+#pragma unroll
+                            for (int w = 0; w < NS; ++w) S[w] = T[w];
+                            const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
+                            a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
+                                    : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
+                        }
+                        if (!need_tb) a.end = -1;
+                        goto band_done;
+                    }
+                }
+            no_band:
                 a = !need_tb ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                     : end_only ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, true, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                                : sg_core_clean<true, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi);
@@ -687,6 +862,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                 a = need_tb ? sg_core<true, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi)
                             : sg_core<false, false, STAGED>(DP, OG, S, q, m, r, n, ae, c, trim_side, jf, jl, max_start, min_end, cjlo, cjhi);
             }
+        band_done:
             score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)norm;  // :155-168
         }
         if (align_one) {  // unit-level API: the direct return of one alignment call

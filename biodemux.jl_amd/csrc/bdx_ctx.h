@@ -40,7 +40,10 @@ struct BdxTuning {
     long long grid = 0;   // BDX_GRID: forced persistent grid
     int diag_min_b = 48;  // BDX_DIAG_MIN_B: barcode threshold of the diagonal filter
     int no_window_upload = 0;  // BDX_NO_WINDOW_UPLOAD: the host entry point always uploads whole reads
-    int no_clean = 0;     // BDX_NO_CLEAN: exact kernel's register DP always in its predicated by-construction form
+    int seed_hash_l2 = 0;  // BDX_SEED_HASH_L2: the piece hash table stays in global memory
+    int seed_bm_log2 = 0;  // BDX_SEED_BM_LOG2: size of the seed bitmap (log2 of its bits)
+    int no_clean = 0;     // BDX_NO_CLEAN
+    int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP: exact kernel's register DP always in its predicated by-construction form
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
 };
@@ -86,6 +89,7 @@ struct bdx_ctx {
     DevBuf d_vlen, d_vlo;
     int virt_maxlen = 0;     // > 0 while a window-upload batch is being classified: its longest read
     int64_t window_uploads = 0;
+    int64_t band_launches = 0;  // (pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled
     std::vector<uint8_t> h_win;    // host staging of the compacted windows
     std::vector<int64_t> h_coff;
     std::vector<int32_t> h_vlen, h_vlo;

@@ -57,6 +57,11 @@ struct BdxDevCfg {
     // stands for.  Position p of read i lives at seq[off[i] + p - vlo[i]].  NULL: ordinary batches.
     const int32_t *vlen;
     const int32_t *vlo;
+    // per launch of the exact kernel, split mode with column windows: the budget (unit operations) the fused kernel's
+    // tracked sweeps used for every barcode of the pass and the lookback it subtracted from the first end column;
+    // with both the exact kernel rebuilds [e_lo, e_hi] and runs the diagonal-band DP (sg_core_band).  -1: off.
+    int band_kb[2];
+    int band_lb[2];
     BdxDevPass pass[2];
 };
 
@@ -112,6 +117,7 @@ struct BdxBitparPlan {
     int short_lb[2];       // per launch and pass: short lookback of the restricted runs (score / end-only clean-class passes)
     int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
+    int kb_uniform[2];  // the budget every barcode of the pass has in this filter set, or -1 (mixed)
     int tier_capped;       // tier 1: some barcode's budget was capped below its full budget
     double tier_slo[2];    //   ... per pass the smallest score a barcode beyond its capped budget can have (else +Inf)
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32

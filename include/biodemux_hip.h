@@ -261,6 +261,12 @@ const char *bdx_kernel_path(const bdx_ctx *ctx);
  * window. */
 int64_t bdx_window_uploads(const bdx_ctx *ctx);
 
+/* How many (pass, exact-kernel launch) pairs ran with the diagonal-band DP enabled (traceback / weighted-cost
+ * configs whose barcodes all have 24 or all have 32 bases: the exact stage then computes only the diagonals an
+ * alignment within the budget can touch, semiglobal_alignment_core classification.jl:238-445 restricted to them).
+ * Results are identical either way; the counter exists so that tests can tell which form ran. */
+int64_t bdx_band_launches(const bdx_ctx *ctx);
+
 typedef struct {
     int32_t threads_per_block;
     int32_t lds_bytes_per_block;

@@ -1311,6 +1311,167 @@ int64_t orc_selftest_clean_short_lookback(uint64_t seed, int64_t iters, int64_t 
     return bad;
 }
 
+/* ---- model of the HIP "diagonal band" DP (csrc/bdx_core.h sg_core_band), test-only --------------------------
+ * Claim: clean class as above; [e_lo, e_hi] = first / last column of the pass window whose unit-cost
+ * distance is <= kb (the fused kernel's tracked sweep), H >= (e_hi - e_lo + 1) + 2 kb.  An alignment of <= kb
+ * operations that ends in row m at a column je of that window passes only through cells (i, j) with
+ * |(je - j) - (m - i)| <= kb, i.e. on the diagonals  j - i  in  [e_lo - m - kb, e_hi - m + kb].  A DP that computes
+ * only the H diagonals below  dtop = e_hi + kb - m  (everything else reads as infinite, row 0 as 0 with origin j,
+ * the reference's initial column indel*i / 1-i when the band crosses the first column of the pass window) records
+ * the same (score, start, end) as the reference's full run whenever that result costs <= kb * cmin: every cell on a
+ * recorded path, and every predecessor that attains a minimum on it, lies inside the band with its true value; the
+ * other predecessors only grow.  With a capped kb (tier 1) anything else it records costs >= (kb + 1) * cmin.
+ * Columns are walked relative to the lane's own anchor (step k <-> column e_hi + kb - (m + H - 2) + k), so the rows
+ * of a step are the same for every lane: rows k - H + 2 .. k + 1 (clipped to 1 .. m). */
+static orc_align_t band_dp(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                           int64_t mismatch, int64_t indel, int32_t output_mode, int32_t trim_side, int64_t first,
+                           int64_t last, int64_t norm, int64_t e_lo, int64_t e_hi, int64_t kb, int64_t H) {
+    const int tb = output_mode == ORC_OUT_TRACEBACK;
+    res_t result = init_result();
+    if (m == 0 || n == 0) return finalize_result(output_mode, result, norm);
+    const int64_t ae = (int64_t)floor(max_error * (double)norm);
+    int64_t D[80], O[80];
+    for (int64_t i = 0; i < 80; i++) {
+        D[i] = INF_INT;
+        O[i] = -1;
+    }
+    if (first < 1) first = 1;
+    if (last > n) last = n;
+    const int64_t K = m + H - 2, A = e_hi + kb;
+    for (int64_t k = 0; k <= K; k++) {
+        const int64_t j = A - K + k;
+        int64_t ra = k - H + 2, rb = k + 1; /* band rows of this step */
+        if (j == first) { /* the reference's initial column (:278-283) on the rows the band held one step earlier */
+            for (int64_t i = ra - 1; i <= rb - 1; i++)
+                if (i >= 1 && i <= m) {
+                    D[i] = indel * i;
+                    O[i] = 1 - i;
+                }
+        }
+        if (j < first || j > last || j > e_hi) continue;
+        const int64_t lo = ra < 1 ? 1 : ra, hi = rb > m ? m : rb;
+        int64_t prev = INF_INT, prev_o = -1, diag = INF_INT, diag_o = -1, vm = INF_INT, om = -1;
+        if (lo == 1) {
+            prev = 0, prev_o = j, diag = 0, diag_o = j; /* row 0: value 0, origin j (:288, :308) */
+        } else {
+            diag = D[lo - 1], diag_o = O[lo - 1]; /* (lo-1, j-1) lies on the band's top diagonal */
+        }
+        for (int64_t i = lo; i <= hi; i++) {
+            const int64_t old = D[i], old_o = O[i];
+            const int64_t ins = (i == rb) ? INF_INT : old + indel; /* (i, j-1) below the band */
+            const int64_t del = prev >= INF_INT ? INF_INT : prev + indel;
+            const int64_t sub = diag >= INF_INT ? INF_INT : diag + (q0[i - 1] == r0[j - 1] ? match : mismatch);
+            int64_t b2 = del, o = prev_o;
+            if (sub < b2) {
+                b2 = sub;
+                o = diag_o;
+            }
+            if (i == m) { /* the last row has no horizontal move */
+                vm = b2;
+                om = o;
+            }
+            int64_t nv = b2;
+            if (ins < nv) {
+                nv = ins;
+                o = old_o;
+            }
+            if (nv > INF_INT) nv = INF_INT;
+            D[i] = nv;
+            O[i] = o;
+            prev = nv;
+            prev_o = o;
+            diag = old;
+            diag_o = old_o;
+        }
+        if (j >= e_lo && vm <= ae) {
+            if (vm == 0 && (!tb || trim_side == 5)) { /* :420-430 */
+                result.score = 0;
+                if (tb) {
+                    result.start = om;
+                    result.end = j;
+                }
+                return finalize_result(output_mode, result, norm);
+            }
+            result = tb ? update_result_traceback(trim_side, result, vm, j, om) : update_result_scoreonly(result, vm);
+        }
+    }
+    return finalize_result(output_mode, result, norm);
+}
+
+int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL; no mismatch: [1..3] = cases compared exactly, of those with traceback, of those with the band crossing the first column */) {
+    int64_t n_exact = 0, n_tb = 0, n_edge = 0;
+    static const char AL[6] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[260];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 2 + (int64_t)(st_next(&s) % 31);
+        int64_t n = (int64_t)(st_next(&s) % 250);
+        const int lowc = (st_next(&s) % 5) == 0;
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : 4)];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[st_next(&s) % (lowc ? 2 : ((st_next(&s) % 50) ? 4 : 5))];
+        int copies = (int)(st_next(&s) % 3);
+        for (int cpy = 0; cpy < copies && n > 0; cpy++) {
+            /* (also copies hanging over either end of the read: the band then crosses the first column) */
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)(n + 8)) - 4;
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (pos < 0) { pos++; continue; }
+                if (u < 5) r[pos++] = (uint8_t)AL[st_next(&s) % 4];
+                else if (u < 8) continue;
+                else if (u < 11) { r[pos++] = (uint8_t)AL[st_next(&s) % 4]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        double rate = RATES[st_next(&s) % 8];
+        int64_t mismatch = 1 + (int64_t)(st_next(&s) % 3), indel = 1 + (int64_t)(st_next(&s) % 3);
+        int64_t match = (st_next(&s) % 8) == 0 ? 1 : 0;
+        int32_t mode = (int32_t)(st_next(&s) % 2);
+        int32_t trim = mode ? (int32_t)((int[]){0, 3, 5}[st_next(&s) % 3]) : 0;
+        int64_t first = 1, last = n;
+        if (n > 0 && (st_next(&s) % 3) == 0) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        int64_t ae0 = (int64_t)floor(rate * (double)m);
+        int64_t cmin = mismatch < indel ? mismatch : indel;
+        int64_t kb = ae0 < 0 ? -1 : ae0 / cmin;
+        if ((st_next(&s) % 3) == 0 && kb > 0) kb = (int64_t)(st_next(&s) % (uint64_t)(kb + 1)); /* a capped budget (tier 1) */
+        double used = (st_next(&s) % 3) ? rate : rate * (double)(st_next(&s) % 100) / 100.0;
+        orc_align_t full = semiglobal_core_cols(DP, OG, q, m, r, n, used, match, mismatch, indel, 0, 0, mode, trim, first,
+                                                last, n, 1, m, INT64_MIN, INT64_MAX);
+        int64_t e_lo = 0, e_hi = 0;
+        int64_t f = first < 1 ? 1 : first, l = last > n ? n : last;
+        int found = (n > 0 && l >= f && kb >= 0) ? (int)unit_cols(q, m, r, f, l, 0, kb, &e_lo, &e_hi) : 0;
+        if (!found) continue; /* (the barcode is not a candidate at this budget) */
+        int64_t H = (e_hi - e_lo + 1) + 2 * kb + (int64_t)(st_next(&s) % 4);
+        if (H > 40) continue; /* (the kernel falls back to the all-rows DP) */
+        orc_align_t got = band_dp(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, e_lo, e_hi, kb, H);
+        const int64_t ops_bound = kb * cmin;
+        int wrong;
+        if (full.raw <= ops_bound) wrong = got.raw != full.raw || (mode && (got.end != full.end || got.start != full.start));
+        else wrong = got.raw <= ops_bound; /* beyond the budget: anything, but never a value inside it */
+        n_exact += full.raw <= ops_bound;
+        n_tb += full.raw <= ops_bound && mode;
+        n_edge += full.raw <= ops_bound && e_hi + kb - (m + H - 2) < first; /* the band crosses the window's first column */
+        if (wrong) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = full.raw;
+                first_bad[4] = got.raw; first_bad[5] = full.start; first_bad[6] = got.start; first_bad[7] = mode * 10 + trim;
+            }
+            bad++;
+        }
+    }
+    if (bad == 0 && first_bad) {
+        first_bad[1] = n_exact;
+        first_bad[2] = n_tb;
+        first_bad[3] = n_edge;
+    }
+    return bad;
+}
+
 int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
     static const char AL[6] = "ACGTN";
     static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};

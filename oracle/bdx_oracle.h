@@ -167,6 +167,7 @@ int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first
 int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_clean_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_clean_short_lookback(uint64_t seed, int64_t iters, int64_t *first_bad);
+int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,59 @@ def random_case_tiers(seed: int, n_reads: int = 1500):
     return cfg, seq, off
 
 
+def random_case_band(seed: int, n_reads: int = 1500):
+    """The diagonal-band DP's domain (exact stage, clean class, every barcode with 24 or every barcode with 32 bases):
+    traceback through trimming or summary, or weighted costs; budgets 0..4 and beyond (fallback), tiers, column
+    windows that start inside the read, barcodes hanging over either end of the read, concatemers, low-complexity
+    barcodes (wide end-column windows: the 17-diagonal body or the all-rows fallback), dual."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xBA9D))
+    m = 24 if rng.random() < 0.7 else 32
+    B = int(rng.integers(8, 140))
+    lowc = rng.random() < 0.15
+    if lowc:
+        bcs = ["".join("AC"[int(x)] for x in rng.integers(0, 2, size=m)) for _ in range(B)]
+        bcs = list(dict.fromkeys(bcs))
+    else:
+        bcs = _rand_barcodes(rng, B, m, m, False)
+    dual = rng.random() < 0.3
+    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 48)), m, m, False) if dual else []
+    unit = rng.random() < 0.6
+    trim = [None, 3, 3, 5, 5][int(rng.integers(0, 5))]
+    summary = bool(rng.random() < (0.6 if trim is None and unit else 0.15))
+    rngs = ["1:end"] * 5 + ["5:end-3", "1:120", "20:end", "end-90:end"]
+    kw = dict(
+        bc_seqs=bcs, bc_lengths_no_N=[m] * len(bcs), ids=[f"a{i}" for i in range(len(bcs))],
+        max_error_rate=float([0.05, 0.1, 0.1, 0.13, 0.17, 0.2, 0.2, 0.25][int(rng.integers(0, 8))]),
+        min_delta=float([0.0, 0.0, 0.05, 0.1][int(rng.integers(0, 4))]),
+        match=0, mismatch=1 if unit else int(rng.integers(1, 4)), indel=1 if unit else int(rng.integers(1, 4)),
+        ref_search_range=H.bdx.parse_dynamic_range(rngs[int(rng.integers(0, len(rngs)))]),
+        trim_side=trim, summary=summary,
+    )
+    if dual:
+        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[m] * len(bcs2), ids2=[f"b{i}" for i in range(len(bcs2))],
+                  trim_side2=[None, 3, 5][int(rng.integers(0, 3))])
+    cfg = H.bdx.DemuxConfig(**kw)
+    max_len = int([60, 100, 150, 150, 200][int(rng.integers(0, 5))])
+    second = (bcs2, max_len // 2, None) if dual else None
+    repeat = dict(frac=0.3) if rng.random() < 0.3 else None
+    err = float([0.0, 0.02, 0.04, 0.07][int(rng.integers(0, 4))])
+    seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 2 if rng.random() < 0.5 else max_len, max_len, seed=seed,
+                                          plant_frac=0.85, sub=err, ins=err / 3, dele=err / 3, n_rate=0.003,
+                                          plant_hi=(max_len // 3 if dual else None), second=second, repeat=repeat)
+    # barcodes hanging over the ends of the read: a prefix cut off at the read's start, a suffix at its end
+    seq = seq.copy()
+    for i in range(0, n_reads, 7):
+        n = int(off[i + 1] - off[i])
+        b = np.frombuffer(bcs[int(rng.integers(0, len(bcs)))].encode(), dtype=np.uint8)
+        cut = int(rng.integers(1, 5))
+        if n >= m:
+            if i % 2:
+                seq[off[i]: off[i] + m - cut] = b[cut:]
+            else:
+                seq[off[i + 1] - (m - cut): off[i + 1]] = b[:m - cut]
+    return cfg, seq, off
+
+
 def assert_same(got: dict, exp: dict, what: str = ""):
     for k in ("bc1", "bc2", "keep_start", "keep_end", "pass_bc", "pass_start", "pass_end"):
         if k in got and k in exp:

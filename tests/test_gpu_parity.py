@@ -98,6 +98,58 @@ def test_fuzz_tiers_vs_oracle(seed):
             assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
 
 
+_BAND_RUNS = {"cases": 0, "band": 0}
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_band_vs_oracle(seed):
+    """Random configs in the diagonal-band DP's domain (fuzz.random_case_band): traceback or weighted costs, every
+    barcode with 24 or with 32 bases.  With and without per-pass outputs (trim_side 5 without them runs the end-only
+    form), and the summary statistics where the config collects them."""
+    cfg, seq, off = fuzz.random_case_band(seed, n_reads=1500)
+    for want_pass in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want_pass)
+        exp = oc.classify(seq, off)
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"seed {seed} pass outputs {want_pass} [{hc.kernel_path}] band {hc.band_launches}")
+            assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+            _BAND_RUNS["cases"] += 1
+            _BAND_RUNS["band"] += hc.band_launches > 0
+    if seed == 39:  # the generator must actually reach the band form in most of its cases
+        assert _BAND_RUNS["band"] * 2 > _BAND_RUNS["cases"], _BAND_RUNS
+
+
+def test_band_dp_equals_the_all_rows_dp(monkeypatch):
+    """Same batch through the diagonal-band DP and (BDX_NO_BAND) through the all-rows clean-class DP: every output and
+    the device statistics agree, for trim_side 3 / 5 / summary at budgets 2 (9 diagonals) and 4 (17 diagonals)."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 40000, 150, repeat=dict(frac=0.1))
+    for kw in (dict(max_error_rate=0.1, trim_side=3), dict(max_error_rate=0.2, trim_side=5), dict(max_error_rate=0.2, summary=True),
+               dict(max_error_rate=0.17, trim_side=3, min_delta=0.05), dict(max_error_rate=0.2, mismatch=1, indel=2)):
+        cfg = _c2_config(bcs, **kw)
+        outs = {}
+        for band in (True, False):
+            if band:
+                monkeypatch.delenv("BDX_NO_BAND", raising=False)
+            else:
+                monkeypatch.setenv("BDX_NO_BAND", "1")
+            with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+                outs[band] = hc.classify(seq, off)
+                assert (hc.band_launches > 0) == band, (kw, hc.kernel_path)
+                if cfg.summary:
+                    outs[band]["tabs"] = hc.stats_tables()
+        for k, v in outs[True].items():
+            if k == "tabs":
+                for p_ in v:
+                    for name in v[p_]:
+                        assert np.array_equal(v[p_][name][0], outs[False]["tabs"][p_][name][0]), (kw, name)
+            else:
+                assert np.array_equal(v, outs[False][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, outs[False][k]), (kw, k)
+        exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq[:off[5000]], off[:5001])
+        fuzz.assert_same({k: (v[:5000] if v.shape[0] == 40000 else v[:10000]) for k, v in outs[True].items() if k != "tabs"}, exp, str(kw))
+
+
 def _c2_config(bcs, **kw):
     base = dict(bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"bc{i + 1}" for i in range(len(bcs))],
                 max_error_rate=0.1)

@@ -59,3 +59,15 @@ def test_clean_class_short_lookback_for_score_and_end():
     fb = (C.c_int64 * 8)()
     bad = H.orc.lib().orc_selftest_clean_short_lookback(20260515, 400_000, fb)
     assert bad == 0, list(fb)
+
+
+def test_diagonal_band_dp_records_what_the_reference_records():
+    """The exact stage's diagonal-band DP (csrc/bdx_core.h sg_core_band, oracle model band_dp): with the end columns of
+    the tracked sweep known, a DP over the H >= W + 2 kb diagonals an alignment within the budget can touch returns
+    the reference's (score, start, end) — all three output forms, both trim sides, ties, copies hanging over the
+    read's ends, column windows that start inside the read, capped budgets (then: never a value within the cap that
+    the reference does not return)."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_band_class(20260515, 600_000, fb)
+    assert bad == 0, list(fb)
+    assert fb[1] > 50_000 and fb[2] > 20_000 and fb[3] > 5_000, list(fb)  # compared exactly / with traceback / band across the first column
