@@ -1275,7 +1275,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             BdxDevCfg dv = ctx->dev;
             for (int k = 0; k < npass; ++k) {
                 const int kb = f.bplan.kb_uniform[k];
-                const bool on = windows && f.splan.enabled && ctx->plan.clean && ctx->plan.uniform_m && !ctx->tune.no_band &&
+                const bool on = windows && ctx->plan.clean && ctx->plan.uniform_m && !ctx->tune.no_band &&
                                 ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && kb >= 0 && kb <= 4;
                 dv.band_kb[k] = on ? kb : -1;
                 if (on) ctx->band_launches += 1;
