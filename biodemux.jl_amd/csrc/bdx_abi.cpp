@@ -790,10 +790,33 @@ int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int npass = ctx->dev.is_dual ? 2 : 1;
+    if (!ctx->st_len_fixed) {
+        // the transposed len table grows by its key stride: every barcode's run of counters moves to the new pitch
+        const int old_stride = bdx_stats_stride(ctx, 1);
+        const int old_rows = ctx->st_len_rows;
+        ctx->st_len_rows = (int)(want > 0x3FFFFFF0LL ? 0x3FFFFFF0LL : want);
+        const int new_stride = bdx_stats_stride(ctx, 1);
+        for (int p = 0; p < npass; ++p) {
+            const size_t B = (size_t)ctx->dev.pass[p].n_barcodes;
+            DevBuf nb;
+            hipError_t e1 = nb.ensure((size_t)new_stride * B * 8);
+            if (e1 == hipSuccess) e1 = hipMemset(nb.p, 0, (size_t)new_stride * B * 8);
+            if (e1 == hipSuccess && old_rows > 0 && ctx->st_tab[p][1].p)
+                e1 = hipMemcpy2D(nb.p, (size_t)new_stride * 8, ctx->st_tab[p][1].p, (size_t)old_stride * 8, (size_t)old_stride * 8, B,
+                                 hipMemcpyDeviceToDevice);
+            if (e1 != hipSuccess) {
+                nb.release();
+                ctx->st_len_rows = old_rows;
+                return fail(ctx, BDX_E_DEVICE, "growing the statistics tables failed: %s", hipGetErrorString(e1));
+            }
+            ctx->st_tab[p][1].release();
+            ctx->st_tab[p][1] = nb;
+        }
+    }
     for (int p = 0; p < npass; ++p)
-        for (int w = 0; w < 2; ++w) {  // pos, len (raw has a fixed height)
-            const size_t old_bytes = bdx_stats_words(ctx, p, w, ctx->st_rows) * 8;
-            const size_t new_bytes = bdx_stats_words(ctx, p, w, want) * 8;
+        for (int w = 0; w < 1; ++w) {  // pos (raw has a fixed height; len: above)
+            const size_t old_bytes = bdx_stats_phys_words(ctx, p, w, ctx->st_rows) * 8;
+            const size_t new_bytes = bdx_stats_phys_words(ctx, p, w, want) * 8;
             DevBuf nb;
             HIP_TRY(ctx, nb.ensure(new_bytes));
             hipError_t e1 = hipMemset(nb.p, 0, new_bytes);
@@ -827,11 +850,18 @@ int init_stats(bdx_ctx *ctx) {
     if (top > (double)(1 << 20))
         return fail(ctx, BDX_E_INVALID, "summary statistics support scores up to %d; max_error_rate * barcode length gives %g", 1 << 20, top);
     ctx->st_raw_rows = (int)top + 1;
-    for (int p = 0; p < npass; ++p) {
-        const size_t bytes = bdx_stats_words(ctx, p, 2, 0) * 8;
-        HIP_TRY(ctx, ctx->st_tab[p][2].ensure(bytes));
-        HIP_TRY(ctx, hipMemset(ctx->st_tab[p][2].p, 0, bytes));
-    }
+    // Clean-class configs (and :hamming / :exact): an alignment spans at most m columns plus its insertions (<= m),
+    // leading deletions count through the origin: end - start + 1 <= 2 m — a fixed height.  Otherwise (start / end
+    // ranges that bind: the band's seeded cells carry origins of their own) only start >= 1 - m and end <= n hold:
+    // the table grows with the reads like the position table.
+    ctx->st_len_fixed = ctx->plan.clean || c.algorithm != BDX_ALG_SEMIGLOBAL;
+    ctx->st_len_rows = ctx->st_len_fixed ? 2 * ctx->dev.max_m + 2 : 0;
+    for (int p = 0; p < npass; ++p)
+        for (int w = (ctx->st_len_fixed ? 1 : 2); w < 3; ++w) {
+            const size_t bytes = bdx_stats_phys_words(ctx, p, w, 0) * 8;
+            HIP_TRY(ctx, ctx->st_tab[p][w].ensure(bytes));
+            HIP_TRY(ctx, hipMemset(ctx->st_tab[p][w].p, 0, bytes));
+        }
     HIP_TRY(ctx, ctx->st_flag.ensure(256));
     HIP_TRY(ctx, hipMemset(ctx->st_flag.p, 0, 256));
     return BDX_OK;
@@ -1189,6 +1219,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         }
         st.rows = ctx->st_rows;
         st.raw_rows = ctx->st_raw_rows;
+        st.len_rows = ctx->st_len_rows;
+        st.len_stride = bdx_stats_stride(ctx, 1);
+        st.raw_stride = bdx_stats_stride(ctx, 2);
         st.pos_bias = ctx->dev.max_m;
         st.overflow = (unsigned int *)ctx->st_flag.p;
         stp = &st;
@@ -1402,7 +1435,7 @@ int32_t bdx_reset_counts(bdx_ctx *ctx) {
         for (int p = 0; p < (ctx->dev.is_dual ? 2 : 1); ++p)
             for (int w = 0; w < 3; ++w)
                 if (ctx->st_tab[p][w].p)
-                    HIP_TRY(ctx, hipMemsetAsync(ctx->st_tab[p][w].p, 0, bdx_stats_words(ctx, p, w, ctx->st_rows) * 8, ctx->stream));
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->st_tab[p][w].p, 0, bdx_stats_phys_words(ctx, p, w, ctx->st_rows) * 8, ctx->stream));
     return BDX_OK;
 }
 
@@ -1410,7 +1443,7 @@ int32_t bdx_stats_shape(const bdx_ctx *ctx, int32_t pass, int32_t which, int64_t
     if (!ctx) return BDX_E_INVALID;
     if (pass < 0 || pass > 1 || which < BDX_STATS_POS || which > BDX_STATS_RAW) return BDX_E_INVALID;
     const bool on = ctx->dev.need_traceback && (pass == 0 || ctx->dev.is_dual);
-    if (rows) *rows = !on ? 0 : (which == BDX_STATS_RAW ? ctx->st_raw_rows : ctx->st_rows);
+    if (rows) *rows = !on ? 0 : (which == BDX_STATS_RAW ? ctx->st_raw_rows : which == BDX_STATS_LEN ? ctx->st_len_rows : ctx->st_rows);
     if (key0) *key0 = which == BDX_STATS_POS ? 1 - (int64_t)ctx->dev.max_m : 0;
     if (n_barcodes) *n_barcodes = on ? ctx->dev.pass[pass].n_barcodes : 0;
     return BDX_OK;
@@ -1428,9 +1461,21 @@ int32_t bdx_get_stats(bdx_ctx *ctx, int32_t pass, int32_t which, int32_t reduced
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->st_flag.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-    if (words) HIP_TRY(ctx, hipMemcpyAsync(out, src.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int64_t> phys;  // len / raw: [barcode][key stride] on the device
+    if (which == BDX_STATS_POS) {
+        if (words) HIP_TRY(ctx, hipMemcpyAsync(out, src.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        phys.resize(bdx_stats_phys_words(ctx, pass, which, rows));
+        if (!phys.empty()) HIP_TRY(ctx, hipMemcpyAsync(phys.data(), src.p, phys.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (flag) return fail(ctx, BDX_E_STATE, "a statistics key fell outside its table (internal sizing error)");
+    if (which != BDX_STATS_POS) {
+        const size_t B = (size_t)ctx->dev.pass[pass].n_barcodes, stride = (size_t)bdx_stats_stride(ctx, which);
+        const size_t keys = which == BDX_STATS_RAW ? (size_t)ctx->st_raw_rows : (size_t)ctx->st_len_rows;
+        for (size_t k = 0; k < keys; ++k)
+            for (size_t b = 0; b < B; ++b) out[k * B + b] = phys[b * stride + k];
+    }
     return BDX_OK;
 }
 

@@ -224,7 +224,7 @@ static int stats_agree_finish(bdx_ctx *ctx) {
     if (rc != BDX_OK) return rc;
     const int npass = ctx->dev.is_dual ? 2 : 1;
     for (int p = 0; p < npass; ++p)
-        for (int w = 0; w < 3; ++w) HIP_TRY(ctx, ctx->st_sum[p][w].ensure(bdx_stats_words(ctx, p, w, ctx->st_rows) * 8 + 8));
+        for (int w = 0; w < 3; ++w) HIP_TRY(ctx, ctx->st_sum[p][w].ensure(bdx_stats_phys_words(ctx, p, w, ctx->st_rows) * 8 + 8));
     ctx->st_sum_rows = ctx->st_rows;
     return BDX_OK;
 }
@@ -241,7 +241,7 @@ static int enqueue_allreduce(bdx_ctx *ctx, Rccl *R) {
         if (ctx->dev.need_traceback)
             for (int p = 0; p < npass; ++p)
                 for (int w = 0; w < 3; ++w) {
-                    const size_t words = bdx_stats_words(ctx, p, w, ctx->st_rows);
+                    const size_t words = bdx_stats_phys_words(ctx, p, w, ctx->st_rows);
                     if (words) HIP_TRY(ctx, hipMemcpyAsync(ctx->st_sum[p][w].p, ctx->st_tab[p][w].p, words * 8, hipMemcpyDeviceToDevice, ctx->stream));
                 }
         return BDX_OK;
@@ -250,7 +250,7 @@ static int enqueue_allreduce(bdx_ctx *ctx, Rccl *R) {
     if (ctx->dev.need_traceback)
         for (int p = 0; p < npass; ++p)
             for (int w = 0; w < 3; ++w) {
-                const size_t words = bdx_stats_words(ctx, p, w, ctx->st_rows);
+                const size_t words = bdx_stats_phys_words(ctx, p, w, ctx->st_rows);
                 if (words) NCCL_TRY(ctx, R, R->AllReduce(ctx->st_tab[p][w].p, ctx->st_sum[p][w].p, words, ncclInt64, ncclSum, ctx->comm->comm, ctx->stream));
             }
     return BDX_OK;

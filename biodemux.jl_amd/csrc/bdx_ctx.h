@@ -101,7 +101,8 @@ struct bdx_ctx {
     // rows x n_barcodes, their all-reduced twins, and the overflow flag
     DevBuf st_tab[2][3], st_sum[2][3], st_flag;
     long long st_rows = 0, st_sum_rows = 0;
-    int st_raw_rows = 0;
+    int st_raw_rows = 0, st_len_rows = 0;
+    bool st_len_fixed = false;  // the length table has a height known from the config (else it grows with the reads)
     // multi-GPU: communicator + the reduced counter vector (bdx_comm.cpp)
     bdx_comm_state *comm = nullptr;
     DevBuf counts_sum;
@@ -116,8 +117,17 @@ int bdx_fail(bdx_ctx *ctx, int code, const char *fmt, ...);
 void bdx_comm_release(bdx_ctx *ctx);  // bdx_comm.cpp: frees ctx->comm (called by bdx_destroy)
 // histogram tables: grow (append zero rows) to at least `rows` rows; synchronises the stream when it grows
 int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact = false);  // exact: the height the ranks agreed on
+// logical size of a table as bdx_get_stats hands it out: [keys][barcodes]
 inline size_t bdx_stats_words(const bdx_ctx *ctx, int pass, int which, long long rows) {
-    return (size_t)(which == 2 ? ctx->st_raw_rows : rows) * (size_t)ctx->dev.pass[pass].n_barcodes;
+    return (size_t)(which == 2 ? ctx->st_raw_rows : which == 1 ? ctx->st_len_rows : rows) * (size_t)ctx->dev.pass[pass].n_barcodes;
+}
+inline int bdx_stats_stride(const bdx_ctx *ctx, int which) {  // key stride of the transposed tables (len, raw)
+    return ((which == 2 ? ctx->st_raw_rows : ctx->st_len_rows) + 15) & ~15;
+}
+// words a table occupies on the device (pos: [rows][barcodes]; len, raw: [barcode][key stride])
+inline size_t bdx_stats_phys_words(const bdx_ctx *ctx, int pass, int which, long long rows) {
+    if (which == 0) return (size_t)rows * (size_t)ctx->dev.pass[pass].n_barcodes;
+    return (size_t)bdx_stats_stride(ctx, which) * (size_t)ctx->dev.pass[pass].n_barcodes;
 }
 
 #define HIP_TRY(ctx, call)                                                                      \

@@ -73,13 +73,13 @@ __device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p,
     const long long prow = (long long)po.start - 1 + st.pos_bias;
     const long long lrow = (long long)po.end - po.start + 1;
     const long long rrow = po.raw;
-    if (prow < 0 || prow >= st.rows || lrow < 0 || lrow >= st.rows || rrow < 0 || rrow >= st.raw_rows) {
+    if (prow < 0 || prow >= st.rows || lrow < 0 || lrow >= st.len_rows || rrow < 0 || rrow >= st.raw_rows) {
         atomicOr(st.overflow, 1u);
         return;
     }
     atomicAdd(&st.pos[p][prow * B + b], 1ULL);
-    atomicAdd(&st.len[p][lrow * B + b], 1ULL);
-    atomicAdd(&st.raw[p][rrow * B + b], 1ULL);
+    atomicAdd(&st.len[p][b * st.len_stride + lrow], 1ULL);
+    atomicAdd(&st.raw[p][b * st.raw_stride + rrow], 1ULL);
 }
 
 // LDS carve-up (all 16-byte aligned):

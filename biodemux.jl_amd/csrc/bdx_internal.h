@@ -78,8 +78,13 @@ struct BdxDevOut {
 // in a later batch only appends rows.
 struct BdxDevStats {
     unsigned long long *pos[2], *len[2], *raw[2];
-    long long rows;       // rows of pos / len (0: no statistics)
+    long long rows;       // rows of pos (0: no statistics)
     int raw_rows;
+    // len and raw live TRANSPOSED on the device, [barcode][key] with the key stride a multiple of 16 counters: nearly
+    // every match of a barcode has the same length and one of two or three scores, so in [key][barcode] order the
+    // whole batch would hammer the half dozen cache lines of those rows (measured: 1.0 of 3.2 ms per 2 M reads);
+    // per barcode the hot keys share one line of their own.  bdx_get_stats hands them out as [key][barcode].
+    int len_rows, len_stride, raw_stride;
     int pos_bias;         // = max barcode length
     unsigned int *overflow;  // set when a key does not fit (cannot happen with rows sized from the batch)
 };

@@ -198,8 +198,10 @@ int32_t bdx_reset_counts(bdx_ctx *ctx);
  *   BDX_STATS_POS  key = best_start (row r holds key r + key0, key0 = 1 - longest barcode: origins may precede the read)
  *   BDX_STATS_LEN  key = best_end - best_start + 1
  *   BDX_STATS_RAW  key = integer numerator of min_score; the host derives round(raw / normalisation, digits = 2) (:835)
- * Summing a row over the barcodes gives bc{1,2}_{pos,len,score}_counts, a column bc{1,2}_per_bc_*.  rows grows with
- * the longest read seen (pos, len); bdx_stats_shape reports the current shape.  reduced != 0 reads the tables
+ * Summing a row over the barcodes gives bc{1,2}_{pos,len,score}_counts, a column bc{1,2}_per_bc_*.  The pos table
+ * grows with the longest read seen; len has 2 * (longest barcode) + 2 rows when no start / end range binds (an
+ * alignment spans its barcode's bases plus at most as many insertions) and grows with the reads otherwise; raw has
+ * floor(max_error_rate * normalisation) + 1 rows; bdx_stats_shape reports the current shape.  reduced != 0 reads the tables
  * summed over the ranks by bdx_allreduce_counts* (which all-reduces them together with the counter vector). */
 #define BDX_STATS_POS 0
 #define BDX_STATS_LEN 1
