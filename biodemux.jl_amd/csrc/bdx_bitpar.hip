@@ -172,6 +172,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS uint32_t *wq = slots;  // split mode: candidates to re-sweep with column tracking (4 R entries)
     LDS int *wcl = scnt;       // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
+    LDS unsigned char *act = take(!SEED && cfg.is_dual ? (size_t)R : 0);  // plain sweep, dual: reads whose first pass has a candidate
     LDS uint32_t *slh = (LDS uint32_t *)take(SEED ? (size_t)R * 4 : 0);  // per read: first | (last + 1) << 16 seed start, relative to the first staged base
     LDS int *srw = (LDS int *)take(SEED ? (size_t)R * 4 : 0);            // per read: stage offset of its first staged base
     // DIAG variant: per-read inverted index of 4-mers (bit p of occ[r][key][.] <=> the 4-mer at staged position p is key)
@@ -544,13 +545,29 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         if (!SEED) {
             for (int p = 0; p < npass; ++p) {
                 const int B = p ? B1 : B0;
-                const int total = BDX_DBG(2) ? 0 : nr * B;
+                int nrp = nr;
+                if (p == 1) {
+                    // the second pass only runs on reads whose first pass matched (classification.jl:884-891): a read
+                    // without any first-pass candidate is :unknown whatever its second pass holds — not swept
+                    __syncthreads();
+                    if (tid == 0) sqn[6] = 0;
+                    __syncthreads();
+                    for (int t = tid; t < nr; t += BS) {
+                        uint32_t any = 0;
+                        for (int w = 0; w < cw0; ++w) any |= cand[t * cw0 + w];
+                        if (any) act[__hip_atomic_fetch_add(&sqn[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (unsigned char)t;
+                    }
+                    __syncthreads();
+                    nrp = sqn[6];
+                }
+                const int total = BDX_DBG(2) ? 0 : nrp * B;
                 for (int pair = tid; pair < total; pair += 2 * BS) {
                     Sweep A, Bw;
                     const int pb = pair + BS;
-                    const int rA = pair / B, rB = pb / B;
-                    setup(true, p, rA, pair - rA * B, A);
-                    setup(pb < total, p, rB, pb - rB * B, Bw);
+                    const int iA = pair / B, iB = pb < total ? pb / B : 0;
+                    const int rA = p ? (int)act[iA] : iA, rB = p ? (int)act[iB] : iB;
+                    setup(true, p, rA, pair - iA * B, A);
+                    setup(pb < total, p, rB, pb - iB * B, Bw);
                     sweep2(A, Bw);
                 }
             }
@@ -1195,6 +1212,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
         o += al((size_t)R) + 2 * al((size_t)R * 4);
     }
     o += al(32);
+    if (!(sp && sp->enabled) && cfg.is_dual) o += al((size_t)R);  // act[]
     return o;
 }
 

@@ -72,6 +72,31 @@ for seed in range(lo3, hi3):
 print(f"tier seeds {lo3}..{hi3 - 1}: paths {paths3}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
+# the diagonal-band DP's domain (exact stage; every barcode with 24 or with 32 bases; traceback / weighted costs)
+lo4, hi4 = int(os.environ.get("SEED4_LO", "20000")), int(os.environ.get("SEED4_HI", "20300"))
+paths4 = {}
+band_runs = 0
+t0 = time.time()
+for seed in range(lo4, hi4):
+    cfg, seq, off = fuzz.random_case_band(seed)
+    for want in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want)
+        exp = oc.classify(seq, off)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                got = hc.classify(seq, off)
+                paths4[hc.kernel_path] = paths4.get(hc.kernel_path, 0) + 1
+                band_runs += hc.band_launches > 0
+                fuzz.assert_same(got, exp, f"band seed {seed} want_pass {want} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), f"band seed {seed} counters"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+    if (seed - lo4) % 50 == 49:
+        print(f"  band seeds .. {seed}: mismatches so far {bad}", flush=True)
+print(f"band seeds {lo4}..{hi4 - 1}: {band_runs} runs took the band form, paths {paths4}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
 def stress(name, bcs, seq, off, **kw):
     global bad
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
