@@ -44,6 +44,7 @@ BdxTuning read_tuning() {
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
+    t.no_dense = getenv("BDX_NO_DENSE") != nullptr;
     t.no_window_upload = getenv("BDX_NO_WINDOW_UPLOAD") != nullptr;
     t.seed_hash_l2 = getenv("BDX_SEED_HASH_L2") != nullptr;
     if (const char *e = getenv("BDX_SEED_BM_LOG2")) t.seed_bm_log2 = atoi(e);
@@ -79,16 +80,27 @@ int plan_generic(bdx_ctx *ctx) {
     // barcode_end_range that resolve to 1:n for every read (no offset from either end) — then neither binds
     p.clean = 0;
     p.uniform_m = 0;
+    p.uniform_len = 0;
     if (p.reg_rows && !ctx->tune.no_clean && d.match >= 0 && d.mismatch >= 1 && d.indel >= 1) {
         bool free_ranges = true, uniform = true;
+        int len0 = -1;
+        bool same_len = true;
         for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) {
             const bdx_pass_t &ps = ctx->cfg.pass[k];
             const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
             free_ranges = free_ranges && ps.explicit_window == 0 && whole(ps.barcode_start_range) && whole(ps.barcode_end_range);
-            for (int b = 0; b < ps.n_barcodes; ++b) uniform = uniform && (int)(ps.bc_off[b + 1] - ps.bc_off[b]) == p.reg_rows;
+            for (int b = 0; b < ps.n_barcodes; ++b) {
+                const int m = (int)(ps.bc_off[b + 1] - ps.bc_off[b]);
+                uniform = uniform && m == p.reg_rows;
+                if (len0 < 0) len0 = m;
+                same_len = same_len && m == len0;
+            }
         }
         p.clean = free_ranges;
         p.uniform_m = free_ranges && uniform;
+        // the diagonal-band bodies exist for these barcode lengths (every barcode of the config alike)
+        const bool band_len = len0 == 8 || len0 == 10 || len0 == 12 || len0 == 16 || len0 == 20 || len0 == 24 || len0 == 32;
+        p.uniform_len = (free_ranges && same_len && band_len) ? len0 : 0;
     }
     p.dp_rows = p.reg_rows ? 1 : d.max_m + 1;
     p.dp_rows_fused = d.max_m + 1;
@@ -259,6 +271,31 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         bp.d_peq[k] = base + o_peq[k];
         bp.d_pvinit[k] = base + o_pv[k];
         bp.d_kb[k] = (const int32_t *)(base + o_kb[k]);
+    }
+    // Reducer replay capacity: short barcodes at high rates have many GENUINE candidates per read (a 10-mer within two
+    // edits of a random 150-base read is common: ~25 of 96 barcodes), and a read with more survivors than the replay
+    // holds costs a full exact DP per candidate.  Expected candidates per read ~ sum over barcodes of
+    // 150 * V(m, kb) / 4^m with V = sum_{e <= kb} C(m, e) 8^e (3 substitutions, 4 insertions, 1 deletion per site).
+    {
+        double expected = 0.0;
+        for (int k = 0; k < npass; ++k) {
+            const bdx_pass_t &p = c.pass[k];
+            const int32_t *kbh = (const int32_t *)(blob.data() + o_kb[k]);
+            for (int b = 0; b < p.n_barcodes; ++b) {
+                const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+                if (kbh[b] < 0 || m > 20) continue;
+                double v = 0.0, term = 1.0;
+                for (int e = 0; e <= kbh[b] && e <= m; ++e) {
+                    v += term;
+                    term *= 8.0 * (double)(m - e) / (double)(e + 1);
+                }
+                expected += 150.0 * v / std::pow(4.0, (double)m);
+            }
+        }
+        bp.slot_cap = expected < 1.0 ? 4 : expected < 2.5 ? 8 : expected < 8.0 ? 16 : 32;
+        int total_b = 0;
+        for (int k = 0; k < npass; ++k) total_b += c.pass[k].n_barcodes;
+        bp.dense_d = expected >= 1.0 && total_b <= 256 && !ctx->tune.no_dense;  // (used by the kernels without seeds only; they then keep four slots)
     }
     // known-score class (config level): SimpleScoring with unit costs, ScoreOnly output.
     for (int k = 0; k < npass; ++k) {
@@ -728,6 +765,8 @@ int upload_tables(bdx_ctx *ctx) {
     d.need_traceback = c.need_traceback != 0;
     d.force_lds_dp = ctx->tune.lds_dp;
     d.band_kb[0] = d.band_kb[1] = -1;
+    d.band_m = 0;
+    d.dense_w = 0;
     d.band_lb[0] = d.band_lb[1] = 0;
     d.max_m = 1;
     d.any_traceback = d.need_traceback;
@@ -1228,6 +1267,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     }
     bool filtered = false;
     int tier_len = 0;  // > 0: tiered budgets apply to this batch (the read length both tiers were planned for)
+    int batch_len = 0;  // the read length the filtered launches were planned for
     if (ctx->F().bplan.enabled) {
         int len = ctx->virt_maxlen > 0 ? ctx->virt_maxlen : ctx->user_len_hint;
         if (len <= 0 && measured_len >= 0) len = measured_len > 0 ? measured_len : 1;
@@ -1238,6 +1278,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             len = host_len;
         }
+        batch_len = len;
         filtered = size_bitpar(ctx, len, n_reads);
         if (filtered && ctx->tiered) {  // both tiers must be plannable for this batch, else the full budget alone
             ctx->cur = 1;
@@ -1265,10 +1306,14 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;
         uint8_t *n0 = nullptr, *n1 = nullptr;
         const bool windows = split && !ctx->tune.no_windows;
+        // dense window table of the plain-sweep kernel (few barcodes, many genuine candidates per read; columns fit 16 bits)
+        const bool dense_w = windows && ctx->fs[0].bplan.dense_d && !ctx->fs[0].splan.enabled && batch_len <= 60000 && !ctx->tune.no_dense;
         for (int k = 0; k < npass; ++k) {
             HIP_TRY(ctx, ctx->d_cand[k].ensure((size_t)n_reads * ctx->dev.pass[k].cand_words * 4 + 64));
             if (windows) {
-                HIP_TRY(ctx, ctx->d_wins[k].ensure((size_t)n_reads * BDX_WCAP * 3 * 4 + 64));
+                size_t per_read = (size_t)BDX_WCAP * 3;
+                if (dense_w && (size_t)ctx->dev.pass[k].n_barcodes > per_read) per_read = (size_t)ctx->dev.pass[k].n_barcodes;
+                HIP_TRY(ctx, ctx->d_wins[k].ensure((size_t)n_reads * per_read * 4 + 64));
                 HIP_TRY(ctx, ctx->d_wcnt[k].ensure((size_t)n_reads + 64));
             }
         }
@@ -1306,10 +1351,12 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // number of rows and of the pass with the same budget, column windows handed over by tracked sweeps
         const auto band_cfg = [&](const BdxFilterSet &f) {
             BdxDevCfg dv = ctx->dev;
+            dv.dense_w = (&f == &ctx->fs[0]) && dense_w;
             for (int k = 0; k < npass; ++k) {
                 const int kb = f.bplan.kb_uniform[k];
-                const bool on = windows && ctx->plan.clean && ctx->plan.uniform_m && !ctx->tune.no_band &&
+                const bool on = windows && ctx->plan.clean && ctx->plan.uniform_len > 0 && !ctx->tune.no_band &&
                                 ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && kb >= 0 && kb <= 4;
+                dv.band_m = ctx->plan.uniform_len;
                 dv.band_kb[k] = on ? kb : -1;
                 if (on) ctx->band_launches += 1;
                 dv.band_lb[k] = short_lb[k] ? ctx->dev.max_m + kb : 2 * (ctx->dev.max_m + kb) + 1;
@@ -1322,6 +1369,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             BdxTierArgs t1{1, (uint32_t *)ctx->d_tier.p, (unsigned int *)(scratch + 192), nullptr, nullptr};
             BdxFilterSet &f1 = ctx->fs[1];
             f1.bplan.d_tile_counter = (int *)(scratch + 256);
+            f1.bplan.dense_w = 0;
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
@@ -1336,6 +1384,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
         ctx->F().bplan.d_tile_counter = (int *)(scratch + 64);
+        ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
         ctx->F().bplan.dbg = ctx->tune.debug;
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,

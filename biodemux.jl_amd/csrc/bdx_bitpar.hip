@@ -71,6 +71,9 @@ struct BitparArgs {
     int known_ok[2];  // config-level eligibility of the known-score class per pass
     int ncode;  // symbol code of 'N' (255 when no barcode contains it)
     int slot_bytes;  // > 0: per-read window slots instead of the flat span copy
+    int slot_cap;    // survivors per read and pass the reducer replay can take (>= 4)
+    int dense_d;     // plain-sweep kernels: byte table of every candidate's d instead of the slots
+    int dense_w;     // plain-sweep kernels, split mode: dense window table wins_out[pass][read][barcode]
     int short_lb[2]; // per pass: the exact kernel only reports score (+ end) through the clean-class DP: its restricted
                      // run may start m + kb columns before the first end column instead of 2 (m + kb) + 1
     // tiered budgets (bdx_abi.cpp): tier 1 appends the reads it cannot settle to tier_list; tier 0 then runs in
@@ -148,7 +151,8 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *wlo = (LDS int *)take((size_t)R * 4);          // first staged base (0-based) of each read
     LDS int *wlen = (LDS int *)take((size_t)R * 4);         // staged bases of each read
     LDS int *win = (LDS int *)take((size_t)R * 4 * 4);      // [pass][first|last][R]
-    LDS uint32_t *slots = (LDS uint32_t *)take((size_t)2 * R * 4 * 4);  // [pass][R][4] (barcode << 8 | d)
+    const int SC = (!SEED && a.dense_d) ? 4 : a.slot_cap;  // survivors per read and pass the reducer replay can take (4; more for short barcodes)
+    LDS uint32_t *slots = (LDS uint32_t *)take((size_t)2 * R * SC * 4);  // [pass][R][SC] (barcode << 8 | d)
     LDS int *scnt = (LDS int *)take((size_t)2 * R * 4);                 // [pass][R] entries pushed
     LDS unsigned char *full = take((size_t)2 * R);                      // [pass][R] read is in the known-score class
     // one staging area: the raw bytes are transcoded IN PLACE to symbol codes; the in-kernel exact
@@ -173,6 +177,9 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     LDS int *wcl = scnt;       // split mode: window entries written per read and pass
     LDS unsigned char *sall = take(SEED ? (size_t)R : 0);
     LDS unsigned char *act = take(!SEED && cfg.is_dual ? (size_t)R : 0);  // plain sweep, dual: reads whose first pass has a candidate
+    // plain sweep, known-score class, few barcodes: d of every (read, barcode) candidate — each pair is swept exactly once
+    const bool dense = !SEED && a.dense_d;
+    LDS unsigned char *dtab = take(dense ? (size_t)R * (B0 + B1) : 0);  // [R][B0] then [R][B1]
     LDS uint32_t *slh = (LDS uint32_t *)take(SEED ? (size_t)R * 4 : 0);  // per read: first | (last + 1) << 16 seed start, relative to the first staged base
     LDS int *srw = (LDS int *)take(SEED ? (size_t)R * 4 : 0);            // per read: stage offset of its first staged base
     // DIAG variant: per-read inverted index of 4-mers (bit p of occ[r][key][.] <=> the 4-mer at staged position p is key)
@@ -465,7 +472,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     };
     // Split mode of the seeded variants: the sweeps themselves record the first / last column whose unit
     // distance is <= kb instead of a second, sparsely populated pass over the survivors.
-    const bool track = SEED && a.split && a.wins_out[0] != nullptr;
+    // dense window table (plain-sweep kernels, few barcodes, many genuine candidates per read): every sweep is tracked
+    // and writes its pair's window to wins_out[pass][read][barcode] (lo + 1024 | hi << 16) — no per-read entry cap
+    const bool dense_w = !SEED && a.dense_w && a.split && a.wins_out[0] != nullptr;
+    const bool track = (SEED || dense_w) && a.split && a.wins_out[0] != nullptr;
     auto step_tracked = [&](Sweep &w, const int j, const int sh) __attribute__((always_inline)) {
         step(w, j, sh);
         const bool in = w.score <= w.kbv;
@@ -473,7 +483,13 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         w.e_hi = in ? j : w.e_hi;
     };
     auto finish = [&](const Sweep &w) __attribute__((always_inline)) {
-        if (track && w.ncol > 0 && w.e_hi >= 0) {
+        if (dense_w && w.ncol > 0 && w.e_hi >= 0) {
+            const int jf_abs = (int)(w.c - (codes + roff[w.r])) + 1;  // 1-based column of sweep column 0
+            const int mm = popw((w.p ? pv1 : pv0)[w.b]);
+            const int lo = jf_abs + w.e_lo - (sg ? (a.short_lb[w.p] ? mm + w.kbv : 2 * (mm + w.kbv) + 1) : mm - 1);
+            (w.p ? a.wins_out[1] : a.wins_out[0])[(long long)rids[w.r] * (w.p ? B1 : B0) + w.b] =
+                (uint32_t)(lo + 1024) | ((uint32_t)(jf_abs + w.e_hi) << 16);
+        } else if (track && w.ncol > 0 && w.e_hi >= 0) {
             const int kk = __hip_atomic_fetch_add(&wcl[w.p * R + w.r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (kk < BDX_WCAP) {
                 const int jf_abs = (int)(w.c - (codes + roff[w.r])) + 1;  // 1-based column of sweep column 0
@@ -493,7 +509,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             if (full[w.p * R + w.r]) {
                 const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (k < 4) slots[(w.p * R + w.r) * 4 + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
+                if (dense)
+                    dtab[(w.p ? R * B0 : 0) + w.r * (w.p ? B1 : B0) + w.b] = (unsigned char)w.best;
+                else if (k < SC)
+                    slots[(w.p * R + w.r) * SC + k] = ((uint32_t)w.b << 8) | (uint32_t)w.best;
             }
         }
     };
@@ -1022,7 +1041,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             for (int p = 0; p < npass; ++p)
                 for (int t = tid; t < nr; t += BS) {
                     const int c = wcl[p * R + t];
-                    a.wcnt_out[p][rids[t]] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
+                    a.wcnt_out[p][rids[t]] = (unsigned char)(dense_w ? ((staged && rlen[t] <= 60000) ? 254 : 255 /* columns beyond 16 bits (a wrong length hint): whole window */) : ((usable && c <= BDX_WCAP) ? c : 255));
                 }
         }
         continue;
@@ -1040,13 +1059,16 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     bool done = false;
     if (active && !BDX_DBG(1)) {
         const int cnt0 = scnt[0 * R + ltid], cnt1 = scnt[1 * R + ltid];
-        bool known = staged && full[0 * R + ltid] && cnt0 <= 4;
-        if (npass > 1) known = known && full[1 * R + ltid] && cnt1 <= 4;
+        bool known = staged && full[0 * R + ltid] && (dense || cnt0 <= SC);
+        if (npass > 1) known = known && full[1 * R + ltid] && (dense || cnt1 <= SC);
         if (known) {
-            const LDS uint32_t *e0 = slots + (0 * R + ltid) * 4;
-            const LDS uint32_t *e1 = slots + (1 * R + ltid) * 4;
-            const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt0};
-            const KnownPass kn1{true, e1[0], e1[1], e1[2], e1[3], cnt1};
+            const LDS uint32_t *e0 = slots + (0 * R + ltid) * SC;
+            const LDS uint32_t *e1 = slots + (1 * R + ltid) * SC;
+            const bool many = cnt0 > 4 || cnt1 > 4;  // (then the replay scans its entries in LDS)
+            const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt0, many ? e0 : nullptr,
+                                dense ? dtab + ltid * B0 : nullptr, cand + ltid * cw0, cw0};
+            const KnownPass kn1{true, e1[0], e1[1], e1[2], e1[3], cnt1, many ? e1 : nullptr,
+                                dense ? dtab + R * B0 + ltid * B1 : nullptr, cand + R * cw0 + ltid * cw1, cw1};
             const auto m0 = [&](const int b) { return popw(pv0[b]); };
             const auto m1 = [&](const int b) { return popw(pv1[b]); };
             classify_known(cfg, m0, m1, rlen[ltid], kn0, kn1, v, p1, p2);
@@ -1195,7 +1217,9 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)bp.ncodes * bp.bpad[0] * wb) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * wb : 0);
     o += al((size_t)B0 * wb) + al((size_t)B1 * wb) + al((size_t)B0 * 4) + al((size_t)B1 * 4);
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 4 * al((size_t)R * 4) + al((size_t)R * 16);
-    o += al((size_t)2 * R * 16) + al((size_t)2 * R * 4) + al((size_t)2 * R);
+    const bool seeded = sp && sp->enabled;
+    const int sc = (!seeded && bp.dense_d) ? 4 : (bp.slot_cap > 4 ? bp.slot_cap : 4);
+    o += al((size_t)2 * R * sc * 4) + al((size_t)2 * R * 4) + al((size_t)2 * R);
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
         const int nw = bp.diag_nw > 0 ? bp.diag_nw : 5;
@@ -1213,6 +1237,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     }
     o += al(32);
     if (!(sp && sp->enabled) && cfg.is_dual) o += al((size_t)R);  // act[]
+    if (!(sp && sp->enabled) && bp.dense_d) o += al((size_t)R * (B0 + B1));  // dtab[]
     return o;
 }
 
@@ -1259,6 +1284,9 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     a.ncodes = bp.ncodes;
     a.dbg = bp.dbg;
     a.slot_bytes = bp.slot_bytes;
+    a.slot_cap = bp.slot_cap > 4 ? bp.slot_cap : 4;
+    a.dense_d = bp.dense_d;
+    a.dense_w = bp.dense_w;
     a.short_lb[0] = bp.short_lb[0];
     a.short_lb[1] = bp.short_lb[1];
     a.ncode = bp.ncode_N;

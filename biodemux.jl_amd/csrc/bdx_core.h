@@ -725,6 +725,46 @@ struct Reducer {
     }
 };
 
+// One candidate through the band bodies of barcode length MM (WIDE17: a 17-diagonal body exists for it).  false: the
+// wave needs the wide body and there is none — the caller takes the all-rows DP.
+template <int MM, bool WIDE17, bool STAGED>
+__device__ __forceinline__ bool band_call(const Bytes<STAGED> q, const Bytes<STAGED> r, AlignOut &a, const bool tbf,
+                                          const bool wide, const int kbb, const int ae, const Costs c, const int trim_side,
+                                          const int jf, const int e_lo, const int e_hi) {
+    if (wide && !WIDE17) return false;
+    // the barcode's bytes, four per word (the barcode tables are word-aligned only by chance)
+    uint32_t QW[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < MM; ++i) QW[i >> 2] |= (uint32_t)q[i] << (8 * (i & 3));
+    const bdx_u32x4 qa = {QW[0], QW[1], QW[2], QW[3]}, qb4 = {QW[4], QW[5], QW[6], QW[7]};
+    const uint32_t costs = (uint32_t)c.match | ((uint32_t)c.mismatch << 8) | ((uint32_t)c.indel << 16) | ((uint32_t)trim_side << 24);
+    uint32_t S[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) S[w] = 0;
+    if (!wide) {
+        constexpr int HH = 9, NS = (MM + HH + 2) / 4 + 1;
+        const int j0 = e_hi + kbb - (MM + HH - 2);
+        uint32_t T[NS];
+        band_fetch<NS, STAGED>(r, j0, T);
+#pragma unroll
+        for (int w = 0; w < NS; ++w) S[w] = T[w];
+        const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
+        a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
+                : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
+    } else if constexpr (WIDE17) {
+        constexpr int HH = 17, NS = (MM + HH + 2) / 4 + 1;
+        const int j0 = e_hi + kbb - (MM + HH - 2);
+        uint32_t T[NS];
+        band_fetch<NS, STAGED>(r, j0, T);
+#pragma unroll
+        for (int w = 0; w < NS; ++w) S[w] = T[w];
+        const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
+        a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
+                : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
+    }
+    return true;
+}
+
 // match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
 // reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
 template <bool STAGED, int REGM = 0, bool CLEAN = false, bool UM = false>
@@ -773,7 +813,11 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         // column restriction of this candidate (split mode hands over up to BDX_WCAP entries
         // {barcode, first column, last column} per read and pass; none -> the whole window)
         int cjlo = -0x40000000, cjhi = 0x40000000;
-        if (wcount <= BDX_WCAP) {
+        if (wcount == 254) {  // dense table: one entry per barcode (plain-sweep kernels, every pair swept once)
+            const uint32_t e = went[b];
+            cjlo = (int)(e & 0xFFFFu) - 1024;
+            cjhi = (int)(e >> 16);
+        } else if (wcount <= BDX_WCAP) {
             // several entries of one barcode (separately swept occurrences) are united
             bool any_entry = false;
             for (int e = 0; e < wcount; ++e)
@@ -800,50 +844,46 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
             } else if (REGM > 0 && CLEAN) {
                 // clean class (see sg_core_clean): same three output forms as below
                 const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
-                if constexpr (UM) {
+                {
                     // diagonal band (sg_core_band): the tracked sweep's end columns are known and the band fits
                     const int pidx = (&P == &cfg.pass[1]) ? 1 : 0;
                     const int kbb = cfg.band_kb[pidx];
                     const int e_lo = cjlo + cfg.band_lb[pidx], e_hi = cjhi;
-                    const int need = kbb >= 0 && wcount <= BDX_WCAP && cjhi < 0x40000000 ? (e_hi - e_lo + 1) + 2 * kbb : 0x7FFF;
+                    const int need = kbb >= 0 && (wcount <= BDX_WCAP || wcount == 254) && cjhi < 0x40000000 ? (e_hi - e_lo + 1) + 2 * kbb : 0x7FFF;
                     if (need <= 17 && n > 0 && cfg.match < 256 && cfg.mismatch < 256 && cfg.indel < 256) {
-                        constexpr int MM = REGM > 0 ? REGM : 4;
-                        // the barcode's bytes, four per word (the barcode tables are word-aligned only by chance)
-                        uint32_t QW[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                        for (int i = 0; i < MM; ++i) QW[i >> 2] |= (uint32_t)q[i] << (8 * (i & 3));
-                        const bdx_u32x4 qa = {QW[0], QW[1], QW[2], QW[3]}, qb4 = {QW[4], QW[5], QW[6], QW[7]};
                         const bool tbf = need_tb && !end_only;
-                        const uint32_t costs = (uint32_t)c.match | ((uint32_t)c.mismatch << 8) | ((uint32_t)c.indel << 16) | ((uint32_t)trim_side << 24);
-                        uint32_t S[16];
-#pragma unroll
-                        for (int w = 0; w < 16; ++w) S[w] = 0;
+                        bool ran = false;
                         // one band width per wave: the straight-line bodies are long, a wave should run only one
-                        if (__builtin_amdgcn_ballot_w64(need > 9) == 0ull) {
-                            constexpr int HH = 9, NS = (MM + HH + 2) / 4 + 1;
-                            const int j0 = e_hi + kbb - (MM + HH - 2);
-                            uint32_t T[NS];
-                            band_fetch<NS, STAGED>(r, j0, T);
-#pragma unroll
-                            for (int w = 0; w < NS; ++w) S[w] = T[w];
-                            const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
-                            a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
-                                    : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
-                        } else if constexpr (MM > 24) {
-                            goto no_band;  // (the 17-diagonal body of 32-row barcodes does not stay in registers)
-                        } else {
-                            constexpr int HH = 17, NS = (MM + HH + 2) / 4 + 1;
-                            const int j0 = e_hi + kbb - (MM + HH - 2);
-                            uint32_t T[NS];
-                            band_fetch<NS, STAGED>(r, j0, T);
-#pragma unroll
-                            for (int w = 0; w < NS; ++w) S[w] = T[w];
-                            const bdx_u32x4 sa = {S[0], S[1], S[2], S[3]}, sb = {S[4], S[5], S[6], S[7]}, sc = {S[8], S[9], S[10], S[11]}, sd = {S[12], S[13], S[14], S[15]};
-                            a = tbf ? sg_core_band<true, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi)
-                                    : sg_core_band<false, MM, HH>(qa, qb4, sa, sb, sc, sd, j0, ae, costs, jf, e_lo, e_hi);
+                        const bool wide = __builtin_amdgcn_ballot_w64(need > 9) != 0ull;
+                        switch (cfg.band_m) {  // (uniform: every barcode of the config has this length)
+                            case 8:
+                                if constexpr (REGM == 24) ran = band_call<8, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 10:
+                                if constexpr (REGM == 24) ran = band_call<10, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 12:
+                                if constexpr (REGM == 24) ran = band_call<12, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 16:
+                                if constexpr (REGM == 24) ran = band_call<16, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 20:
+                                if constexpr (REGM == 24) ran = band_call<20, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 24:
+                                if constexpr (REGM == 24) ran = band_call<24, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            case 32:
+                                if constexpr (REGM == 32) ran = band_call<32, false, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                                break;
+                            default:
+                                break;
                         }
-                        if (!need_tb) a.end = -1;
-                        goto band_done;
+                        if (ran) {
+                            if (!need_tb) a.end = -1;
+                            goto band_done;
+                        }
                     }
                 }
             no_band:
@@ -929,11 +969,70 @@ struct Verdict {
     int bc1, bc2, keep_start, keep_end;
 };
 
+// The same replay over `count` entries in LDS (short barcodes at high rates have many genuine candidates per read:
+// a 10-mer within two edits of a random 150-base read is no rarity).  Selection of the next entry in ascending
+// (barcode << 8 | d) order is a scan per step — count is small (<= 32).
+template <class MLen>
+__device__ __forceinline__ PassOut run_pass_known_ent(const BdxDevCfg &cfg, const MLen mlen, const LDS uint32_t *ent,
+                                                      const int count) {
+    Reducer red;
+    red.init(cfg);
+    uint32_t last = 0;
+    int fed_b = -1;
+    for (int k = 0; k < count; ++k) {
+        uint32_t pick = 0xFFFFFFFFu;
+        for (int t = 0; t < count; ++t) {
+            const uint32_t c = ent[t] + 1u;
+            if (c > last && c < pick) pick = c;
+        }
+        if (pick == 0xFFFFFFFFu) break;
+        last = pick;
+        const uint32_t e = pick - 1u;
+        const int b = (int)(e >> 8);
+        const int d = (int)(e & 255u);
+        if (b == fed_b) continue;
+        fed_b = b;
+        const int m = mlen(b);
+        const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
+        AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};
+        const double score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :155-160
+        red.feed(b, a, score);
+    }
+    return red.finish(cfg);
+}
+
+template <class MLen>
+__device__ __forceinline__ PassOut run_pass_known_dense(const BdxDevCfg &cfg, const MLen mlen, const LDS unsigned char *dt,
+                                                        const LDS uint32_t *cbits, const int cwords) {
+    Reducer red;
+    red.init(cfg);
+    for (int w = 0; w < cwords; ++w) {
+        uint32_t bits = cbits[w];
+        while (bits) {
+            const int b = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const int d = dt[b];
+            const int m = mlen(b);
+            const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
+            AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};
+            const double score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :155-160
+            red.feed(b, a, score);
+        }
+    }
+    return red.finish(cfg);
+}
+
 // Per-pass hand-over from the bit-vector sweep for reads of the known-score class.
 struct KnownPass {
     bool use;
     uint32_t e0, e1, e2, e3;
     int count;
+    const LDS uint32_t *ent;  // != nullptr: the entries live in LDS (count may exceed four: short barcodes, see slot_cap)
+    // dense form (plain-sweep kernels with few barcodes): d of EVERY candidate in a byte table, walked through the
+    // read's candidate mask in ascending barcode (= file) order — any number of survivors, no selection scan
+    const LDS unsigned char *dt;
+    const LDS uint32_t *cbits;
+    int cwords;
 };
 
 template <bool STAGED, int REGM = 0, bool CLEAN = false, bool UM = false>
@@ -1003,13 +1102,17 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
                                                PassOut &p2) {
     v = Verdict{0, 0, -1, -1};
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-    p1 = run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
+    p1 = kn0.dt ? run_pass_known_dense(cfg, m0, kn0.dt, kn0.cbits, kn0.cwords)
+         : kn0.ent ? run_pass_known_ent(cfg, m0, kn0.ent, kn0.count)
+                   : run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
     }
     if (cfg.is_dual) {  // :887-895
-        p2 = run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
+        p2 = kn1.dt ? run_pass_known_dense(cfg, m1, kn1.dt, kn1.cbits, kn1.cwords)
+             : kn1.ent ? run_pass_known_ent(cfg, m1, kn1.ent, kn1.count)
+                       : run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;

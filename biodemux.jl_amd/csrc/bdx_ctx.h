@@ -43,6 +43,7 @@ struct BdxTuning {
     int seed_hash_l2 = 0;  // BDX_SEED_HASH_L2: the piece hash table stays in global memory
     int seed_bm_log2 = 0;  // BDX_SEED_BM_LOG2: size of the seed bitmap (log2 of its bits)
     int no_clean = 0;     // BDX_NO_CLEAN
+    int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP: exact kernel's register DP always in its predicated by-construction form
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_gen
         const uint32_t *c1 = a.cand1 ? a.cand1 + ridx * cfg.pass[1].cand_words : nullptr;
         LDS int *DP = DPbase + tid;
         LDS int *OG = OGbase + tid;
-        const uint32_t *we0 = a.wins[0] ? a.wins[0] + ridx * (BDX_WCAP * 3) : nullptr;
-        const uint32_t *we1 = a.wins[1] ? a.wins[1] + ridx * (BDX_WCAP * 3) : nullptr;
+        const uint32_t *we0 = a.wins[0] ? a.wins[0] + ridx * (cfg.dense_w ? (long long)B0 : (long long)(BDX_WCAP * 3)) : nullptr;
+        const uint32_t *we1 = a.wins[1] ? a.wins[1] + ridx * (cfg.dense_w ? (long long)B1 : (long long)(BDX_WCAP * 3)) : nullptr;
         const int wc0 = a.wcnt[0] ? (int)a.wcnt[0][ridx] : 255;
         const int wc1 = a.wcnt[1] ? (int)a.wcnt[1][ridx] : 255;
         const KnownPass nokn{false, 0, 0, 0, 0, 0};

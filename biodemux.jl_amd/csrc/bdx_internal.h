@@ -62,6 +62,8 @@ struct BdxDevCfg {
     // with both the exact kernel rebuilds [e_lo, e_hi] and runs the diagonal-band DP (sg_core_band).  -1: off.
     int band_kb[2];
     int band_lb[2];
+    int dense_w;       // per launch: the column windows are a dense table wins[pass][read][barcode] (lo + 1024 | hi << 16), wcnt = 254
+    int band_m;        // the common barcode length the band bodies run with (8, 10, 12, 16, 20, 24 or 32)
     BdxDevPass pass[2];
 };
 
@@ -95,6 +97,7 @@ struct BdxGenericPlan {
     int reg_rows;        // 24 / 32: register-resident exact DP (no DP columns in LDS); 0: LDS columns
     int clean;           // register DP in its clean-class form (sg_core_clean): in-domain costs, start / end ranges "1:end"
     int uniform_m;       //   ... and every barcode has exactly reg_rows rows
+    int uniform_len;     //   ... every barcode of the config has this length and band bodies exist for it (else 0)
     int dp_rows;         // generic kernel: max_m + 1, or 1 in register mode
     int dp_rows_fused;   // fused kernel's in-kernel exact stage always keeps LDS columns: max_m + 1
     int stage_bytes;     // LDS bytes reserved for staged read bytes (0 = read from HBM/L2 directly)
@@ -115,6 +118,9 @@ struct BdxBitparPlan {
     int diag_qcap;         //   ... and sweep-queue entries to provide per read
     int read_len_hint_for_lds;  // same value, set before sizing (used for the seed work areas)
     int slot_bytes;        // > 0: window-slot staging (long reads with a short column window)
+    int dense_w;           // per launch: split mode of the plain-sweep kernel hands the column windows over as a dense [read][barcode] table
+    int dense_d;           // known-score class, plain-sweep kernels: byte table of every candidate's d (few barcodes, many genuine candidates)
+    int slot_cap;          // known-score class: survivors per read and pass the replay takes (4 .. 32, from the expected number of genuine candidates)
     int seed_span;         // bases per read the seed scan covers (read length, or the window in slot mode)
     int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 16)

@@ -156,12 +156,13 @@ def random_case_tiers(seed: int, n_reads: int = 1500):
 
 
 def random_case_band(seed: int, n_reads: int = 1500):
-    """The diagonal-band DP's domain (exact stage, clean class, every barcode with 24 or every barcode with 32 bases):
+    """The diagonal-band DP's domain (exact stage, clean class, every barcode of the config with the same 8, 10, 12, 16,
+    20, 24 or 32 bases):
     traceback through trimming or summary, or weighted costs; budgets 0..4 and beyond (fallback), tiers, column
     windows that start inside the read, barcodes hanging over either end of the read, concatemers, low-complexity
     barcodes (wide end-column windows: the 17-diagonal body or the all-rows fallback), dual."""
     rng = np.random.Generator(np.random.PCG64(seed ^ 0xBA9D))
-    m = 24 if rng.random() < 0.7 else 32
+    m = int([24, 24, 24, 32, 32, 8, 10, 12, 16, 20][int(rng.integers(0, 10))])
     B = int(rng.integers(8, 140))
     lowc = rng.random() < 0.15
     if lowc:

@@ -104,7 +104,7 @@ _BAND_RUNS = {"cases": 0, "band": 0}
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_band_vs_oracle(seed):
     """Random configs in the diagonal-band DP's domain (fuzz.random_case_band): traceback or weighted costs, every
-    barcode with 24 or with 32 bases.  With and without per-pass outputs (trim_side 5 without them runs the end-only
+    barcode of the config with the same 8 / 10 / 12 / 16 / 20 / 24 / 32 bases.  With and without per-pass outputs (trim_side 5 without them runs the end-only
     form), and the summary statistics where the config collects them."""
     cfg, seq, off = fuzz.random_case_band(seed, n_reads=1500)
     for want_pass in (True, False):
@@ -123,10 +123,14 @@ def test_fuzz_band_vs_oracle(seed):
 def test_band_dp_equals_the_all_rows_dp(monkeypatch):
     """Same batch through the diagonal-band DP and (BDX_NO_BAND) through the all-rows clean-class DP: every output and
     the device statistics agree, for trim_side 3 / 5 / summary at budgets 2 (9 diagonals) and 4 (17 diagonals)."""
-    bcs = synth.make_barcodes(96, 24)
-    seq, off, _ = synth.make_reads(bcs, 40000, 150, repeat=dict(frac=0.1))
-    for kw in (dict(max_error_rate=0.1, trim_side=3), dict(max_error_rate=0.2, trim_side=5), dict(max_error_rate=0.2, summary=True),
-               dict(max_error_rate=0.17, trim_side=3, min_delta=0.05), dict(max_error_rate=0.2, mismatch=1, indel=2)):
+    for m, kw in ((24, dict(max_error_rate=0.1, trim_side=3)), (24, dict(max_error_rate=0.2, trim_side=5)),
+                  (24, dict(max_error_rate=0.2, summary=True)), (24, dict(max_error_rate=0.17, trim_side=3, min_delta=0.05)),
+                  (24, dict(max_error_rate=0.2, mismatch=1, indel=2)), (10, dict(max_error_rate=0.2, trim_side=3)),
+                  (8, dict(max_error_rate=0.2, summary=True)), (16, dict(max_error_rate=0.2, trim_side=5)),
+                  (20, dict(max_error_rate=0.2, trim_side=3, min_delta=0.05)), (12, dict(max_error_rate=0.17, trim_side=5)),
+                  (32, dict(max_error_rate=0.1, trim_side=3))):
+        bcs = synth.make_barcodes(96, m, seed=400 + m, min_hamming=max(3, m // 4))
+        seq, off, _ = synth.make_reads(bcs, 40000 if m >= 16 else 12000, 150, seed=400 + m, repeat=dict(frac=0.1))
         cfg = _c2_config(bcs, **kw)
         outs = {}
         for band in (True, False):
@@ -146,8 +150,37 @@ def test_band_dp_equals_the_all_rows_dp(monkeypatch):
                         assert np.array_equal(v[p_][name][0], outs[False]["tabs"][p_][name][0]), (kw, name)
             else:
                 assert np.array_equal(v, outs[False][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, outs[False][k]), (kw, k)
+        nall = len(off) - 1
         exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq[:off[5000]], off[:5001])
-        fuzz.assert_same({k: (v[:5000] if v.shape[0] == 40000 else v[:10000]) for k, v in outs[True].items() if k != "tabs"}, exp, str(kw))
+        fuzz.assert_same({k: (v[:5000] if v.shape[0] == nall else v[:10000]) for k, v in outs[True].items() if k != "tabs"}, exp, str(kw))
+
+
+@pytest.mark.parametrize("m,kw", [
+    (8, dict(max_error_rate=0.2)),
+    (8, dict(max_error_rate=0.25, min_delta=0.1)),
+    (10, dict(max_error_rate=0.2)),
+    (10, dict(max_error_rate=0.2, min_delta=0.05)),
+    (12, dict(max_error_rate=0.2)),
+    (12, dict(max_error_rate=0.25, min_delta=0.09)),
+    (16, dict(max_error_rate=0.2)),
+], ids=lambda x: str(x) if isinstance(x, int) else ",".join(f"{k}={v}" for k, v in x.items()))
+def test_short_barcodes_many_genuine_candidates(m, kw):
+    """Short barcodes at the reference's default rate: a read holds MANY genuine candidates (a 10-mer within two edits
+    of a random 150-base read is common), so the reducer replay takes up to 32 survivors per read and pass instead of
+    four.  Every filter mode against the oracle, with and without per-pass outputs, dual as well."""
+    bcs = synth.make_barcodes(96, m, seed=200 + m, min_hamming=3)
+    seq, off, _ = synth.make_ragged_reads(bcs, 20000, 60, 160, seed=200 + m, sub=0.03, ins=0.005, dele=0.005, repeat=dict(frac=0.1))
+    cfg = _c2_config(bcs, **kw)
+    exp = _all_filters_agree(cfg, seq, off)
+    assert (exp["bc1"] > 0).mean() > 0.3
+    with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+        got = hc.classify(seq, off)
+        assert np.array_equal(got["bc1"], exp["bc1"])
+    b2 = synth.make_barcodes(24, m, seed=300 + m, min_hamming=3)
+    s2, o2, _ = synth.make_reads(bcs, 8000, 150, seed=300 + m, plant_lo=0, plant_hi=40, second=(b2, 90, 150 - m))
+    cfgd = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[m] * 96, ids=[f"x{i}" for i in range(96)], is_dual=True,
+                             bc_seqs2=b2, bc_lengths_no_N2=[m] * 24, ids2=[f"y{i}" for i in range(24)], **kw)
+    _all_filters_agree(cfgd, s2, o2)
 
 
 def _c2_config(bcs, **kw):
