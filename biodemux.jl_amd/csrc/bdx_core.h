@@ -765,6 +765,154 @@ __device__ __forceinline__ bool band_call(const Bytes<STAGED> q, const Bytes<STA
     return true;
 }
 
+// band bodies by barcode length (every barcode of the config has cfg.band_m bases); false: no body for this case
+template <bool STAGED, int REGM>
+__device__ __forceinline__ bool band_dispatch(const int band_m, const Bytes<STAGED> q, const Bytes<STAGED> r, AlignOut &a,
+                                              const bool tbf, const bool wide, const int kbb, const int ae, const Costs c,
+                                              const int trim_side, const int jf, const int e_lo, const int e_hi) {
+    switch (band_m) {
+        case 8:
+            if constexpr (REGM == 24) return band_call<8, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 10:
+            if constexpr (REGM == 24) return band_call<10, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 12:
+            if constexpr (REGM == 24) return band_call<12, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 16:
+            if constexpr (REGM == 24) return band_call<16, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 20:
+            if constexpr (REGM == 24) return band_call<20, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 24:
+            if constexpr (REGM == 24) return band_call<24, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        case 32:
+            if constexpr (REGM == 32) return band_call<32, false, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+            break;
+        default:
+            break;
+    }
+    return false;
+}
+
+// One pass of a read with MANY candidates (short barcodes: dense window table, wcount == 254) in the band's domain —
+// clean class, every barcode with the same number of bases m, no N-scoring.  There the reference's reducers are
+// order-independent: an alignment's result does not depend on the tightened threshold beyond being accepted (clean
+// class), all scores share the divisor m, so both reducers (:632-713) end with  min = the smallest raw score (first
+// barcode in file order among ties), sub_min = the second smallest  — whatever the order of evaluation, and a
+// barcode that ties the running sub_min changes nothing whether floor(sub_min * m) lets it through or not.
+// That frees the evaluation order: lane-per-read evaluation in file order makes a wave pay the most expensive body
+// of any of its lanes at EVERY step (one candidate in eight has two hits in the read and a window of many columns);
+// here each lane walks its candidates class by class — 9-diagonal band, 17-diagonal band, then the wide windows in
+// chunks of end columns, each chunk a band of its own (results folded in column order with the recording rule
+// :142-153 and the early exit :420-430; oracle: orc_selftest_band_class, chunked cases) — so a wave runs one body per
+// phase.  The winner and the runner-up are handed to the ordinary Reducer at the end.
+template <bool STAGED, int REGM>
+__device__ __forceinline__ PassOut run_pass_phased(const BdxDevCfg &cfg, const BdxDevPass &P, const int pidx,
+                                                   const Bytes<STAGED> bcb, const LDS uint32_t *bc_off,
+                                                   const Bytes<STAGED> r, const uint32_t *cand, const uint32_t *went,
+                                                   const int jf, const int trim_side, const bool need_tb) {
+    const int m = cfg.band_m;
+    const int kbb = cfg.band_kb[pidx], lb = cfg.band_lb[pidx];
+    const int B = P.n_barcodes;
+    const Costs c{cfg.match, cfg.mismatch, cfg.indel, cfg.nindel, 0x4E};
+    const int ae = (int)__builtin_floor(cfg.max_error_rate * (double)m);  // :254 at the initial threshold
+    const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
+    const bool tbf = need_tb && !end_only;
+    const bool has17 = m <= 24;  // (no 17-diagonal body for 32-row barcodes: their medium windows are walked in chunks)
+    int best_raw = BDX_INF32, best_b = -1, best_s = -1, best_e = -1, sub_raw = BDX_INF32;
+    const auto fold = [&](const int b, const AlignOut &a) {
+        if (a.raw >= BDX_INF32) return;
+        if (a.raw < best_raw || (a.raw == best_raw && b < best_b)) {
+            sub_raw = best_raw < sub_raw ? best_raw : sub_raw;
+            best_raw = a.raw;
+            best_b = b;
+            best_s = a.start;
+            best_e = a.end;
+        } else {
+            sub_raw = a.raw < sub_raw ? a.raw : sub_raw;
+        }
+    };
+    // the lane's candidates of one class, in ascending barcode order
+    struct Cursor { int word; uint32_t bits; };
+    const auto next_of_class = [&](Cursor &cu, const int cls, int &b, int &e_lo, int &e_hi) {
+        for (;;) {
+            while (cu.bits == 0u) {
+                if (++cu.word >= P.cand_words) return false;
+                cu.bits = cand[cu.word];
+            }
+            b = cu.word * 32 + __builtin_ctz(cu.bits);
+            cu.bits &= cu.bits - 1u;
+            if (b >= B) return false;
+            const uint32_t e = went[b];
+            e_lo = (int)(e & 0xFFFFu) - 1024 + lb;
+            e_hi = (int)(e >> 16);
+            const int need = (e_hi - e_lo + 1) + 2 * kbb;
+            const int k = need <= 9 ? 0 : (need <= 17 && has17) ? 1 : 2;
+            if (k == cls) return true;
+        }
+    };
+    for (int cls = 0; cls < 2; ++cls) {
+        Cursor cu{0, cand[0]};
+        for (;;) {
+            int b = 0, e_lo = 0, e_hi = 0;
+            const bool have = next_of_class(cu, cls, b, e_lo, e_hi);
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            if (have) {
+                AlignOut a{BDX_INF32, -1, -1};
+                band_dispatch<STAGED, REGM>(m, bcb.at((int)bc_off[b]), r, a, tbf, cls == 1, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                if (!need_tb) a.end = -1;
+                fold(b, a);
+            }
+        }
+    }
+    {   // wide windows: chunks of end columns
+        const bool wide_body = has17;
+        const int cw = (wide_body ? 17 : 9) - 2 * kbb;  // end columns per chunk (kb <= 4: >= 1)
+        Cursor cu{0, cand[0]};
+        int cur_b = -1, c_lo = 0, cur_hi = -1;
+        AlignOut cur{BDX_INF32, -1, -1};
+        bool stop = false;
+        for (;;) {
+            bool have = cur_b >= 0 && !stop && c_lo <= cur_hi;
+            if (!have) {
+                if (cur_b >= 0) fold(cur_b, cur);
+                cur_b = -1;
+                int b = 0, e_lo = 0, e_hi = 0;
+                if (next_of_class(cu, 2, b, e_lo, e_hi)) {
+                    cur_b = b;
+                    c_lo = e_lo;
+                    cur_hi = e_hi;
+                    cur = AlignOut{BDX_INF32, -1, -1};
+                    stop = false;
+                    have = true;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            if (have) {
+                const int c_hi = c_lo + cw - 1 < cur_hi ? c_lo + cw - 1 : cur_hi;
+                AlignOut a{BDX_INF32, -1, -1};
+                band_dispatch<STAGED, REGM>(m, bcb.at((int)bc_off[cur_b]), r, a, tbf, wide_body, kbb, ae, c, trim_side, jf, c_lo, c_hi);
+                if (a.raw < BDX_INF32) {
+                    if (a.raw < cur.raw || (a.raw == cur.raw && tbf && trim_side == 3 && a.start > cur.start)) cur = a;  // :142-153
+                    if (a.raw == 0 && (!tbf || trim_side == 5)) stop = true;                                             // :420-430
+                }
+                c_lo += cw;
+            }
+        }
+    }
+    Reducer red;
+    red.init(cfg);
+    if (best_b >= 0) {
+        red.feed(best_b, AlignOut{best_raw, best_s, need_tb ? best_e : -1}, (double)best_raw / (double)m);  // :155-168
+        if (sub_raw < BDX_INF32) red.feed(best_b + 1, AlignOut{sub_raw, -1, -1}, (double)sub_raw / (double)m);
+    }
+    return red.finish(cfg);
+}
+
 // match_barcode_pass (classification.jl:776-868, minus the histogram block :827-865) with the
 // reducers find_best_matching_bc_no_delta (:632-667) / _with_delta (:669-713) inlined.
 template <bool STAGED, int REGM = 0, bool CLEAN = false, bool UM = false>
@@ -786,6 +934,13 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 
     const bool align_one = P.explicit_window == BDX_WINDOW_ALIGN_ONE;
     const int B = align_one ? 1 : P.n_barcodes;
+    if constexpr (REGM > 0 && CLEAN) {
+        // many candidates per read (dense window table) inside the band's domain: class-phased evaluation
+        const int pidx0 = (&P == &cfg.pass[1]) ? 1 : 0;
+        if (wcount == 254 && cand && !align_one && n > 0 && cfg.band_m > 0 && cfg.band_kb[pidx0] >= 0 && !cfg.has_nindel &&
+            cfg.algorithm == BDX_ALG_SEMIGLOBAL && cfg.match < 256 && cfg.mismatch < 256 && cfg.indel < 256)
+            return run_pass_phased<STAGED, REGM>(cfg, P, pidx0, bcb, bc_off, r, cand, went, jf, trim_side, need_tb);
+    }
     // :638 / :676 — barcodes in file order, the threshold tightens as we go.  With a candidate
     // mask each lane walks its OWN set bits (ascending = file order), so the lanes of a wave
     // evaluate their k-th candidate together instead of serialising on the barcode index.
@@ -855,31 +1010,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                         bool ran = false;
                         // one band width per wave: the straight-line bodies are long, a wave should run only one
                         const bool wide = __builtin_amdgcn_ballot_w64(need > 9) != 0ull;
-                        switch (cfg.band_m) {  // (uniform: every barcode of the config has this length)
-                            case 8:
-                                if constexpr (REGM == 24) ran = band_call<8, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 10:
-                                if constexpr (REGM == 24) ran = band_call<10, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 12:
-                                if constexpr (REGM == 24) ran = band_call<12, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 16:
-                                if constexpr (REGM == 24) ran = band_call<16, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 20:
-                                if constexpr (REGM == 24) ran = band_call<20, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 24:
-                                if constexpr (REGM == 24) ran = band_call<24, true, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            case 32:
-                                if constexpr (REGM == 32) ran = band_call<32, false, STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
-                                break;
-                            default:
-                                break;
-                        }
+                        ran = band_dispatch<STAGED, REGM>(cfg.band_m, q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
                         if (ran) {
                             if (!need_tb) a.end = -1;
                             goto band_done;

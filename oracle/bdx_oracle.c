@@ -1399,7 +1399,7 @@ static orc_align_t band_dp(const uint8_t *q0, int64_t m, const uint8_t *r0, int6
 }
 
 int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL; no mismatch: [1..3] = cases compared exactly, of those with traceback, of those with the band crossing the first column */) {
-    int64_t n_exact = 0, n_tb = 0, n_edge = 0;
+    int64_t n_exact = 0, n_tb = 0, n_edge = 0, n_chunked = 0;
     static const char AL[6] = "ACGTN";
     static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
     uint8_t q[40], r[260];
@@ -1449,6 +1449,29 @@ int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad
         int64_t H = (e_hi - e_lo + 1) + 2 * kb + (int64_t)(st_next(&s) % 4);
         if (H > 40) continue; /* (the kernel falls back to the all-rows DP) */
         orc_align_t got = band_dp(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, e_lo, e_hi, kb, H);
+        if ((st_next(&s) % 2) == 0 && e_hi > e_lo) {
+            /* a wide window walked in chunks of end columns (the kernel's third phase): every chunk is a band of its own,
+             * the chunk results are folded in ascending column order with the recording rule (:142-153) and the early
+             * exit on a zero (:420-430) */
+            const int64_t cw = 1 + (int64_t)(st_next(&s) % (uint64_t)(e_hi - e_lo + 1));
+            const int tb = mode == ORC_OUT_TRACEBACK;
+            orc_align_t acc = {INFINITY, INF_INT, -1, -1};
+            int have = 0;
+            for (int64_t c_lo = e_lo; c_lo <= e_hi; c_lo += cw) {
+                const int64_t c_hi = c_lo + cw - 1 < e_hi ? c_lo + cw - 1 : e_hi;
+                orc_align_t part = band_dp(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, c_lo, c_hi, kb,
+                                           cw + 2 * kb + (int64_t)(st_next(&s) % 3));
+                if (part.raw >= INF_INT) continue;
+                if (!have || part.raw < acc.raw || (part.raw == acc.raw && tb && trim == 3 && part.start > acc.start)) {
+                    acc = part;
+                    have = 1;
+                }
+                if (part.raw == 0 && (!tb || trim == 5)) break;
+            }
+            if (have) got = acc;
+            else got.raw = INF_INT, got.start = -1, got.end = -1;
+            n_chunked++;
+        }
         const int64_t ops_bound = kb * cmin;
         int wrong;
         if (full.raw <= ops_bound) wrong = got.raw != full.raw || (mode && (got.end != full.end || got.start != full.start));
@@ -1468,6 +1491,7 @@ int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad
         first_bad[1] = n_exact;
         first_bad[2] = n_tb;
         first_bad[3] = n_edge;
+        first_bad[4] = n_chunked;
     }
     return bad;
 }
