@@ -961,3 +961,40 @@ def test_stress_shapes(name):
         assert path.startswith(TIER)
     if name == "min_delta_beyond_an_unseen_barcode":  # tier 1 could prove nothing: it is not built
         assert not path.startswith(TIER) and "bitpar" in path
+
+
+def test_concurrent_contexts_on_os_threads():
+    """SURVEY §8(b) threading: worker tasks call the boundary concurrently, each with its own context
+    (core.jl:587-599).  Four OS threads (ctypes releases the GIL inside the library), four different configs, several
+    batches each, every result against the oracle."""
+    import threading
+    bcs = synth.make_barcodes(96, 24)
+    b16 = synth.make_barcodes(40, 16, seed=77, min_hamming=5)
+    jobs = [
+        (_c2_config(bcs), synth.make_reads(bcs, 30000, 150, seed=501)[:2]),
+        (_c2_config(bcs, max_error_rate=0.2, trim_side=3), synth.make_reads(bcs, 20000, 150, seed=502)[:2]),
+        (_c2_config(bcs, max_error_rate=0.2, summary=True, min_delta=0.05), synth.make_reads(bcs, 20000, 150, seed=503)[:2]),
+        (_c2_config(b16, max_error_rate=0.2, trim_side=5), synth.make_ragged_reads(b16, 20000, 60, 200, seed=504)[:2]),
+    ]
+    expected = [H.orc.OracleClassifier(cfg, nthreads=8).classify(seq, off) for cfg, (seq, off) in jobs]
+    errors = []
+    barrier = threading.Barrier(len(jobs))
+
+    def work(k):
+        try:
+            cfg, (seq, off) = jobs[k]
+            with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+                barrier.wait(timeout=60)
+                for rep in range(4):
+                    got = hc.classify(seq, off)
+                    fuzz.assert_same(got, expected[k], f"thread {k} repetition {rep} [{hc.kernel_path}]")
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
