@@ -45,6 +45,7 @@ BdxTuning read_tuning() {
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
     t.no_dense = getenv("BDX_NO_DENSE") != nullptr;
+    if (const char *e = getenv("BDX_TIER_Q")) t.tier_q = atoi(e);
     t.no_window_upload = getenv("BDX_NO_WINDOW_UPLOAD") != nullptr;
     t.seed_hash_l2 = getenv("BDX_SEED_HASH_L2") != nullptr;
     if (const char *e = getenv("BDX_SEED_BM_LOG2")) t.seed_bm_log2 = atoi(e);
@@ -146,7 +147,8 @@ int plan_generic(bdx_ctx *ctx) {
 // barcode, or with one beyond kb1 — are filtered again at the full budget (tier 0, in list mode).
 long long tier_cap(const bdx_ctx *ctx, int m) {
     if (ctx->cur == 0) return (1LL << 40);
-    const int c = m / 8 - 1;
+    const int q = ctx->tier_q >= 5 && ctx->tier_q <= 8 ? ctx->tier_q : 8;
+    const int c = m / q - 1;
     return c > 0 ? c : 0;
 }
 
@@ -1116,6 +1118,48 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
                     if (config->pass[k].bc_bytes[i] == 'N') plain_windows = false;
         }
         if (full.bplan.enabled && plain_windows && !strict_full && !ctx->tune.no_tier && config->filter == BDX_FILTER_AUTO) {
+            // Piece length behind tier 1's capped budgets, cap(m) = m / q - 1: 8-base seeds are the most selective; 7- or
+            // 6-base pieces raise the cap of some lengths by one (14-15 and 21-23 bases with q = 7, 12-13 with q = 6), so
+            // that tier 1 settles reads with one more error and tier 0 — a plain sweep or the two-intact-pieces kernel —
+            // sees far fewer reads (m = 14, B = 96, rate 0.2: 444 -> 724 M reads/s), as long as the chance hits per
+            // read stay few and no cap goes beyond 2 (measured: caps of 3 — m = 24 with q = 6, m = 28 with q = 7 — cost
+            // more in tier 1 than they save in tier 0, at 24 and at 96 barcodes).
+            {
+                int cmin = 1;
+                if (config->algorithm == BDX_ALG_SEMIGLOBAL) {
+                    cmin = config->mismatch < config->indel ? config->mismatch : config->indel;
+                    if (config->has_nindel && config->nindel < cmin) cmin = config->nindel;
+                    if (cmin < 1) cmin = 1;
+                }
+                long long best_caps = -1;
+                int best_q = 8;
+                const double limit[9] = {0, 0, 0, 0, 0, 0, 8.0, 4.0, 1e30};
+                for (int q = 8; q >= 6; --q) {
+                    long long caps = 0, pieces = 0, cap_max = 0;
+                    for (int k = 0; k < (config->is_dual ? 2 : 1); ++k)
+                        for (int b = 0; b < config->pass[k].n_barcodes; ++b) {
+                            const int m = (int)(config->pass[k].bc_off[b + 1] - config->pass[k].bc_off[b]);
+                            const double norm = (config->algorithm == BDX_ALG_SEMIGLOBAL && config->has_nindel) ? (double)config->pass[k].bc_len_no_N[b] : (double)m;
+                            const long long ae = config->algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(config->max_error_rate * norm);
+                            if (ae < 0) continue;
+                            long long cap = m / q - 1;
+                            if (cap < 0) cap = 0;
+                            if (cap > ae / cmin) cap = ae / cmin;
+                            caps += cap;
+                            pieces += cap + 1;
+                            if (cap > cap_max) cap_max = cap;
+                        }
+                    const double chance = 150.0 * (double)pieces / std::pow(4.0, (double)q);
+                    // a cap lifted from 0 to 1 pays at once, 1 -> 2 a little, 2 -> 3 never did (measured, B = 24 and 96)
+                    if (q < 8 && cap_max > (q == 6 ? 1 : 2)) continue;
+                    if (chance <= limit[q] && caps > best_caps) {
+                        best_caps = caps;
+                        best_q = q;
+                    }
+                }
+                ctx->tier_q = best_q;
+            }
+            if (ctx->tune.tier_q >= 5 && ctx->tune.tier_q <= 8) ctx->tier_q = ctx->tune.tier_q;
             ctx->cur = 1;
             rc = build_bitpar_tables(ctx);
             if (rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped) {
@@ -1123,7 +1167,7 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
                 // very many barcodes: moderately selective 8-base seeds (a dozen chance pairs per read) still beat
                 // the full-budget filter by far
                 if (rc == BDX_OK && !ctx->fs[1].splan.enabled) rc = build_seed_tables(ctx, false);
-                if (rc == BDX_OK && ctx->fs[1].splan.enabled && ctx->fs[1].splan.q < 8) ctx->fs[1].splan.enabled = 0;
+                if (rc == BDX_OK && ctx->fs[1].splan.enabled && ctx->fs[1].splan.q < ctx->tier_q) ctx->fs[1].splan.enabled = 0;
             }
             ctx->cur = 0;
             if (rc != BDX_OK) return bail(rc);

@@ -43,6 +43,7 @@ struct BdxTuning {
     int seed_hash_l2 = 0;  // BDX_SEED_HASH_L2: the piece hash table stays in global memory
     int seed_bm_log2 = 0;  // BDX_SEED_BM_LOG2: size of the seed bitmap (log2 of its bits)
     int no_clean = 0;     // BDX_NO_CLEAN
+    int tier_q = 0;       // BDX_TIER_Q: piece length (5..8) the capped budgets of tier 1 are derived from (default: chosen per config)
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP: exact kernel's register DP always in its predicated by-construction form
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
@@ -89,6 +90,7 @@ struct bdx_ctx {
     // window upload (host entry point, long reads with short column windows): per-read true lengths / window starts
     DevBuf d_vlen, d_vlo;
     int virt_maxlen = 0;     // > 0 while a window-upload batch is being classified: its longest read
+    int tier_q = 8;          // piece length behind tier 1's capped budgets: cap(m) = m / tier_q - 1
     int64_t window_uploads = 0;
     int64_t band_launches = 0;  // (pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled
     std::vector<uint8_t> h_win;    // host staging of the compacted windows
