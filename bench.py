@@ -312,6 +312,12 @@ def main():
                         valu = (valu or []) + [{
                             "kernel": kname, "launches_per_step": e.get("meta", {}).get("dispatches_per_step"),
                             "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
+                            # SIMD cycles per issued VALU wave-instruction (SQ_BUSY_CYCLES: 32 counter instances, 1024
+                            # SIMDs); the pipe's limit for this instruction mix is ~3.2 (tools/ubench_valu.hip: 2.6-2.8
+                            # for v_and/or/xor/add and 3-source v_bitop3, 3.9-4.4 for shifts, v_add3, carries)
+                            "simd_cycles_per_valu_instr": (round(c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0 / c["SQ_INSTS_VALU"], 2)
+                                                           if c.get("SQ_BUSY_CYCLES") else None),
+                            "valu_ceiling_cycles_per_instr": 3.2,
                             "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}]
                 if src:
                     traffic, traffic_src = tot, f"profiles/{tagged[-1]} ({' + '.join(src)})"
