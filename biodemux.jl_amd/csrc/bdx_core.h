@@ -934,8 +934,10 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 
     const bool align_one = P.explicit_window == BDX_WINDOW_ALIGN_ONE;
     const int B = align_one ? 1 : P.n_barcodes;
-    if constexpr (REGM > 0 && CLEAN) {
-        // many candidates per read (dense window table) inside the band's domain: class-phased evaluation
+    if constexpr (REGM > 0 && CLEAN && !UM) {
+        // many candidates per read (dense window table) inside the band's domain: class-phased evaluation.  (Not in the
+        // kernels whose barcodes all have REGM rows: 24- and 32-base barcodes never have that many genuine candidates,
+        // and the extra code costs the ordinary path registers — C4 853 -> 814 M reads/s with it.)
         const int pidx0 = (&P == &cfg.pass[1]) ? 1 : 0;
         if (wcount == 254 && cand && !align_one && n > 0 && cfg.band_m > 0 && cfg.band_kb[pidx0] >= 0 && !cfg.has_nindel &&
             cfg.algorithm == BDX_ALG_SEMIGLOBAL && cfg.match < 256 && cfg.mismatch < 256 && cfg.indel < 256)
@@ -1010,7 +1012,10 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                         bool ran = false;
                         // one band width per wave: the straight-line bodies are long, a wave should run only one
                         const bool wide = __builtin_amdgcn_ballot_w64(need > 9) != 0ull;
-                        ran = band_dispatch<STAGED, REGM>(cfg.band_m, q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                        if constexpr (UM)  // (every barcode has REGM rows: one body set, no dispatch)
+                            ran = band_call<(REGM > 0 ? REGM : 4), (REGM <= 24), STAGED>(q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
+                        else
+                            ran = band_dispatch<STAGED, REGM>(cfg.band_m, q, r, a, tbf, wide, kbb, ae, c, trim_side, jf, e_lo, e_hi);
                         if (ran) {
                             if (!need_tb) a.end = -1;
                             goto band_done;
