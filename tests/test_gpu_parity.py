@@ -998,3 +998,26 @@ def test_concurrent_contexts_on_os_threads():
         t.join(timeout=300)
     assert not errors, errors
     assert not any(t.is_alive() for t in threads)
+
+
+@pytest.mark.parametrize("kw", [dict(max_error_rate=0.2), dict(max_error_rate=0.2, trim_side=3), dict(max_error_rate=0.2, summary=True, min_delta=0.05),
+                                dict(max_error_rate=0.25, trim_side=5, mismatch=1, indel=2)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_dense_tables_change_nothing(kw, monkeypatch):
+    """Short barcodes: the dense d / window tables and the class-phased exact stage against the four-entry forms
+    (BDX_NO_DENSE) on the same batch — every output identical, and both equal to the oracle."""
+    bcs = synth.make_barcodes(96, 10, seed=610, min_hamming=3)
+    seq, off, _ = synth.make_ragged_reads(bcs, 15000, 40, 160, seed=611, sub=0.03, ins=0.005, dele=0.005, repeat=dict(frac=0.1))
+    cfg = _c2_config(bcs, **kw)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
+    outs = {}
+    for dense in (True, False):
+        if dense:
+            monkeypatch.delenv("BDX_NO_DENSE", raising=False)
+        else:
+            monkeypatch.setenv("BDX_NO_DENSE", "1")
+        with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+            outs[dense] = hc.classify(seq, off)
+            fuzz.assert_same(outs[dense], exp, f"dense tables {dense} {kw} [{hc.kernel_path}]")
+    for k, v in outs[True].items():
+        assert np.array_equal(v, outs[False][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, outs[False][k]), k
