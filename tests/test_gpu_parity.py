@@ -1021,3 +1021,26 @@ def test_dense_tables_change_nothing(kw, monkeypatch):
             fuzz.assert_same(outs[dense], exp, f"dense tables {dense} {kw} [{hc.kernel_path}]")
     for k, v in outs[True].items():
         assert np.array_equal(v, outs[False][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, outs[False][k]), k
+
+
+def test_dense_windows_with_reads_beyond_16_bit_columns():
+    """The dense window table packs columns into 16 bits; a read longer than that (here hidden behind a wrong length
+    hint) must fall back to the whole-window DP for itself — results still exact."""
+    bcs = synth.make_barcodes(96, 10, seed=620, min_hamming=3)
+    seq0, off0, _ = synth.make_reads(bcs, 3000, 150, seed=621)
+    reads = [seq0[off0[i]:off0[i + 1]].tobytes().decode() for i in range(3000)]
+    rng = np.random.Generator(np.random.PCG64(622))
+    for k, at in enumerate((70, 1500, 2999)):
+        big = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=66000 + 1000 * k))
+        pos = 64000 + 300 * k  # a barcode far beyond column 60000
+        big = big[:pos] + bcs[7 * k] + big[pos + 10:]
+        reads[at] = big
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(max_error_rate=0.2, trim_side=3), dict(max_error_rate=0.2)):
+        cfg = _c2_config(bcs, **kw)
+        exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
+        for hint in (150, None):
+            with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+                if hint:
+                    hc.set_read_length_hint(hint)
+                fuzz.assert_same(hc.classify(seq, off), exp, f"{kw} hint {hint} [{hc.kernel_path}]")
