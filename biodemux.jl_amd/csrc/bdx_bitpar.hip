@@ -90,6 +90,11 @@ struct BitparArgs {
 };
 
 // The product library has no phase-skip switches: BDX_DBG folds to 0 and the branches disappear.
+// reads indexed at a time by the two-intact-pieces variant (5 KiB of index each).  4 instead of 8 gives a fourth
+// workgroup per CU in list mode: measured +3 % on C2d, +6 % at 384 barcodes, -3.5 % at 96 barcodes on small batches
+#ifndef BDX_DIAG_SB_NARROW
+#define BDX_DIAG_SB_NARROW 8
+#endif
 #ifdef BDX_TUNING
 #define BDX_DBG(bit) (a.dbg & (bit))
 #else
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     const auto popw = [](const WT x) __attribute__((always_inline)) { return W64 ? (int)__builtin_popcountll((unsigned long long)x) : (int)__builtin_popcount((uint32_t)x); };
     constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
     // NW (DIAG): position words per 4-mer key: 5 for reads of <= 152 staged bases, 10 for <= 312
-    constexpr int SBMAX = NW <= 5 ? 8 : 4;           // 40 KiB of index either way
+    constexpr int SBMAX = NW <= 5 ? BDX_DIAG_SB_NARROW : 4;  // index sub-batch: SBMAX x 5 KiB (NW = 5) or x 10 KiB
     constexpr int SB = DIAG ? (R < SBMAX ? R : SBMAX) : R;  // DIAG: reads indexed at a time (5 KiB of index each); larger tiles are walked in sub-batches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
@@ -1223,7 +1228,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     o += al((size_t)bp.stage_bytes + 16);
     if (sp && sp->enabled && sp->diag) {
         const int nw = bp.diag_nw > 0 ? bp.diag_nw : 5;
-        const int sbmax = nw <= 5 ? 8 : 4;
+        const int sbmax = nw <= 5 ? BDX_DIAG_SB_NARROW : 4;
         const int SBh = R < sbmax ? R : sbmax;  // index sub-batch (see the kernel)
         o += al((size_t)(bp.stage_bytes >> 2) + 32) + al((size_t)2 * (bp.diag_qcap > 0 ? bp.diag_qcap : 64) * SBh * 4);
         o += al((size_t)R) + 2 * al((size_t)R * 4);
