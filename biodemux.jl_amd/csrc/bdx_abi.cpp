@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bdx_ctx.h"
@@ -1007,26 +1008,54 @@ static int classify_host_windows(bdx_ctx *ctx, const uint8_t *seq_bytes, const i
     ctx->h_coff.resize(n + 1);
     ctx->h_vlen.resize(n);
     ctx->h_vlo.resize(n);
-    int64_t wbytes = 0;
+    // two passes over the reads, both on a few host threads (the gather touches one cache line or two of every
+    // 10 kbp read: latency-bound on one core): windows, a serial prefix sum of their sizes, gather
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthr = n < 65536 ? 1 : (hw >= 8 ? 8 : (hw >= 2 ? hw : 1));
+    const auto parallel = [&](const auto &body) {
+        if (nthr == 1) {
+            body((size_t)0, n, (size_t)0);
+            return;
+        }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthr; ++t) th.emplace_back([&, t]() { body(n * t / nthr, n * (t + 1) / nthr, t); });
+        for (std::thread &x : th) x.join();
+    };
+    std::vector<long long> t_max(nthr, 0);
+    std::vector<int> t_bad(nthr, 0);
+    parallel([&](const size_t i0, const size_t i1, const size_t t) {
+        long long mx = 0;
+        for (size_t i = i0; i < i1; ++i) {
+            const long long len = seq_off[i + 1] - seq_off[i];
+            if (len < 0) {
+                t_bad[t] = 1;
+                return;
+            }
+            long long ulo, uhi;
+            host_union_window(ctx->dev, len, ulo, uhi);
+            ctx->h_coff[i + 1] = uhi - ulo;  // (sizes now, offsets after the prefix sum)
+            ctx->h_vlen[i] = (int32_t)(len > (1LL << 30) ? (1LL << 30) : len);
+            ctx->h_vlo[i] = (int32_t)ulo;
+            if (len > mx) mx = len;
+        }
+        t_max[t] = mx;
+    });
     long long maxlen = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const long long len = seq_off[i + 1] - seq_off[i];
-        if (len < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
-        long long ulo, uhi;
-        host_union_window(ctx->dev, len, ulo, uhi);
-        ctx->h_coff[i] = wbytes;
-        ctx->h_vlen[i] = (int32_t)(len > (1LL << 30) ? (1LL << 30) : len);
-        ctx->h_vlo[i] = (int32_t)ulo;
-        wbytes += uhi - ulo;
-        if (len > maxlen) maxlen = len;
+    for (size_t t = 0; t < nthr; ++t) {
+        if (t_bad[t]) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
+        if (t_max[t] > maxlen) maxlen = t_max[t];
     }
-    ctx->h_coff[n] = wbytes;
+    ctx->h_coff[0] = 0;
+    for (size_t i = 0; i < n; ++i) ctx->h_coff[i + 1] += ctx->h_coff[i];
+    const int64_t wbytes = ctx->h_coff[n];
     if (wbytes * 2 + (int64_t)n_reads * 16 > total) return 1;  // the windows are most of the reads anyway
     ctx->h_win.resize((size_t)wbytes + 64);
-    for (size_t i = 0; i < n; ++i) {
-        const int64_t len_w = ctx->h_coff[i + 1] - ctx->h_coff[i];
-        if (len_w > 0) memcpy(ctx->h_win.data() + ctx->h_coff[i], seq_bytes + seq_off[i] + ctx->h_vlo[i], (size_t)len_w);
-    }
+    parallel([&](const size_t i0, const size_t i1, const size_t) {
+        for (size_t i = i0; i < i1; ++i) {
+            const int64_t len_w = ctx->h_coff[i + 1] - ctx->h_coff[i];
+            if (len_w > 0) memcpy(ctx->h_win.data() + ctx->h_coff[i], seq_bytes + seq_off[i] + ctx->h_vlo[i], (size_t)len_w);
+        }
+    });
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)wbytes + 64));
     HIP_TRY(ctx, ctx->d_off.ensure((n + 1) * 8));
     HIP_TRY(ctx, ctx->d_vlen.ensure(n * 4));
