@@ -936,6 +936,28 @@ static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d
         if (!h || !dv) return hipSuccess;
         return hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, ctx->stream);
     };
+    // Small batches (the reference hands over chunks of 4000 reads, core.jl:5-10): the four verdict vectors sit side
+    // by side on the device — ONE copy into a page-locked staging buffer and four host memcpys instead of four
+    // pageable copies with their fixed cost each.
+    const bool one_copy = n <= (size_t)(256 * 1024) && !out->pass_start && !out->pass_end && !out->pass_raw && !out->pass_bc &&
+                          !out->pass_score && !out->pass_delta;
+    if (one_copy) {
+        if (ctx->h_stage_bytes < n * 16) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_bytes = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_stage, n * 16 + 4096, hipHostMallocDefault));
+            ctx->h_stage_bytes = n * 16 + 4096;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage, bi, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int32_t *hs = (const int32_t *)ctx->h_stage;
+        if (out->bc1) memcpy(out->bc1, hs, n * 4);
+        if (out->bc2) memcpy(out->bc2, hs + n, n * 4);
+        if (out->keep_start) memcpy(out->keep_start, hs + 2 * n, n * 4);
+        if (out->keep_end) memcpy(out->keep_end, hs + 3 * n, n * 4);
+        return BDX_OK;
+    }
     HIP_TRY(ctx, back(out->bc1, d.bc1, n * 4));
     HIP_TRY(ctx, back(out->bc2, d.bc2, n * 4));
     HIP_TRY(ctx, back(out->keep_start, d.keep_start, n * 4));
@@ -1262,6 +1284,10 @@ void bdx_destroy(bdx_ctx *ctx) {
     ctx->d_out_f64.release();
     ctx->d_vlen.release();
     ctx->d_vlo.release();
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    ctx->h_in = nullptr;
     bdx_comm_release(ctx);
     ctx->counts_sum.release();
     for (int p = 0; p < 2; ++p)
@@ -1312,8 +1338,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
     BdxDevStats st{};
     const BdxDevStats *stp = nullptr;
     int measured_len = -1;
-    if (ctx->dev.need_traceback && ctx->virt_maxlen > 0) {
+    if (ctx->virt_maxlen > 0) {
         measured_len = ctx->virt_maxlen;  // window upload: the host has seen every length
+    } else if (ctx->host_maxlen > 0) {
+        measured_len = ctx->host_maxlen;  // host entry point: the offsets were on the host anyway
     } else if (ctx->dev.need_traceback) {
         // statistics tables are sized from the batch's true maximum read length (a hint is only a hint)
         HIP_TRY(ctx, ctx->d_maxlen.ensure(1024));
@@ -1515,6 +1543,39 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
         // 10 kbp reads with "1:200" move 212 B per read over PCIe instead of 10 KB.
         int rcw = classify_host_windows(ctx, seq_bytes, seq_off, n_reads, out);
         if (rcw != 1) return rcw;  // 0 done, < 0 error, 1: ordinary upload below
+    }
+    // The batch's longest read, for the launch plan and the statistics tables: the offsets are on the host anyway
+    // (saves the device-side measurement — a tiny kernel, a 4-byte copy and a stream synchronisation per call, which
+    // matters at the reference's chunk size of 4000 reads)
+    if (n_reads <= 262144) {  // (large batches: the device-side measurement is cheaper than a pass over the offsets)
+        int64_t mx = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            const int64_t d = seq_off[i + 1] - seq_off[i];
+            if (d < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
+            mx = d > mx ? d : mx;
+        }
+        ctx->host_maxlen = (int)(mx > (1LL << 30) ? (1LL << 30) : (mx < 1 ? 1 : mx));
+    }
+    struct HostLenReset {
+        bdx_ctx *c;
+        ~HostLenReset() { c->host_maxlen = 0; }
+    } host_len_reset{ctx};
+    if ((size_t)total + (size_t)(n_reads + 1) * 8 <= ((size_t)2 << 20)) {  // (beyond ~2 MB the extra host copy costs more than the second transfer)
+        // small batches: bytes and offsets through ONE page-locked staging buffer and ONE asynchronous copy
+        const size_t o_off = ((size_t)total + 64 + 255) & ~(size_t)255;
+        const size_t bytes = o_off + (size_t)(n_reads + 1) * 8;
+        if (ctx->h_in_bytes < bytes) {
+            if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+            ctx->h_in = nullptr;
+            ctx->h_in_bytes = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_in, bytes + (1 << 16), hipHostMallocDefault));
+            ctx->h_in_bytes = bytes + (1 << 16);
+        }
+        memcpy(ctx->h_in, seq_bytes + base, (size_t)total);
+        memcpy((char *)ctx->h_in + o_off, seq_off, (size_t)(n_reads + 1) * 8);
+        HIP_TRY(ctx, ctx->d_seq.ensure(bytes + 64));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_seq.p, ctx->h_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off), n_reads, out);
     }
     // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));

@@ -91,6 +91,11 @@ struct bdx_ctx {
     DevBuf d_vlen, d_vlo;
     int virt_maxlen = 0;     // > 0 while a window-upload batch is being classified: its longest read
     int tier_q = 8;          // piece length behind tier 1's capped budgets: cap(m) = m / tier_q - 1
+    int host_maxlen = 0;     // > 0 while bdx_classify_host runs an ordinary batch: its longest read (seen on the host)
+    void *h_stage = nullptr;  // page-locked staging for the verdict vectors of small batches
+    size_t h_stage_bytes = 0;
+    void *h_in = nullptr;     // page-locked staging for the bytes + offsets of small batches
+    size_t h_in_bytes = 0;
     int64_t window_uploads = 0;
     int64_t band_launches = 0;  // (pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled
     std::vector<uint8_t> h_win;    // host staging of the compacted windows
