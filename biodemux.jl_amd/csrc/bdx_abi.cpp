@@ -913,9 +913,39 @@ int init_stats(bdx_ctx *ctx) {
 
 
 // ---- host entry point: shared tail (device outputs, launch, download) and the window upload ----------
-static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d_off, int64_t n_reads, const bdx_outputs_t *out) {
+static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d_off, int64_t n_reads, const bdx_outputs_t *out,
+                            const bool mapped_outputs = false) {
     // int32 outputs: bc1 bc2 keep_start keep_end (n each), pass_start pass_end pass_raw pass_bc (2n each)
     const size_t n = (size_t)n_reads;
+    if (mapped_outputs && n <= (size_t)(256 * 1024) && !out->pass_start && !out->pass_end && !out->pass_raw && !out->pass_bc &&
+        !out->pass_score && !out->pass_delta) {
+        // small batches: the kernels write the four verdict vectors straight into page-locked host memory (posted
+        // writes over PCIe, 16 bytes per read) — no device-to-host copy call at all
+        if (ctx->h_stage_bytes < n * 16) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_bytes = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->h_stage, n * 16 + 4096, hipHostMallocDefault));
+            ctx->h_stage_bytes = n * 16 + 4096;
+        }
+        void *hs_dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&hs_dev, ctx->h_stage, 0));
+        int32_t *bm = (int32_t *)hs_dev;
+        bdx_outputs_t dm{};
+        dm.bc1 = bm;
+        dm.bc2 = out->bc2 ? bm + n : nullptr;
+        dm.keep_start = out->keep_start ? bm + 2 * n : nullptr;
+        dm.keep_end = out->keep_end ? bm + 3 * n : nullptr;
+        int rcm = bdx_classify_device(ctx, d_seq, d_off, n_reads, &dm);
+        if (rcm != BDX_OK) return rcm;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int32_t *hs = (const int32_t *)ctx->h_stage;
+        if (out->bc1) memcpy(out->bc1, hs, n * 4);
+        if (out->bc2) memcpy(out->bc2, hs + n, n * 4);
+        if (out->keep_start) memcpy(out->keep_start, hs + 2 * n, n * 4);
+        if (out->keep_end) memcpy(out->keep_end, hs + 3 * n, n * 4);
+        return BDX_OK;
+    }
     HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
     HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
     int32_t *bi = (int32_t *)ctx->d_out_i32.p;
@@ -1574,8 +1604,11 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
         memcpy(ctx->h_in, seq_bytes + base, (size_t)total);
         memcpy((char *)ctx->h_in + o_off, seq_off, (size_t)(n_reads + 1) * 8);
         HIP_TRY(ctx, ctx->d_seq.ensure(bytes + 64));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_seq.p, ctx->h_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off), n_reads, out);
+        void *h_in_dev = nullptr;  // the staging buffer as the device sees it
+        HIP_TRY(ctx, hipHostGetDevicePointer(&h_in_dev, ctx->h_in, 0));
+        HIP_TRY(ctx, bdx_launch_copy(ctx->d_seq.p, h_in_dev, bytes, ctx->stream));
+        return run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off), n_reads, out,
+                                /*mapped_outputs=*/true);
     }
     // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));

@@ -318,6 +318,26 @@ __global__ void bdx_maxlen_kernel(const long long *off, long long n, int *out) {
 }
 }  // namespace
 
+namespace {
+// page-locked host memory -> device memory, 16 bytes per lane and trip.  The host entry point uses it for small
+// batches instead of hipMemcpyAsync: copies of a few hundred KB through the copy engines cost ~35 us each and
+// serialise between the contexts of concurrent worker threads; a kernel runs on the context's own stream.
+typedef uint32_t bdx_copy_v4 __attribute__((ext_vector_type(4)));
+__global__ void bdx_copy_kernel(bdx_copy_v4 *dst, const bdx_copy_v4 *src, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+}  // namespace
+
+hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream) {
+    const long long n16 = (long long)((bytes + 15) / 16);
+    if (n16 <= 0) return hipSuccess;
+    long long blocks = (n16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bdx_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bdx_copy_v4 *)d_dst, (const bdx_copy_v4 *)src_mapped, n16);
+    return hipGetLastError();
+}
+
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
