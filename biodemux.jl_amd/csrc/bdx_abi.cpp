@@ -1465,7 +1465,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, ctx->d_exc.ensure((size_t)n_reads * 4 + 64));
             exc_list = (uint32_t *)ctx->d_exc.p;
         }
-        HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
+        if (!ctx->scratch_zeroed) HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
+        ctx->scratch_zeroed = false;
         // restricted runs of passes that only report score (+ end) through the clean-class DP start m + kb columns before
         // the first end column (orc_selftest_clean_short_lookback); everything else keeps 2 (m + kb) + 1
         int short_lb[2] = {0, 0};
@@ -1606,9 +1607,13 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
         HIP_TRY(ctx, ctx->d_seq.ensure(bytes + 64));
         void *h_in_dev = nullptr;  // the staging buffer as the device sees it
         HIP_TRY(ctx, hipHostGetDevicePointer(&h_in_dev, ctx->h_in, 0));
-        HIP_TRY(ctx, bdx_launch_copy(ctx->d_seq.p, h_in_dev, bytes, ctx->stream));
-        return run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off), n_reads, out,
-                                /*mapped_outputs=*/true);
+        const bool zero_scratch = ctx->d_maxlen.p != nullptr;  // (allocated at bdx_create when a filter is in use)
+        HIP_TRY(ctx, bdx_launch_copy(ctx->d_seq.p, h_in_dev, bytes, ctx->stream, zero_scratch ? (char *)ctx->d_maxlen.p + 64 : nullptr, 448));
+        ctx->scratch_zeroed = zero_scratch;
+        const int rcs = run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off),
+                                         n_reads, out, /*mapped_outputs=*/true);
+        ctx->scratch_zeroed = false;  // (also when the batch took a path that never looked at the flag)
+        return rcs;
     }
     // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));

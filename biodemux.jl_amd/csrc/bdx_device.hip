@@ -323,18 +323,22 @@ namespace {
 // batches instead of hipMemcpyAsync: copies of a few hundred KB through the copy engines cost ~35 us each and
 // serialise between the contexts of concurrent worker threads; a kernel runs on the context's own stream.
 typedef uint32_t bdx_copy_v4 __attribute__((ext_vector_type(4)));
-__global__ void bdx_copy_kernel(bdx_copy_v4 *dst, const bdx_copy_v4 *src, long long n16) {
+__global__ void bdx_copy_kernel(bdx_copy_v4 *dst, const bdx_copy_v4 *src, long long n16, uint32_t *zero, int zero_words) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
         dst[i] = __builtin_nontemporal_load(src + i);
+    // (the launch also clears the filter kernels' scratch words: one stream operation less per small batch)
+    if (blockIdx.x == 0 && zero)
+        for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0u;
 }
 }  // namespace
 
-hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream) {
+hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream, void *d_zero, int zero_bytes) {
     const long long n16 = (long long)((bytes + 15) / 16);
     if (n16 <= 0) return hipSuccess;
     long long blocks = (n16 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bdx_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bdx_copy_v4 *)d_dst, (const bdx_copy_v4 *)src_mapped, n16);
+    hipLaunchKernelGGL(bdx_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bdx_copy_v4 *)d_dst, (const bdx_copy_v4 *)src_mapped, n16,
+                       (uint32_t *)d_zero, zero_bytes / 4);
     return hipGetLastError();
 }
 
