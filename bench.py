@@ -302,7 +302,16 @@ def main():
         for k in wl["outputs"]:
             got = d_out[k][:sample].cpu().numpy()
             assert np.array_equal(got, exp[k]), f"bench: HIP {k} differs from the oracle on the CPU-baseline sample"
-        cpu = {"value": sample / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        cpu = {"value": sample / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+               "nproc": os.cpu_count(),
                "sample": f"first {sample} reads of the same {args.config} batch, oracle (C restatement of the reference "
                          f"algorithm) on {cores} host threads, {cpu_s:.1f} s; {', '.join(wl['outputs'])} equal the HIP output"}
 
