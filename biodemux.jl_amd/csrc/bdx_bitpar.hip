@@ -511,7 +511,10 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             LDS uint32_t *cnd = cand + (w.p ? R * cw0 : 0);
             __hip_atomic_fetch_or(&cnd[w.r * cw + (w.b >> 5)], 1u << (w.b & 31), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (full[w.p * R + w.r]) {
+            // (split mode reuses scnt / slots as its window counters / re-sweep queue: a dual config with ONE pass in the
+            // known-score class — e.g. trim_side 5 + no trim_side2 — must not push replay slots there, or the window
+            // counts handed to the exact kernel cover entries nobody wrote)
+            if (!a.split && full[w.p * R + w.r]) {
                 const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (dense)

@@ -1044,3 +1044,31 @@ def test_dense_windows_with_reads_beyond_16_bit_columns():
                 if hint:
                     hc.set_read_length_hint(hint)
                 fuzz.assert_same(hc.classify(seq, off), exp, f"{kw} hint {hint} [{hc.kernel_path}]")
+
+
+def test_dual_with_one_known_score_pass_hands_over_clean_window_counts():
+    """Regression (found by the fuzz campaign as a GPU memory fault): a dual config whose first pass trims
+    (split mode) while the second is score-only (known-score class) pushed replay slots into the LDS words split mode
+    uses as window counters, so the exact kernel was told about window entries nobody had written and read whatever
+    the buffer held before — here: the previous context's per-pass doubles.  Same sequence as the campaign: per-pass
+    outputs first, then without them, on fresh contexts."""
+    for seed in (53109,):
+        cfg, seq, off = fuzz.random_case_band(seed)
+        assert cfg.is_dual and cfg.trim_side == 5 and cfg.trim_side2 is None  # the shape of the failing case
+        for want in (True, False, True, False):
+            oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want)
+            exp = oc.classify(seq, off)
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                fuzz.assert_same(hc.classify(seq, off), exp, f"seed {seed} per-pass outputs {want} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts)
+    bcs = synth.make_barcodes(19, 20, seed=631, min_hamming=6)
+    b2 = synth.make_barcodes(23, 20, seed=632, min_hamming=6)
+    seq, off, _ = synth.make_reads(bcs, 6000, 100, seed=633, plant_lo=0, plant_hi=30, second=(b2, 50, 80))
+    for t1, t2 in ((5, None), (3, None), (None, 3), (None, 5)):
+        cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[20] * 19, ids=[f"x{i}" for i in range(19)], is_dual=True,
+                                bc_seqs2=b2, bc_lengths_no_N2=[20] * 23, ids2=[f"y{i}" for i in range(23)],
+                                max_error_rate=0.1, trim_side=t1, trim_side2=t2)
+        _all_filters_agree(cfg, seq, off)
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=False)
+        with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+            fuzz.assert_same(hc.classify(seq, off), oc.classify(seq, off), f"trim {t1}/{t2} without per-pass outputs")
