@@ -814,7 +814,8 @@ template <bool STAGED, int REGM>
 __device__ __forceinline__ PassOut run_pass_phased(const BdxDevCfg &cfg, const BdxDevPass &P, const int pidx,
                                                    const Bytes<STAGED> bcb, const LDS uint32_t *bc_off,
                                                    const Bytes<STAGED> r, const uint32_t *cand, const uint32_t *went,
-                                                   const int jf, const int trim_side, const bool need_tb) {
+                                                   const int jf, const int jl_last, const int n_read, const int trim_side,
+                                                   const bool need_tb) {
     const int m = cfg.band_m;
     const int kbb = cfg.band_kb[pidx], lb = cfg.band_lb[pidx];
     const int B = P.n_barcodes;
@@ -850,6 +851,10 @@ __device__ __forceinline__ PassOut run_pass_phased(const BdxDevCfg &cfg, const B
             const uint32_t e = went[b];
             e_lo = (int)(e & 0xFFFFu) - 1024 + lb;
             e_hi = (int)(e >> 16);
+            if (e_hi < 1 || e_hi > n_read || e_lo > e_hi) {  // not a window (defence in depth): the whole pass window, in chunks
+                e_lo = jf;
+                e_hi = jl_last;
+            }
             const int need = (e_hi - e_lo + 1) + 2 * kbb;
             const int k = need <= 9 ? 0 : (need <= 17 && has17) ? 1 : 2;
             if (k == cls) return true;
@@ -941,7 +946,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         const int pidx0 = (&P == &cfg.pass[1]) ? 1 : 0;
         if (wcount == 254 && cand && !align_one && n > 0 && cfg.band_m > 0 && cfg.band_kb[pidx0] >= 0 && !cfg.has_nindel &&
             cfg.algorithm == BDX_ALG_SEMIGLOBAL && cfg.match < 256 && cfg.mismatch < 256 && cfg.indel < 256)
-            return run_pass_phased<STAGED, REGM>(cfg, P, pidx0, bcb, bc_off, r, cand, went, jf, trim_side, need_tb);
+            return run_pass_phased<STAGED, REGM>(cfg, P, pidx0, bcb, bc_off, r, cand, went, jf, jl, n, trim_side, need_tb);
     }
     // :638 / :676 — barcodes in file order, the threshold tightens as we go.  With a candidate
     // mask each lane walks its OWN set bits (ascending = file order), so the lanes of a wave
@@ -984,6 +989,12 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                     cjhi = any_entry ? (hi_e > cjhi ? hi_e : cjhi) : hi_e;
                     any_entry = true;
                 }
+        }
+        // a hand-over window ends inside the read; anything else is not a window (defence in depth: columns drive
+        // addresses in the band form) -> no restriction
+        if (cjhi < 0x40000000 && (cjhi < 1 || cjhi > n || cjlo > cjhi)) {
+            cjlo = -0x40000000;
+            cjhi = 0x40000000;
         }
         if (cfg.algorithm == BDX_ALG_HAMMING) {
             const int allowed = (int)__builtin_floor(red.rate * (double)m);  // :567
