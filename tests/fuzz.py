@@ -209,6 +209,34 @@ def random_case_band(seed: int, n_reads: int = 1500):
     return cfg, seq, off
 
 
+def permuted_batch(seq: np.ndarray, off: np.ndarray, seed: int):
+    """The same reads in another order, a few dropped: (seq, off, index of each new read in the old batch).  Classifying
+    it on a context that has just classified the original batch makes every stale per-read buffer entry a WRONG
+    one (same indices, other reads) — reads of unwritten device memory turn into mismatches."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x9E37))
+    n = len(off) - 1
+    keep = rng.permutation(n)[: max(1, n - int(rng.integers(0, max(2, n // 10))))]
+    lens = (off[1:] - off[:-1])[keep]
+    noff = np.zeros(len(keep) + 1, dtype=np.int64)
+    noff[1:] = np.cumsum(lens)
+    nseq = np.empty(int(noff[-1]), dtype=np.uint8)
+    for k, i in enumerate(keep):
+        nseq[noff[k]:noff[k + 1]] = seq[off[i]:off[i + 1]]
+    return nseq, noff, keep
+
+
+def expected_permuted(exp: dict, keep: np.ndarray, n_old: int) -> dict:
+    out = {}
+    for k, v in exp.items():
+        if v.shape[0] == n_old:
+            out[k] = v[keep]
+        elif v.shape[0] == 2 * n_old:
+            out[k] = v.reshape(n_old, 2)[keep].reshape(-1)
+        else:
+            out[k] = v
+    return out
+
+
 def assert_same(got: dict, exp: dict, what: str = ""):
     for k in ("bc1", "bc2", "keep_start", "keep_end", "pass_bc", "pass_start", "pass_end"):
         if k in got and k in exp:

@@ -1072,3 +1072,23 @@ def test_dual_with_one_known_score_pass_hands_over_clean_window_counts():
         oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=False)
         with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
             fuzz.assert_same(hc.classify(seq, off), oc.classify(seq, off), f"trim {t1}/{t2} without per-pass outputs")
+
+
+@pytest.mark.parametrize("gen,seed", [("band", s) for s in range(100, 112)] + [("tiers", s) for s in range(100, 108)] +
+                         [("many", s) for s in range(100, 106)] + [("band", 53109)])
+def test_context_reuse_with_permuted_batches(gen, seed):
+    """One context, three batches: the reads, the same reads permuted (a few dropped), the reads again.  Every per-read
+    work buffer of the second call still holds the first call's entries at the same indices for OTHER reads, so any
+    read of an entry the second call did not write becomes a mismatch instead of going unnoticed."""
+    make = {"band": fuzz.random_case_band, "tiers": fuzz.random_case_tiers, "many": fuzz.random_case_many_barcodes}[gen]
+    cfg, seq, off = make(seed)
+    n = len(off) - 1
+    pseq, poff, keep = fuzz.permuted_batch(seq, off, seed)
+    for want in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want)
+        exp = oc.classify(seq, off)
+        pexp = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want).classify(pseq, poff)
+        with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+            fuzz.assert_same(hc.classify(seq, off), exp, f"{gen} {seed} first batch [{hc.kernel_path}]")
+            fuzz.assert_same(hc.classify(pseq, poff), pexp, f"{gen} {seed} permuted batch on the same context [{hc.kernel_path}]")
+            fuzz.assert_same(hc.classify(seq, off), exp, f"{gen} {seed} first batch again [{hc.kernel_path}]")

@@ -97,6 +97,28 @@ for seed in range(lo4, hi4):
 print(f"band seeds {lo4}..{hi4 - 1}: {band_runs} runs took the band form, paths {paths4}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
+# one context, three batches (reads, the same reads permuted, reads again): stale per-read buffer entries of the
+# previous batch sit at the same indices for OTHER reads
+lo5, hi5 = int(os.environ.get("SEED5_LO", "70000")), int(os.environ.get("SEED5_HI", "70200"))
+t0 = time.time()
+for seed in range(lo5, hi5):
+    gen = (fuzz.random_case_band, fuzz.random_case_tiers, fuzz.random_case_many_barcodes)[seed % 3]
+    cfg, seq, off = gen(seed)
+    pseq, poff, keep = fuzz.permuted_batch(seq, off, seed)
+    for want in (True, False):
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want).classify(seq, off)
+        pexp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want).classify(pseq, poff)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                fuzz.assert_same(hc.classify(seq, off), exp, f"reuse seed {seed} first batch [{hc.kernel_path}]")
+                fuzz.assert_same(hc.classify(pseq, poff), pexp, f"reuse seed {seed} permuted batch [{hc.kernel_path}]")
+                fuzz.assert_same(hc.classify(seq, off), exp, f"reuse seed {seed} first batch again [{hc.kernel_path}]")
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"context-reuse seeds {lo5}..{hi5 - 1}: {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
 def stress(name, bcs, seq, off, **kw):
     global bad
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
