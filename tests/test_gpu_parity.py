@@ -1092,3 +1092,36 @@ def test_context_reuse_with_permuted_batches(gen, seed):
             fuzz.assert_same(hc.classify(seq, off), exp, f"{gen} {seed} first batch [{hc.kernel_path}]")
             fuzz.assert_same(hc.classify(pseq, poff), pexp, f"{gen} {seed} permuted batch on the same context [{hc.kernel_path}]")
             fuzz.assert_same(hc.classify(seq, off), exp, f"{gen} {seed} first batch again [{hc.kernel_path}]")
+
+
+def test_host_entry_point_small_batch_forms():
+    """The host entry point picks its transfer path from the batch size (staged input + verdicts written into
+    page-locked memory below ~2 MB, a single staged device-to-host copy up to 256 k reads, plain copies beyond) and
+    from the outputs asked for.  Sizes on both sides of every threshold, output subsets through the raw C call,
+    batches of empty reads, alternating sizes on one context."""
+    import ctypes as C
+    from biodemux_jl_amd import hipabi
+    bcs = synth.make_barcodes(24, 16, seed=640, min_hamming=5)
+    seq_all, off_all, _ = synth.make_ragged_reads(bcs, 300000, 20, 120, seed=641)
+    for kw in (dict(max_error_rate=0.13), dict(max_error_rate=0.2, trim_side=3)):
+        cfg = _c2_config(bcs, **kw)
+        exp_all = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(seq_all, off_all)
+        with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+            for n in (1, 3, 4000, 20000, 70000, 5, 262144, 262145, 300000, 2):
+                seq, off = seq_all[:off_all[n]], off_all[:n + 1]
+                got = hc.classify(seq, off)
+                for k in ("bc1", "bc2", "keep_start", "keep_end"):
+                    assert np.array_equal(got[k], exp_all[k][:n]), (kw, n, k)
+                # output subsets through the raw entry point
+                for fields in (("bc1",), ("bc1", "keep_end"), ("bc1", "bc2", "keep_start")):
+                    o = hipabi.BdxOutputs()
+                    bufs = {f: np.full(n, -77, dtype=np.int32) for f in fields}
+                    for f, b in bufs.items():
+                        setattr(o, f, b.ctypes.data)
+                    assert hc.lib.bdx_classify_host(hc.h, seq.ctypes.data, off.ctypes.data, n, C.byref(o)) == 0
+                    for f, b in bufs.items():
+                        assert np.array_equal(b, exp_all[f][:n]), (kw, n, fields, f)
+            # reads without a single base
+            e_seq, e_off = np.zeros(1, np.uint8), np.zeros(6, np.int64)
+            got = hc.classify(e_seq[:0], e_off)
+            assert np.array_equal(got["bc1"], np.zeros(5, np.int32)) and np.array_equal(got["keep_start"], np.full(5, -1, np.int32))
