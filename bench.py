@@ -259,24 +259,29 @@ def main():
         windowed = hc.window_uploads > wu0
         # the same call the way a long-running host makes it: page-locked input buffers, result vectors kept across
         # chunks (fresh pageable result arrays are page-faulted in by the device-to-host copies)
-        from biodemux_jl_amd import hipabi as _abi
-        pseq = _abi.pinned_empty(seq.size, np.uint8)
-        pseq[:] = seq
-        poff = _abi.pinned_empty(off.size, np.int64)
-        poff[:] = off
-        pout = {k: _abi.pinned_empty(n, np.int32) for k in ("bc1", "bc2", "keep_start", "keep_end")}
-        hc.classify(pseq, poff, out=pout)
-        t1 = time.perf_counter()
-        hc.classify(pseq, poff, out=pout)
-        hs_pinned = time.perf_counter() - t1
-        for k in wl["outputs"]:
-            assert np.array_equal(pout[k], got_host[k]), f"page-locked host path disagrees on {k}"
-        del pseq, poff
+        hs_pinned = None
+        try:
+            from biodemux_jl_amd import hipabi as _abi
+            pseq = _abi.pinned_empty(seq.size, np.uint8)
+            pseq[:] = seq
+            poff = _abi.pinned_empty(off.size, np.int64)
+            poff[:] = off
+            pout = {k: _abi.pinned_empty(n, np.int32) for k in ("bc1", "bc2", "keep_start", "keep_end")}
+            hc.classify(pseq, poff, out=pout)
+            t1 = time.perf_counter()
+            hc.classify(pseq, poff, out=pout)
+            hs_pinned = time.perf_counter() - t1
+            for k in wl["outputs"]:
+                assert np.array_equal(pout[k], got_host[k]), f"page-locked host path disagrees on {k}"
+            del pseq, poff
+        except MemoryError:  # (page-locked memory is a limited resource: the figure is optional)
+            hs_pinned = None
         host_path = {"value": n / hs, "unit": "reads/s", "ms": hs * 1e3,
                      "pcie_gb_per_s": None if windowed else moved / hs / 1e9, "window_upload": windowed,
                      "host_gb_per_s": moved / hs / 1e9,
-                     "page_locked_reused": {"value": n / hs_pinned, "unit": "reads/s", "ms": hs_pinned * 1e3,
-                                            "note": "same call on page-locked input buffers with result vectors kept across calls"},
+                     "page_locked_reused": (None if hs_pinned is None else
+                                            {"value": n / hs_pinned, "unit": "reads/s", "ms": hs_pinned * 1e3,
+                                             "note": "same call on page-locked input buffers with result vectors kept across calls"}),
                      "note": "bdx_classify_host on pageable numpy buffers: H2D + kernels + D2H of bc1, bc2, keep_start, "
                              "keep_end (+ the Python wrapper's output allocation); verdicts equal the device-resident run"
                              + ("; window upload: only each read's column window crossed PCIe (host_gb_per_s = whole "
