@@ -46,6 +46,7 @@ BdxTuning read_tuning() {
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
     t.no_dense = getenv("BDX_NO_DENSE") != nullptr;
+    t.no_pipeline = getenv("BDX_NO_PIPELINE") != nullptr;
     if (const char *e = getenv("BDX_TIER_Q")) t.tier_q = atoi(e);
     t.no_window_upload = getenv("BDX_NO_WINDOW_UPLOAD") != nullptr;
     t.seed_hash_l2 = getenv("BDX_SEED_HASH_L2") != nullptr;
@@ -1002,6 +1003,96 @@ static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d
     return BDX_OK;
 }
 
+// Large batches through the host entry point: the reads go up in a few chunks on a copy stream of the context's own
+// while the kernels of the previous chunk run (one classify call per chunk on the context's stream, tied to its copy
+// by an event); the verdict vectors come back once at the end.  With pageable host memory hipMemcpyAsync returns when
+// the chunk is staged, so the launch of chunk i's kernels falls exactly between the copies of chunks i and i + 1.
+static int classify_host_pipelined(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t *seq_off, int64_t n_reads,
+                                   const bdx_outputs_t *out, int n_chunks) {
+    const size_t n = (size_t)n_reads;
+    const int64_t base = seq_off[0];
+    const int64_t total = seq_off[n_reads] - base;
+    if (!ctx->copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->copy_events) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));
+    HIP_TRY(ctx, ctx->d_off.ensure((n + 1) * 8));
+    HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
+    HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
+    int32_t *bi = (int32_t *)ctx->d_out_i32.p;
+    double *bf = (double *)ctx->d_out_f64.p;
+    // the longest read, on a few host threads (a device-side measurement per chunk would synchronise the stream and
+    // undo the overlap)
+    {
+        const size_t nthr = 8;
+        std::vector<int64_t> mx(nthr, 0);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthr; ++t)
+            th.emplace_back([&, t]() {
+                int64_t m = 0;
+                for (size_t i = n * t / nthr; i < n * (t + 1) / nthr; ++i) {
+                    const int64_t d = seq_off[i + 1] - seq_off[i];
+                    m = d > m ? d : m;
+                }
+                mx[t] = m;
+            });
+        for (std::thread &x : th) x.join();
+        int64_t m = 1;
+        for (int64_t v : mx) m = v > m ? v : m;
+        ctx->host_maxlen = (int)(m > (1LL << 30) ? (1LL << 30) : m);
+    }
+    struct Reset {
+        bdx_ctx *c;
+        ~Reset() { c->host_maxlen = 0; }
+    } reset{ctx};
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off.p, seq_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    const uint8_t *d_seq = (const uint8_t *)ctx->d_seq.p - base;
+    for (int c = 0; c < n_chunks; ++c) {
+        // (earlier chunks take the remainder: no work buffer has to grow while kernels run)
+        const size_t r0 = n / n_chunks * c + ((size_t)c < n % n_chunks ? c : n % n_chunks);
+        const size_t r1 = r0 + n / n_chunks + ((size_t)c < n % n_chunks ? 1 : 0);
+        const int64_t b0 = seq_off[r0], b1 = seq_off[r1];
+        if (b1 > b0)
+            HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->d_seq.p + (b0 - base), seq_bytes + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->copy_events[c], ctx->copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0));
+        bdx_outputs_t d{};
+        d.bc1 = bi + r0;
+        d.bc2 = out->bc2 ? bi + n + r0 : nullptr;
+        d.keep_start = out->keep_start ? bi + 2 * n + r0 : nullptr;
+        d.keep_end = out->keep_end ? bi + 3 * n + r0 : nullptr;
+        d.pass_start = out->pass_start ? bi + 4 * n + 2 * r0 : nullptr;
+        d.pass_end = out->pass_end ? bi + 6 * n + 2 * r0 : nullptr;
+        d.pass_raw = out->pass_raw ? bi + 8 * n + 2 * r0 : nullptr;
+        d.pass_bc = out->pass_bc ? bi + 10 * n + 2 * r0 : nullptr;
+        d.pass_score = out->pass_score ? bf + 2 * r0 : nullptr;
+        d.pass_delta = out->pass_delta ? bf + 2 * n + 2 * r0 : nullptr;
+        const int rc = bdx_classify_device(ctx, d_seq, (const int64_t *)ctx->d_off.p + r0, (int64_t)(r1 - r0), &d);
+        if (rc != BDX_OK) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            return rc;
+        }
+    }
+    auto back = [&](void *h, const void *dv, size_t bytes) -> hipError_t {
+        if (!h || !dv) return hipSuccess;
+        return hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIP_TRY(ctx, back(out->bc1, bi, n * 4));
+    HIP_TRY(ctx, back(out->bc2, out->bc2 ? bi + n : nullptr, n * 4));
+    HIP_TRY(ctx, back(out->keep_start, out->keep_start ? bi + 2 * n : nullptr, n * 4));
+    HIP_TRY(ctx, back(out->keep_end, out->keep_end ? bi + 3 * n : nullptr, n * 4));
+    HIP_TRY(ctx, back(out->pass_start, out->pass_start ? bi + 4 * n : nullptr, n * 8));
+    HIP_TRY(ctx, back(out->pass_end, out->pass_end ? bi + 6 * n : nullptr, n * 8));
+    HIP_TRY(ctx, back(out->pass_raw, out->pass_raw ? bi + 8 * n : nullptr, n * 8));
+    HIP_TRY(ctx, back(out->pass_bc, out->pass_bc ? bi + 10 * n : nullptr, n * 8));
+    HIP_TRY(ctx, back(out->pass_score, out->pass_score ? bf : nullptr, n * 16));
+    HIP_TRY(ctx, back(out->pass_delta, out->pass_delta ? bf + 2 * n : nullptr, n * 16));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pipelined_calls += 1;
+    return BDX_OK;
+}
+
 // Host mirror of the device's per-read window arithmetic (bdx_core.h resolve_range / pass_window and the per-read
 // setup of bdx_bitpar.hip): the 0-based half-open byte range [ulo, uhi) of a read of n code units that ANY pass may
 // touch — final_search_range first:last per pass (classification.jl:795-809), + max_m - 1 beyond the last start
@@ -1290,6 +1381,12 @@ void bdx_destroy(bdx_ctx *ctx) {
     if (ctx->own_stream) {
         (void)hipStreamSynchronize(ctx->own_stream);
         (void)hipStreamDestroy(ctx->own_stream);
+    }
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        for (hipEvent_t &e : ctx->copy_events)
+            if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(ctx->copy_stream);
     }
     for (int k = 0; k < 2; ++k) {
         ctx->bc_bytes[k].release();
@@ -1614,6 +1711,16 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
                                          n_reads, out, /*mapped_outputs=*/true);
         ctx->scratch_zeroed = false;  // (also when the batch took a path that never looked at the flag)
         return rcs;
+    }
+    // (worth it when the kernels take a noticeable part of the call — tiered budgets, split mode, no filter; the
+    // single fused launch of a plain known-score config is 3 ms per 10 M reads, chunking it costs more than it hides:
+    // measured C4 202 -> 242 M reads/s from pageable and 235 -> 295 M from page-locked buffers, C2 299 -> 260 M)
+    bool heavy = ctx->tiered || !ctx->fs[0].bplan.enabled;
+    for (int k = 0; k < (ctx->dev.is_dual ? 2 : 1); ++k) heavy = heavy || !ctx->fs[0].bplan.known_ok[k];
+    if (heavy && total >= ((int64_t)96 << 20) && n_reads >= 8 * 65536 && !ctx->tune.no_pipeline) {
+        int k = (int)(total / ((int64_t)48 << 20));
+        k = k < 2 ? 2 : (k > 8 ? 8 : k);
+        return classify_host_pipelined(ctx, seq_bytes, seq_off, n_reads, out, k);
     }
     // The offsets are uploaded as given; the byte pointer is rebased so that off[0] indexes it.
     HIP_TRY(ctx, ctx->d_seq.ensure((size_t)total + 64));

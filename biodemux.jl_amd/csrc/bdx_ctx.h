@@ -42,10 +42,11 @@ struct BdxTuning {
     int no_window_upload = 0;  // BDX_NO_WINDOW_UPLOAD: the host entry point always uploads whole reads
     int seed_hash_l2 = 0;  // BDX_SEED_HASH_L2: the piece hash table stays in global memory
     int seed_bm_log2 = 0;  // BDX_SEED_BM_LOG2: size of the seed bitmap (log2 of its bits)
-    int no_clean = 0;     // BDX_NO_CLEAN
+    int no_clean = 0;     // BDX_NO_CLEAN: exact kernel's register DP always in its predicated by-construction form
     int tier_q = 0;       // BDX_TIER_Q: piece length (5..8) the capped budgets of tier 1 are derived from (default: chosen per config)
+    int no_pipeline = 0;  // BDX_NO_PIPELINE: the host entry point uploads large batches in one piece
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
-    int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP: exact kernel's register DP always in its predicated by-construction form
+    int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
 };
@@ -80,6 +81,9 @@ struct bdx_ctx {
     int filter_used = BDX_FILTER_OFF;
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // host entry point, large batches: chunk uploads beside the previous chunk's kernels
+    hipEvent_t copy_events[8] = {};
+    int64_t pipelined_calls = 0;
     hipStream_t stream = nullptr;
     // device tables
     DevBuf bc_bytes[2], bc_off[2], bc_nn[2];

@@ -1125,3 +1125,32 @@ def test_host_entry_point_small_batch_forms():
             e_seq, e_off = np.zeros(1, np.uint8), np.zeros(6, np.int64)
             got = hc.classify(e_seq[:0], e_off)
             assert np.array_equal(got["bc1"], np.zeros(5, np.int32)) and np.array_equal(got["keep_start"], np.full(5, -1, np.int32))
+
+
+def test_pipelined_host_upload_equals_the_single_upload(monkeypatch):
+    """Large batches of configs with heavier kernels go up in chunks beside the previous chunk's kernels (one classify
+    call per chunk on the same context).  Same outputs, counters and statistics as the single upload (BDX_NO_PIPELINE),
+    and a sample against the oracle."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 1_000_001, 150, seed=651, repeat=dict(frac=0.05))
+    for kw in (dict(max_error_rate=0.2, summary=True, min_delta=0.05), dict(max_error_rate=0.2, trim_side=5)):
+        cfg = _c2_config(bcs, **kw)
+        res = {}
+        for piped in (True, False):
+            if piped:
+                monkeypatch.delenv("BDX_NO_PIPELINE", raising=False)
+            else:
+                monkeypatch.setenv("BDX_NO_PIPELINE", "1")
+            with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+                out = hc.classify(seq, off)
+                res[piped] = (out, hc.counts.copy(), hc.stats_tables() if cfg.summary else None)
+        for k, v in res[True][0].items():
+            assert np.array_equal(v, res[False][0][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, res[False][0][k]), (kw, k)
+        assert np.array_equal(res[True][1], res[False][1])
+        if cfg.summary:
+            for p_ in res[True][2]:
+                for name in res[True][2][p_]:
+                    assert np.array_equal(res[True][2][p_][name][0], res[False][2][p_][name][0]), (kw, name)
+        k = 4000
+        exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq[:off[k]], off[:k + 1])
+        fuzz.assert_same({kk: (v[:k] if v.shape[0] == 1_000_001 else v[:2 * k]) for kk, v in res[True][0].items()}, exp, str(kw))
