@@ -43,6 +43,10 @@ BdxTuning read_tuning() {
     t.no_slot = getenv("BDX_NO_SLOT") != nullptr;
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
+    t.no_wave = getenv("BDX_NO_WAVE") != nullptr;
+    if (const char *e = getenv("BDX_WAVE_RW")) t.wave_rw = atoi(e);
+    if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
+    if (const char *e = getenv("BDX_CU_COUNT")) t.cu_count = atoi(e);
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
     t.no_dense = getenv("BDX_NO_DENSE") != nullptr;
@@ -568,6 +572,155 @@ int build_diag_tables(bdx_ctx *ctx) {
     return BDX_OK;
 }
 
+// ---- wave-autonomous kernel (bdx_wave.hip): tables of one filter set ------------------------------
+// Eligible: single pass in the known-score class (ScoreOnly, unit costs), strict single seeds for every barcode
+// (no barcode swept unconditionally), barcodes of plain A / C / G / T up to 32 nt, and ranges that resolve to 1:n
+// for every read (then final_search_range = 1:n, max_start_pos = n, min_end_pos = 1: neither binds, DESIGN.md
+// §3.1).  Same pieces, keys and budgets as build_seed_tables / build_bitpar_tables of the set — only the symbol
+// coding differs: the kernel transcodes arithmetically, code = (byte >> 1) & 3 (A 0, C 1, T 2, G 3).
+int build_wave_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxFilterSet &F = ctx->F();
+    BdxWavePlan &wp = F.wplan;
+    wp = BdxWavePlan{};
+    const BdxBitparPlan &bp = F.bplan;
+    const BdxSeedPlan &sp = F.splan;
+    if (ctx->tune.no_wave || !bp.enabled || !sp.enabled || sp.diag || bp.word_bytes != 4 || c.is_dual || !bp.known_ok[0] ||
+        sp.n_always[0] != 0 || sp.q < 6 || sp.q > 8 || c.algorithm != BDX_ALG_SEMIGLOBAL)
+        return BDX_OK;
+    const bdx_pass_t &p = c.pass[0];
+    const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
+    if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+    const int B = p.n_barcodes;
+    if (B < 1 || B > 1024) return BDX_OK;
+    for (uint32_t i = 0; i < p.bc_off[B]; ++i) {
+        const uint8_t ch = p.bc_bytes[i];
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return BDX_OK;
+    }
+    const int q = sp.q;
+    struct Piece { int b, start; };
+    std::vector<Piece> pieces;
+    std::vector<uint32_t> meta((size_t)B, 0u), peq8((size_t)B * 8, 0u);
+    int track = 1 << 20;
+    for (int b = 0; b < B; ++b) {
+        const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+        if (m < 1 || m > 32) return BDX_OK;
+        const uint8_t *bc = p.bc_bytes + p.bc_off[b];
+        const int shift = 32 - m;
+        const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
+        const uint32_t pad = ~rows;  // virtual rows below the barcode: match everything, D stays 0
+        for (int code = 0; code < 8; ++code) {
+            uint32_t mask = pad;
+            if (code < 4)
+                for (int i = 0; i < m; ++i)
+                    if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
+            peq8[(size_t)b * 8 + code] = mask;
+        }
+        const long long ae = (long long)std::floor(c.max_error_rate * (double)m);  // (known-score class: SimpleScoring, cmin = 1)
+        if (ae < 0) {  // can never be recorded: neither seeded nor swept
+            meta[b] = (uint32_t)m;
+            continue;
+        }
+        long long kb = ae;
+        if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
+        if (kb > 255) return BDX_OK;
+        const long long L = m / (kb + 1);
+        if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
+        meta[b] = (uint32_t)m | ((uint32_t)kb << 8);
+        if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
+        for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{b, (int)(t * L)});
+    }
+    if (pieces.empty() || pieces.size() > 8192) return BDX_OK;
+    // the per-read record table holds four seeded barcodes: the planted one plus the chance pairs must nearly always fit
+    if (150.0 * (double)pieces.size() / std::pow(4.0, (double)q) > 1.2) return BDX_OK;
+    wp.q = q;
+    wp.n_barcodes = B;
+    wp.bm_bytes = (1 << (2 * q)) / 8;
+    wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
+    wp.hash_log2 = 8;
+    while ((1u << wp.hash_log2) < pieces.size() * 2) wp.hash_log2++;
+    std::vector<uint8_t> bitmap((size_t)wp.bm_bytes, 0), hash_ps((size_t)1 << wp.hash_log2, 0);
+    std::vector<uint32_t> hash((size_t)1 << wp.hash_log2, 0);
+    const uint32_t hmask = (1u << wp.hash_log2) - 1;
+    for (const Piece &pc : pieces) {
+        uint32_t key = 0;
+        for (int i = 0; i < q; ++i) key |= (uint32_t)((p.bc_bytes[p.bc_off[pc.b] + pc.start + i] >> 1) & 3) << (2 * i);
+        bitmap[key >> 3] |= (uint8_t)(1u << (key & 7));
+        const uint32_t entry = (key << 16) | (uint32_t)(pc.b + 1);
+        uint32_t slot = (key * 0x9E3779B1u) >> (32 - wp.hash_log2);
+        bool dup = false;  // one entry per (key, barcode, piece start): two pieces of one barcode may share a key
+        while (hash[slot] != 0) {
+            if (hash[slot] == entry && hash_ps[slot] == (uint8_t)pc.start) { dup = true; break; }
+            slot = (slot + 1) & hmask;
+        }
+        if (!dup) {
+            hash[slot] = entry;
+            hash_ps[slot] = (uint8_t)pc.start;
+        }
+    }
+    // the tables must leave room for at least eight waves' work areas at the smallest tile
+    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_bm = 0, o_hash = al(bitmap.size()), o_ps = o_hash + al(hash.size() * 4), o_peq = o_ps + al(hash_ps.size()),
+                 o_meta = o_peq + al(peq8.size() * 4), bytes = o_meta + al(meta.size() * 4);
+    std::vector<uint8_t> blob(bytes, 0);
+    memcpy(blob.data() + o_bm, bitmap.data(), bitmap.size());
+    memcpy(blob.data() + o_hash, hash.data(), hash.size() * 4);
+    memcpy(blob.data() + o_ps, hash_ps.data(), hash_ps.size());
+    memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
+    memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
+    HIP_TRY(ctx, F.wave_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(F.wave_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)F.wave_tables.p;
+    wp.d_bitmap = base + o_bm;
+    wp.d_hash = (const uint32_t *)(base + o_hash);
+    wp.d_hash_ps = base + o_ps;
+    wp.d_peq8 = (const uint32_t *)(base + o_peq);
+    wp.d_meta = (const uint32_t *)(base + o_meta);
+    wp.enabled = 1;
+    return BDX_OK;
+}
+
+// Geometry of the wave kernel for a batch: the tile size and workgroup shape that keep the most waves resident
+// per compute unit (tables once per workgroup + one work area per wave within 160 KiB, at most 16 waves: the
+// kernel is compiled for four waves per SIMD).  false: this batch runs the general kernel.
+bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
+    BdxWavePlan &wp = ctx->fs[set].wplan;
+    if (!wp.enabled || ctx->dev.vlen) return false;  // (window uploads stage per-read slots: general kernel)
+    if (read_len < 1) read_len = 1;
+    const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
+    const int rws[3] = {32, 16, 8};
+    int best_waves = 0;
+    for (int rw : rws) {
+        if (ctx->tune.wave_rw && rw != ctx->tune.wave_rw) continue;
+        // small batches: at least one tile per resident wave before the tile grows
+        if (!ctx->tune.wave_rw && rw > 8 && n_reads / rw < (long long)ctx->n_cu * 16) continue;
+        const long long span = (((long long)rw * read_len + 64 + 15) & ~15LL);
+        if (span > 60000) continue;  // flat positions are 16-bit
+        const size_t area = bdx_wave_area_bytes(rw, (int)span);
+        const int shapes[3] = {8, 16, 4};
+        for (int w : shapes) {
+            if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
+            const size_t lds = tables + (size_t)w * area;
+            if (lds > LDS_MAX) continue;
+            int per_cu = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));  // 1280-byte LDS granules
+            if (per_cu * w > 16) per_cu = 16 / w;
+            const int resident = per_cu * w;
+            if (resident > best_waves) {
+                best_waves = resident;
+                wp.rw = rw;
+                wp.waves = w;
+                wp.blocks = per_cu * ctx->n_cu;
+                wp.span_cap = (int)span;
+            }
+        }
+        if (best_waves >= 12) break;  // a larger tile at (nearly) full residency beats a smaller one
+    }
+    if (best_waves < 4) return false;
+    wp.read_len_hint = read_len;
+    return true;
+}
+
 // Geometry of the fused kernel for a given typical read length: the largest R whose LDS
 // footprint still lets two workgroups share a CU (8 waves/CU), else whatever fits.
 // force_slot: list mode (tier 0 of the tiered budgets) — the reads are scattered, every read is staged into a slot
@@ -578,7 +731,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads, bool force_slot 
     if (ctx->dev.vlen) force_slot = true;  // window upload: only each read's window is there
     // small batches: keep >= ~1024 tiles in flight (4 per CU) before growing the tile
     int r_cap = 256;
-    while (r_cap > 16 && n_reads / r_cap < 1024) r_cap >>= 1;
+    while (r_cap > 16 && n_reads / r_cap < 4LL * ctx->n_cu) r_cap >>= 1;
     if (bp.read_len_hint == read_len && bp.r_cap == r_cap && bp.reads_per_block > 0 && (bp.slot_bytes > 0 || !force_slot)) return true;
     bp.r_cap = r_cap;
     const int forced = ctx->tune.bitpar_r;
@@ -1256,10 +1409,17 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
         return bail(BDX_E_DEVICE);
     }
     ctx->stream = ctx->own_stream;
+    {
+        // the device's shape comes from the device (a partitioned part has fewer compute units than a full MI355X)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+        ctx->n_cu = ctx->tune.cu_count > 0 ? ctx->tune.cu_count : cus;
+    }
     rc = upload_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
     rc = plan_generic(ctx);  // needs the caller's host tables: run before they are dropped
     if (rc != BDX_OK) return bail(rc);
+    ctx->plan.n_cu = ctx->n_cu;
     rc = init_stats(ctx);
     if (rc != BDX_OK) return bail(rc);
     rc = build_bitpar_tables(ctx);
@@ -1275,6 +1435,8 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
         rc = build_seed_tables(ctx, false, true);
         if (rc != BDX_OK) return bail(rc);
     }
+    rc = build_wave_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
     // tier 1 (capped budgets, strict single seeds) beside a full-budget set that is NOT already strict single seeds
     {
         const BdxFilterSet &full = ctx->fs[0];
@@ -1340,6 +1502,7 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
                 // the full-budget filter by far
                 if (rc == BDX_OK && !ctx->fs[1].splan.enabled) rc = build_seed_tables(ctx, false);
                 if (rc == BDX_OK && ctx->fs[1].splan.enabled && ctx->fs[1].splan.q < ctx->tier_q) ctx->fs[1].splan.enabled = 0;
+                if (rc == BDX_OK) rc = build_wave_tables(ctx);
             }
             ctx->cur = 0;
             if (rc != BDX_OK) return bail(rc);
@@ -1401,7 +1564,9 @@ void bdx_destroy(bdx_ctx *ctx) {
         f.bp_tables.release();
         f.seed_tables.release();
         f.seed_tables_alt.release();
+        f.wave_tables.release();
     }
+    ctx->d_wlist.release();
     ctx->d_tier.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
@@ -1575,6 +1740,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         for (BdxFilterSet &f : ctx->fs) {
             f.bplan.short_lb[0] = short_lb[0];
             f.bplan.short_lb[1] = short_lb[1];
+            f.bplan.n_cu = ctx->n_cu;
         }
         // diagonal-band DP of the exact kernel (sg_core_band): clean class, every barcode of the config with the same
         // number of rows and of the pass with the same budget, column windows handed over by tracked sweeps
@@ -1593,6 +1759,26 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             return dv;
         };
         BdxTierArgs t0{0, nullptr, nullptr, nullptr, nullptr};
+        // Wave-autonomous kernel (bdx_wave.hip) in front of the general one: it answers the reads of the known-score
+        // class and lists the rest — as tier 1 of a tiered config, or (plain configs) ahead of the same filter set
+        // in list mode.  The list-mode plan is made first: if it cannot be made, the general kernel runs alone.
+        bool wave1 = false, wave0 = false;
+        if (!split && !ctx->dev.vlen) {
+            if (tiered)
+                wave1 = size_wave(ctx, 1, batch_len, n_reads);
+            else if (size_wave(ctx, 0, batch_len, n_reads))
+                wave0 = size_bitpar(ctx, batch_len, n_reads, true);
+            if (!tiered && !wave0) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
+        }
+        if (wave0) {
+            HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                         ctx->counts, (int *)(scratch + 256), 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192),
+                                         ctx->stream));
+            ctx->wave_launches += 1;
+            t0.in_list = (const uint32_t *)ctx->d_wlist.p;
+            t0.in_count = (const unsigned int *)(scratch + 192);
+        }
         if (tiered) {
             HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
             BdxTierArgs t1{1, (uint32_t *)ctx->d_tier.p, (unsigned int *)(scratch + 192), nullptr, nullptr};
@@ -1601,6 +1787,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.dense_w = 0;
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
+            if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
+                HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                             ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream));
+                ctx->wave_launches += 1;
+            } else
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
                                            o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0, n1, split ? 1 : 0, exc_list, exc_count, &t1));
             if (split)  // the exact kernel answers what tier 1 settles and lists the rest (known-score configs: the fused kernel did)
@@ -1618,7 +1809,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->F().bplan.dbg = ctx->tune.debug;
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
-                                       n1, split ? 1 : 0, exc_list, exc_count, tiered ? &t0 : nullptr));
+                                       n1, split ? 1 : 0, exc_list, exc_count, (tiered || wave0) ? &t0 : nullptr));
         if (split)  // (tiered: list mode over the reads tier 1 handed on)
             HIP_TRY(ctx, bdx_launch_generic(band_cfg(ctx->F()), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
@@ -1640,7 +1831,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
 #endif
         ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
-        if (tiered) ctx->path = "tier1:qgram+bitpar > " + ctx->path;
+        if (tiered) ctx->path = (wave1 ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (wave0) ctx->path = "wave > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -1820,6 +2012,8 @@ const char *bdx_kernel_path(const bdx_ctx *ctx) { return ctx ? ctx->path.c_str()
 int64_t bdx_window_uploads(const bdx_ctx *ctx) { return ctx ? ctx->window_uploads : 0; }
 
 int64_t bdx_band_launches(const bdx_ctx *ctx) { return ctx ? ctx->band_launches : 0; }
+
+int64_t bdx_wave_launches(const bdx_ctx *ctx) { return ctx ? ctx->wave_launches : 0; }
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;

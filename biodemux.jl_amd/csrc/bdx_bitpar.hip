@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
 }
 
 template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5, bool W64 = false>
-hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream, long long grid_override) {
+hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream, long long grid_override, int n_cu) {
     // the attribute is per device: one flag per device of this process.  Contexts of several OS threads may
     // launch concurrently: setting the attribute twice is harmless, the flag itself must not be a data race.
     static std::atomic<bool> attr_set[64];
@@ -1203,7 +1203,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     long long per_cu = (long long)((160 * 1024) / (lds ? ((lds + 1279) / 1280) * 1280 : 1));  // 1280-byte LDS granules
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    long long blocks = 256 * per_cu;  // exactly the resident set; the tile queue balances it
+    long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * per_cu;  // exactly the resident set; the tile queue balances it
     if (grid_override > 0) blocks = grid_override;
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
@@ -1334,7 +1334,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
     const size_t lds = bdx_bitpar_lds_bytes(cfg, bp, gp, &sp);
     const bool seed = sp.enabled != 0;
     if (seed && sp.diag) {
-#define BDX_LAUNCH_D(RR) return bp.diag_nw > 5 ? launch_one<256, RR, true, true, 10>(a, lds, n_reads, stream, bp.grid_override) : launch_one<256, RR, true, true, 5>(a, lds, n_reads, stream, bp.grid_override)
+#define BDX_LAUNCH_D(RR) return bp.diag_nw > 5 ? launch_one<256, RR, true, true, 10>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu) : launch_one<256, RR, true, true, 5>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)
         switch (bp.reads_per_block) {
             case 32:
                 BDX_LAUNCH_D(32);
@@ -1350,10 +1350,10 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
 #undef BDX_LAUNCH_D
     }
 #define BDX_LAUNCH_R(RR)                                                                                                  \
-    return bp.word_bytes == 8 ? (seed ? launch_one<256, RR, true, false, 5, true>(a, lds, n_reads, stream, bp.grid_override)    \
-                                      : launch_one<256, RR, false, false, 5, true>(a, lds, n_reads, stream, bp.grid_override)) \
-                              : (seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override)                    \
-                                      : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override))
+    return bp.word_bytes == 8 ? (seed ? launch_one<256, RR, true, false, 5, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)    \
+                                      : launch_one<256, RR, false, false, 5, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)) \
+                              : (seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)                    \
+                                      : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu))
     switch (bp.reads_per_block) {
         case 256:
             BDX_LAUNCH_R(256);

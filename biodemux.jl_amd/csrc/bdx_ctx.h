@@ -47,6 +47,10 @@ struct BdxTuning {
     int no_pipeline = 0;  // BDX_NO_PIPELINE: the host entry point uploads large batches in one piece
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
+    int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
+    int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
+    int wave_waves = 0;
+    int cu_count = 0;     // BDX_CU_COUNT: pretend the device has this many compute units (tests of the grid sizing)
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)
 };
@@ -63,6 +67,8 @@ struct BdxFilterSet {
     // batch at hand (very many barcodes, reads beyond 312 bases); built at create, while the barcodes are there
     BdxSeedPlan splan_alt{};
     DevBuf bp_tables, seed_tables, seed_tables_alt;
+    BdxWavePlan wplan{};   // wave-autonomous kernel (bdx_wave.hip) for this set, when the config qualifies
+    DevBuf wave_tables;
 };
 
 struct bdx_ctx {
@@ -80,6 +86,9 @@ struct bdx_ctx {
     int user_len_hint = 0;  // 0 = measure every device batch
     int filter_used = BDX_FILTER_OFF;
     int device = 0;
+    int n_cu = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount, read in bdx_create)
+    int64_t wave_launches = 0;  // launches of the wave-autonomous kernel
+    DevBuf d_wlist;          // reads the wave kernel hands to the general kernel (plain configs; tiered ones use d_tier)
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;   // host entry point, large batches: chunk uploads beside the previous chunk's kernels
     hipEvent_t copy_events[8] = {};

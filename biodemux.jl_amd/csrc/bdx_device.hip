@@ -410,7 +410,8 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
     a.hist_entries = plan.hist_entries;
     long long blocks = (n_reads + plan.threads - 1) / plan.threads;
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
-    if (d_list && blocks > 1024) blocks = 1024;  // list mode: the hand-overs are few; the grid strides
+    const long long list_grid = 4LL * (plan.n_cu > 0 ? plan.n_cu : 256);
+    if (d_list && blocks > list_grid) blocks = list_grid;  // list mode: the hand-overs are few; the grid strides
     const dim3 grid((unsigned)blocks), block((unsigned)plan.threads);
     if (plan.reg_rows == 24 && plan.threads == 256 && plan.clean) {
         if (plan.uniform_m)

@@ -104,6 +104,7 @@ struct BdxGenericPlan {
     int bc_stage_bytes;  // LDS bytes for the staged barcode bytes of both passes (0 = not staged)
     int hist_entries;    // LDS histogram entries (0 = global atomics)
     size_t lds_bytes;
+    int n_cu;            // compute units of the device (list-mode grid: 4 workgroups per unit)
 };
 
 // Bit-parallel (Myers) pre-filter: tables built on the host in bdx_abi.cpp, used by
@@ -125,6 +126,7 @@ struct BdxBitparPlan {
     int ncode_N;           // symbol code of 'N' (255 if no barcode contains it)
     int ncodes;            // symbol codes incl. the trailing "other" code (<= 16)
     long long grid_override;  // > 0: forced persistent grid (tuning, BdxTuning::grid)
+    int n_cu;              // compute units of the device: the persistent grid is n_cu x the LDS-limited residency
     int short_lb[2];       // per launch and pass: short lookback of the restricted runs (score / end-only clean-class passes)
     int dbg;               // BdxTuning::debug (only builds with -DBDX_TUNING look at it)
     int known_ok[2];       // pass qualifies for the known-score class (see bdx_bitpar.hip)
@@ -163,6 +165,29 @@ struct BdxSeedPlan {
     const uint32_t *d_dkeys[2];    // per barcode: 2 words, 8 bits per piece key (first 4 bases of the piece)
 };
 
+// Wave-autonomous seeded kernel (bdx_wave.hip): the single-seed filter + reducer replay of known-score configs whose
+// barcodes are plain A/C/G/T, every wave on a tile of its own (no workgroup barriers), bytes transcoded arithmetically.
+// Tables are built next to the seed tables of a filter set (bdx_abi.cpp, build_wave_tables); the geometry per batch.
+struct BdxWavePlan {
+    int enabled;           // config-level eligibility of this filter set
+    int q;                 // seed length (6..8)
+    int hash_log2;
+    int n_barcodes;
+    int bm_bytes;          // direct bitmap over the 4^q keys
+    int track_from;        // columns [0, track_from) of a sweep cannot end an alignment within any barcode's budget
+    const uint8_t *d_bitmap;
+    const uint32_t *d_hash;      // key << 16 | barcode + 1
+    const uint8_t *d_hash_ps;
+    const uint32_t *d_peq8;      // [B][8]: rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
+    const uint32_t *d_meta;      // [B]: m | kb << 8
+    // per batch (size_wave)
+    int rw;                // reads per wave tile (32 / 16 / 8)
+    int waves;             // waves per workgroup
+    int blocks;            // persistent grid
+    int span_cap;          // bytes of a tile's span the images hold
+    int read_len_hint;     // the read length the geometry was planned for
+};
+
 // Tiered budgets: tier 1 (tier1 = 1) appends the reads it cannot settle to out_list / *out_count; tier 0 then
 // runs over in_list[0 .. *in_count) only (list mode).
 struct BdxTierArgs {
@@ -184,6 +209,13 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
 // max read length of a device-resident batch (one tiny kernel; result written to *d_out)
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
 hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream, void *d_zero = nullptr, int zero_bytes = 0);
+
+// Implemented in bdx_wave.hip.
+size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
+size_t bdx_wave_area_bytes(int rw, int span_cap);
+hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                           long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream);
 
 // Implemented in bdx_device.hip.
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,

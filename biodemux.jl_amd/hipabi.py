@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
-    "bdx_window_uploads", "bdx_band_launches",
+    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
 BDX_COMM_ID_BYTES = 128
@@ -214,6 +214,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_window_uploads.argtypes = [vp]
     L.bdx_band_launches.restype = C.c_int64
     L.bdx_band_launches.argtypes = [vp]
+    L.bdx_wave_launches.restype = C.c_int64
+    L.bdx_wave_launches.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -462,6 +464,11 @@ class HipClassifier:
     def band_launches(self) -> int:
         """(pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled."""
         return int(self.lib.bdx_band_launches(self.h))
+
+    @property
+    def wave_launches(self) -> int:
+        """Launches of the wave-autonomous kernel (bdx_wave.hip) this context made."""
+        return int(self.lib.bdx_wave_launches(self.h))
 
     @property
     def window_uploads(self) -> int:

@@ -269,6 +269,14 @@ int64_t bdx_window_uploads(const bdx_ctx *ctx);
  * Results are identical either way; the counter exists so that tests can tell which form ran. */
 int64_t bdx_band_launches(const bdx_ctx *ctx);
 
+/* How many launches of the WAVE-AUTONOMOUS kernel this context made (bdx_wave.hip): known-score configs (ScoreOnly,
+ * unit costs) with plain A/C/G/T barcodes and ranges "1:end" — the reference's default call and the headline
+ * benchmark — get their verdicts from a kernel in which every wavefront walks its own tile of reads (seed scan,
+ * bit-vector sweeps, replay of find_best_matching_bc, classification.jl:632-713); reads it cannot answer go to the
+ * general kernel.  Results are identical either way (env BDX_NO_WAVE switches it off); the counter exists so that
+ * tests can tell which kernel ran. */
+int64_t bdx_wave_launches(const bdx_ctx *ctx);
+
 typedef struct {
     int32_t threads_per_block;
     int32_t lds_bytes_per_block;

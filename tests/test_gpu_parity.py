@@ -687,7 +687,7 @@ def test_diag_partial_tiles_and_sub_batches(n_reads, max_len):
 
 
 # ---- tiered budgets: tier 1 (capped budgets, single seeds) settles what it can, tier 0 (full budget, list mode) the rest ----
-TIER = "tier1:qgram+bitpar > "
+TIER = "tier1:"  # ("tier1:wave > ..." when tier 1 runs as the wave-autonomous kernel, else "tier1:qgram+bitpar > ...")
 
 
 @pytest.mark.parametrize("kw", [

@@ -1,0 +1,239 @@
+"""GPU parity of the wave-autonomous kernel (csrc/bdx_wave.hip) — the kernel behind the headline configuration.
+
+It answers reads of the known-score class (find_best_matching_bc replayed on unit distances,
+classification.jl:632-713) and hands every other read to the general kernel; each test compares the whole chain
+with the oracle, checks through the ``wave_launches`` counter that the kernel under test really ran, and most
+also run the same batch with ``BDX_NO_WAVE`` (general kernel alone) — every output must be identical.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import fuzz
+import helpers as H
+from biodemux_jl_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(bcs, **kw):
+    base = dict(bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"bc{i + 1}" for i in range(len(bcs))],
+                max_error_rate=0.1)
+    base.update(kw)
+    return H.bdx.DemuxConfig(**base)
+
+
+def _both_kernels(cfg, seq, off, monkeypatch, want_pass=True, expect_wave=True, hint=None, env=None):
+    """classify with and without the wave kernel; both equal the oracle (outputs and counters)."""
+    oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want_pass)
+    exp = oc.classify(seq, off)
+    for wave in (True, False):
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        if wave:
+            monkeypatch.delenv("BDX_NO_WAVE", raising=False)
+        else:
+            monkeypatch.setenv("BDX_NO_WAVE", "1")
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            monkeypatch.delenv("BDX_NO_WAVE", raising=False)
+            for k in (env or {}):
+                monkeypatch.delenv(k, raising=False)
+            if hint is not None:
+                hc.set_read_length_hint(hint)
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"wave {wave} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), (wave, hc.kernel_path)
+            if wave and expect_wave:
+                assert hc.wave_launches > 0 and "wave" in hc.kernel_path, hc.kernel_path
+            if not wave:
+                assert hc.wave_launches == 0 and "wave" not in hc.kernel_path, hc.kernel_path
+            got2 = hc.classify(seq, off)  # the same context again: per-launch scratch words are re-armed
+            fuzz.assert_same(got2, exp, f"wave {wave}, second call [{hc.kernel_path}]")
+    return exp
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(min_delta=0.05), dict(max_error_rate=0.13), dict(max_error_rate=0.05),
+                                dict(max_error_rate=0.0)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "C2")
+def test_wave_c2_shape(kw, monkeypatch):
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 60000, 150)
+    exp = _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 4000, 4001])
+def test_wave_batch_sizes(n, monkeypatch):
+    """Partial tiles, partial chunks of the tile queue, fewer tiles than waves."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 4096, 150, seed=5)
+    _both_kernels(_cfg(bcs), seq[: off[n]], off[: n + 1].copy(), monkeypatch)
+
+
+@pytest.mark.parametrize("want_pass", [True, False])
+@pytest.mark.parametrize("kw", [dict(max_error_rate=0.2), dict(max_error_rate=0.2, min_delta=0.1), dict(max_error_rate=0.17, min_delta=0.04)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_wave_as_tier_1(kw, want_pass, monkeypatch):
+    """The reference's default rate: tier 1 (capped budgets + settle rule) runs as the wave kernel, tier 0 as before."""
+    bcs = synth.make_barcodes(96, 24, seed=101)
+    seq, off, _ = synth.make_reads(bcs, 40000, 150, seed=102, sub=0.05, ins=0.015, dele=0.015, repeat=dict(frac=0.15))
+    cfg = _cfg(bcs, **kw)
+    exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=want_pass)
+    with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+        hc.classify(seq, off)
+        assert hc.kernel_path.startswith("tier1:wave > "), hc.kernel_path
+    assert 0.3 < (exp["bc1"] > 0).mean() < 0.98
+
+
+def test_wave_bytes_outside_acgt(monkeypatch):
+    """Reads with N, lower case, IUPAC letters, control bytes and bytes that alias a letter's 3-bit index ((byte >> 1)
+    & 7): none of them equals a barcode base (the reference compares raw bytes, classification.jl:185; reads are never
+    upper-cased), inside a planted barcode they are substitutions."""
+    bcs = synth.make_barcodes(48, 24, seed=7)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=8, n_rate=0.0)
+    rng = np.random.Generator(np.random.PCG64(9))
+    seq = seq.copy()
+    odd = np.frombuffer(b"NnacgtRYKMSWBDHVU*-.\x00\x01\x7f\xff@BDFPQRSUVEaceg\x21\x23\x27\x34", dtype=np.uint8)
+    pos = rng.choice(len(seq), size=len(seq) // 60, replace=False)
+    seq[pos] = odd[rng.integers(0, len(odd), size=len(pos))]
+    # whole reads in lower case: must never match
+    mat = seq.reshape(-1, 150)
+    mat[::97] = np.where((mat[::97] >= 65) & (mat[::97] <= 90), mat[::97] + 32, mat[::97])
+    exp = _both_kernels(_cfg(bcs), seq, off, monkeypatch)
+    assert (exp["bc1"][::97] <= 0).all()
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("hint", [None, 40, 150, 400])
+def test_wave_ragged_reads_and_wrong_hints(hint, monkeypatch):
+    """Lengths 0 .. 260 (empty reads, reads shorter than a seed or a barcode), hints that are too small (tiles that do
+    not fit the images go to the general kernel) or too large."""
+    bcs = synth.make_barcodes(48, 24, seed=21)
+    seq, off, _ = synth.make_ragged_reads(bcs, 20000, 0, 260, seed=21)
+    _both_kernels(_cfg(bcs), seq, off, monkeypatch, hint=hint, expect_wave=hint != 40 or True)
+
+
+def test_wave_offsets_need_not_start_at_zero_or_be_aligned(monkeypatch):
+    bcs = synth.make_barcodes(24, 24, seed=3)
+    seq, off, _ = synth.make_reads(bcs, 5000, 151, seed=4)  # odd length: every tile starts at another alignment
+    cfg = _cfg(bcs)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
+    pad = 13
+    seq2 = np.concatenate([np.full(pad, ord("A"), dtype=np.uint8), seq])
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+        got = hc.classify(seq2, off + pad)
+        assert hc.wave_launches > 0
+        fuzz.assert_same(got, exp, "shifted offsets")
+
+
+def test_wave_low_complexity_overflows(monkeypatch):
+    """Low-complexity barcodes and reads make almost every position a seed hit: the hit queue, the per-read record
+    tables and the sweep queue overflow; the affected tiles / reads must come back from the general kernel unchanged."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    bcs = ["A" * 24, "AC" * 12, "ACG" * 8, "AAAACCCCGGGGTTTTAAAACCCC", "ACGT" * 6, "T" * 24, "TTTTTTTTAAAAAAAAGGGGGGGG"]
+    bcs += synth.make_barcodes(25, 24, seed=11)
+    motifs = ["A", "AC", "ACG", "ACGT", "T", "TTTTAAAA", "AAAACCCCGGGGTTTT"]
+    reads = []
+    for i in range(6000):
+        if i % 3 == 0:  # ordinary reads between the pathological ones: tiles mix both
+            reads.append("".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=150)))
+            continue
+        mo = motifs[int(rng.integers(0, len(motifs)))]
+        s = list((mo * 200)[int(rng.integers(0, 8)):][:150])
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, 150))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s))
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(), dict(min_delta=0.05)):
+        exp = _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch)
+    assert (exp["bc1"] != 0).mean() > 0.3
+
+
+def test_wave_many_survivors_and_concatemers(monkeypatch):
+    """A family of near-identical barcodes leaves more than four survivors per read (list), concatemers seed one
+    barcode at two places (one merged, long sweep window: more than one 32-column block)."""
+    base = synth.make_barcodes(1, 24, seed=77)[0]
+    fam = [base]
+    for i in range(9):
+        j = 2 * i + 1
+        fam.append(base[:j] + ("A" if base[j] != "A" else "C") + base[j + 1:])
+    bcs = fam + synth.make_barcodes(22, 24, seed=78)
+    seq, off, _ = synth.make_reads(bcs, 20000, 150, seed=79, repeat=dict(frac=0.3))
+    for kw in (dict(), dict(min_delta=0.05), dict(max_error_rate=0.13)):
+        exp = _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("m,rate", [(16, 0.07), (20, 0.1), (24, 0.1), (28, 0.08), (32, 0.1), (21, 0.1), (31, 0.07)])
+def test_wave_barcode_lengths(m, rate, monkeypatch):
+    """Other barcode lengths / budgets: pieces of 6, 7 and 8 bases, top-aligned patterns of 16 .. 32 rows, the column
+    from which a sweep tracks its score (min over the barcodes of m - kb - 1)."""
+    bcs = synth.make_barcodes(64, m, seed=m)
+    seq, off, _ = synth.make_reads(bcs, 20000, 120, seed=m + 1)
+    _both_kernels(_cfg(bcs, max_error_rate=rate), seq, off, monkeypatch, expect_wave=False)
+
+
+def test_wave_mixed_barcode_lengths(monkeypatch):
+    lens = [24, 26, 28, 30, 32, 25, 27, 29] * 6
+    bcs = synth.make_barcodes(len(lens), 24, seed=55, lengths=lens)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=56)
+    _both_kernels(_cfg(bcs, max_error_rate=0.08), seq, off, monkeypatch, expect_wave=False)
+
+
+@pytest.mark.parametrize("env", [dict(BDX_WAVE_RW="8"), dict(BDX_WAVE_RW="16"), dict(BDX_WAVE_RW="32", BDX_WAVE_WAVES="4"),
+                                 dict(BDX_WAVE_WAVES="16"), dict(BDX_CU_COUNT="32"), dict(BDX_CU_COUNT="7")],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_wave_geometries_and_device_shape(env, monkeypatch):
+    """Forced tile sizes / workgroup shapes, and a device that reports fewer compute units (a partitioned part): the
+    persistent grids follow the device's shape (hipDeviceAttributeMultiprocessorCount), results do not change."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 50000, 150, seed=17)
+    _both_kernels(_cfg(bcs), seq, off, monkeypatch, env=env)
+
+
+def test_device_shape_override_on_the_other_paths(monkeypatch):
+    """BDX_CU_COUNT also shapes the general kernel's persistent grid and the exact kernel's list-mode grid."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 50000, 150, seed=18)
+    for kw in (dict(max_error_rate=0.2, trim_side=5), dict(max_error_rate=0.2, min_delta=0.1), dict(max_error_rate=0.25, mismatch=1, indel=2)):
+        cfg = _cfg(bcs, **kw)
+        oc = H.orc.OracleClassifier(cfg, nthreads=16)
+        exp = oc.classify(seq, off)
+        monkeypatch.setenv("BDX_CU_COUNT", "24")
+        with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+            monkeypatch.delenv("BDX_CU_COUNT")
+            fuzz.assert_same(hc.classify(seq, off), exp, f"{kw} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+
+
+def test_wave_full_size_equals_the_general_kernel(monkeypatch):
+    """BASELINE config 2 at its full size: all 10 M verdicts and the counters identical between the two kernels, a
+    strided sample equal to the oracle."""
+    import torch
+
+    n = 10_000_000
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, n, 150)
+    cfg = _cfg(bcs)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    res = {}
+    for wave in (True, False):
+        if not wave:
+            monkeypatch.setenv("BDX_NO_WAVE", "1")
+        with H.bdx.HipClassifier(cfg) as hc:
+            monkeypatch.delenv("BDX_NO_WAVE", raising=False)
+            hc.set_read_length_hint(150)
+            out = torch.empty(n, dtype=torch.int32, device=dev)
+            hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, bc1=out.data_ptr())
+            hc.sync()
+            res[wave] = (out.cpu().numpy(), hc.counts.copy(), hc.wave_launches)
+    assert res[True][2] > 0 and res[False][2] == 0
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    idx = np.arange(0, n, 100)
+    sseq = seq.reshape(n, 150)[idx].reshape(-1)
+    soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
+    assert np.array_equal(res[True][0][idx], exp["bc1"])
