@@ -600,7 +600,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     const int q = sp.q;
     struct Piece { int b, start; };
     std::vector<Piece> pieces;
-    std::vector<uint32_t> meta((size_t)B, 0u), peq8((size_t)B * 8, 0u);
+    std::vector<uint32_t> meta((size_t)B, 0u), peq8((size_t)B * 9, 0u);  // (stride 9: bank spread, see the kernel)
     int track = 1 << 20;
     for (int b = 0; b < B; ++b) {
         const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
@@ -614,7 +614,7 @@ int build_wave_tables(bdx_ctx *ctx) {
             if (code < 4)
                 for (int i = 0; i < m; ++i)
                     if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
-            peq8[(size_t)b * 8 + code] = mask;
+            peq8[(size_t)b * 9 + code] = mask;
         }
         const long long ae = (long long)std::floor(c.max_error_rate * (double)m);  // (known-score class: SimpleScoring, cmin = 1)
         if (ae < 0) {  // can never be recorded: neither seeded nor swept
@@ -623,7 +623,7 @@ int build_wave_tables(bdx_ctx *ctx) {
         }
         long long kb = ae;
         if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
-        if (kb > 255) return BDX_OK;
+        if (kb > 15) return BDX_OK;  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
         const long long L = m / (kb + 1);
         if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
         meta[b] = (uint32_t)m | ((uint32_t)kb << 8);
@@ -696,7 +696,7 @@ bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
         // small batches: at least one tile per resident wave before the tile grows
         if (!ctx->tune.wave_rw && rw > 8 && n_reads / rw < (long long)ctx->n_cu * 16) continue;
         const long long span = (((long long)rw * read_len + 64 + 15) & ~15LL);
-        if (span > 60000) continue;  // flat positions are 16-bit
+        if (span > 10 * 1024) continue;  // a tile's bytes wait in registers: at most ten 16-byte vectors per lane
         const size_t area = bdx_wave_area_bytes(rw, (int)span);
         const int shapes[3] = {8, 16, 4};
         for (int w : shapes) {
@@ -1774,7 +1774,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                          ctx->counts, (int *)(scratch + 256), 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192),
-                                         ctx->stream));
+                                         ctx->stream, ctx->tune.debug));
             ctx->wave_launches += 1;
             t0.in_list = (const uint32_t *)ctx->d_wlist.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
@@ -1789,7 +1789,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.dbg = ctx->tune.debug;
             if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                             ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream));
+                                             ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
                 ctx->wave_launches += 1;
             } else
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,

@@ -178,7 +178,7 @@ struct BdxWavePlan {
     const uint8_t *d_bitmap;
     const uint32_t *d_hash;      // key << 16 | barcode + 1
     const uint8_t *d_hash_ps;
-    const uint32_t *d_peq8;      // [B][8]: rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
+    const uint32_t *d_peq8;      // [B][9] (stride 9 dwords): rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
     const uint32_t *d_meta;      // [B]: m | kb << 8
     // per batch (size_wave)
     int rw;                // reads per wave tile (32 / 16 / 8)
@@ -215,7 +215,7 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
 size_t bdx_wave_area_bytes(int rw, int span_cap);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream);
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0);
 
 // Implemented in bdx_device.hip.
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,

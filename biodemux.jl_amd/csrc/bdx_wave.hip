@@ -48,18 +48,28 @@ struct WaveArgs {
     const uint32_t *hash;    // key << 16 | barcode + 1 (0: empty), open addressing
     const uint8_t *hash_ps;  // piece start (bases) of every entry
     int hash_log2;
-    const uint32_t *peq8;    // [B][8]: sweep word of barcode b for symbol code c (4..7: "other")
+    const uint32_t *peq8;    // [B][9]: sweep word of barcode b for symbol code c (4..7: "other"; the ninth word pads the stride)
     const uint32_t *meta;    // [B]: m | kb << 8
     int B;
     int q;
     int span_cap;            // bytes of one tile's span the images hold
     int per_wave;            // LDS bytes of one wave's work area
-    int *tile_counter;       // zeroed before the launch: dynamic chunk queue
     int tier;                // 1: tier 1 of the tiered budgets (settle rule applies)
     double tier_slo;
     uint32_t *list;          // reads this kernel does not answer ...
     unsigned int *list_count;  // ... and how many
+    int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a skip bit
+              // is set: 1 skip verdicts, 2 skip sweeps, 4 skip resolve + emit, 8 skip seed scan, 32 skip transcode, 64 skip loads
 };
+
+// The product library has no phase-skip switches: BDX_DBG folds to 0 and the branches disappear.
+#ifdef BDX_TUNING
+#define BDX_DBG(bit) (a.dbg & (bit))
+#else
+#define BDX_DBG(bit) 0
+#endif
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE_SYNC()                                          \
     do {                                                     \
@@ -131,45 +141,63 @@ __device__ __forceinline__ void sweep_step(const uint32_t Eq, uint32_t &Pv, uint
 // j + 1 columns is >= m - (j + 1)), so the score is first needed at column TF, where it is popcount(Pv) -
 // popcount(Mv): D[m][j] = D[0][j] + the vertical deltas, D[0][j] = 0 (free start), the virtual rows below the
 // barcode carry no delta.
+// Eight LDS reads issued back to back (the compiler, left alone, keeps one or two in flight and waits in front of
+// every use): inline asm for the loads and for the wait, which names the destinations so that nothing that uses
+// them moves above it.  Waits are always lgkmcnt(0), which is correct whatever else is outstanding.
+__device__ __forceinline__ void lds_read8(uint32_t (&d)[8], const uint32_t (&addr)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(d[i]) : "v"(addr[i]) : "memory");
+}
+__device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+                 :
+                 : "memory");
+}
+
 template <int TF>
 __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3,
                                             const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best) {
     const uint32_t A[4] = {A0, A1, A2, A3};
+    uint32_t Eq[2][8];
+    const auto issue = [&](const int h) __attribute__((always_inline)) {
+        uint32_t addr[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // the Eq words of 16 columns in flight at a time
-        uint32_t Eq[16];
+        for (int jj = 0; jj < 8; ++jj) addr[jj] = pbase + (__builtin_amdgcn_ubfe(A[h], 4 * jj, 3) << 2);
+        lds_read8(Eq[h & 1], addr);
+    };
+    issue(0);
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * h + jj;
-            const uint32_t c = __builtin_amdgcn_ubfe(A[j >> 3], 4 * (j & 7), 3);
-            Eq[jj] = *(const LDS uint32_t *)(uintptr_t)(pbase + (c << 2));
-        }
+    for (int h = 0; h < 4; ++h) {  // the Eq words of the next eight columns fly while these eight are worked on
+        lds_wait8(Eq[h & 1]);
+        if (h < 3) issue(h + 1);
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * h + jj;
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = 8 * h + jj;
             if (j < TF) {
-                sweep_step<false>(Eq[jj], Pv, Mv, score, best);
+                sweep_step<false>(Eq[h & 1][jj], Pv, Mv, score, best);
             } else {
                 if (j == TF && TF > 0) score = __builtin_popcount(Pv) - __builtin_popcount(Mv);
-                sweep_step<true>(Eq[jj], Pv, Mv, score, best);
+                sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
             }
         }
     }
 }
 
-template <int RW, int TF>
+// NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
+// on); Q: seed length
+template <int RW, int TF, int NV, int Q>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
-    constexpr int RCAP = 4;       // sweep records (distinct seeded barcodes) per read
+    constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
     constexpr int HQ = 6 * RW;    // seed hits per tile
-    constexpr int SQ = 3 * RW;    // sweeps per tile
-    constexpr int CH = 8;         // tiles per fetch from the chunk queue
+    constexpr int SQ = 3 * RW;    // sweeps (= records) per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: tile numbers and their geometry live in scalar registers)
     const int B = a.B;
-    const int q = a.q;
+    constexpr int q = Q;  // seed length
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
     size_t o = 0;
@@ -181,30 +209,32 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS unsigned char *bm = take((size_t)a.bm_bytes);  // LDS address 0: a probe's address is its byte index
     LDS uint32_t *hsh = (LDS uint32_t *)take((size_t)4 << a.hash_log2);
     LDS unsigned char *hps = take((size_t)1 << a.hash_log2);
-    LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 32);
+    LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 36);  // 9 dwords per barcode: (9 b + code) mod 32 spreads over every bank
     LDS uint32_t *meta = (LDS uint32_t *)take((size_t)B * 4);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
+    // per-wave work area: the arrays whose size only depends on RW come first, at compile-time offsets from the area's
+    // base (one base register + immediate offsets in the DS instructions), the two images after them
     LDS unsigned char *wbase = smem + o + (size_t)wv * (size_t)a.per_wave;
-    size_t wo = 0;
-    auto wtake = [&](size_t bytes) -> LDS unsigned char * {
-        LDS unsigned char *p = wbase + wo;
-        wo = (wo + bytes + 15) & ~(size_t)15;
-        return p;
-    };
+    constexpr int O_FB = 0;                                  // int[RW + 1]: flat index of every read's first base
+    constexpr int O_HQ = O_FB + ((RW + 1) * 4 + 15) / 16 * 16;  // u32[HQ]: seed hits: flat position << 16 | key
+    constexpr int O_RID = O_HQ + HQ * 4;                     // u32[RW * RCAP]: sweep records: barcode + 1 | (first diagonal + 64) << 16
+    constexpr int O_RMK = O_RID + RW * RCAP * 4;             // u32[RW * RCAP]: diagonals seen, as bits: diagonal - first + kb
+    constexpr int O_SLOTS = O_RMK + RW * RCAP * 4;           // u32[RW * 4]: survivors: barcode << 8 | d
+    constexpr int O_SCNT = O_SLOTS + RW * 16;                // int[RW]
+    constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
+    constexpr int O_RECQ = O_FLAG + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
+    constexpr int O_IMG2 = O_RECQ + SQ * 4;                  // u32[nvec_cap + 2]: 2-bit image
     const int nvec_cap = a.span_cap >> 4;
-    LDS uint32_t *img2 = (LDS uint32_t *)wtake((size_t)(nvec_cap + 2) * 4);
-    LDS uint32_t *img4 = (LDS uint32_t *)wtake((size_t)(2 * nvec_cap + 6) * 4);
-    LDS int *fb = (LDS int *)wtake((size_t)(RW + 1) * 4);          // flat index of every read's first base
-    LDS uint32_t *hq = (LDS uint32_t *)wtake((size_t)HQ * 4);      // seed hits: flat position << 16 | key
-    LDS uint32_t *rid = (LDS uint32_t *)wtake((size_t)RW * RCAP * 4);  // sweep records: barcode + 1
-    LDS int *rlo = (LDS int *)wtake((size_t)RW * RCAP * 4);            //   window start (min)
-    LDS int *rhi = (LDS int *)wtake((size_t)RW * RCAP * 4);            //   window end (max)
-    LDS uint32_t *sq = (LDS uint32_t *)wtake((size_t)SQ * 4);      // sweeps: read << 16 | barcode + 1
-    LDS uint32_t *sw = (LDS uint32_t *)wtake((size_t)SQ * 4);      //   lo << 16 | hi
-    LDS uint32_t *slots = (LDS uint32_t *)wtake((size_t)RW * 4 * 4);  // survivors: barcode << 8 | d
-    LDS int *scnt = (LDS int *)wtake((size_t)RW * 4);
-    LDS int *flag = (LDS int *)wtake((size_t)RW * 4);             // read goes to the list
-    LDS int *cn = (LDS int *)wtake(16);                            // [0] seed hits of the tile
+    LDS int *fb = (LDS int *)(wbase + O_FB);
+    LDS uint32_t *hq = (LDS uint32_t *)(wbase + O_HQ);
+    LDS uint32_t *rid = (LDS uint32_t *)(wbase + O_RID);
+    LDS uint32_t *rmk = (LDS uint32_t *)(wbase + O_RMK);
+    LDS uint32_t *slots = (LDS uint32_t *)(wbase + O_SLOTS);
+    LDS int *scnt = (LDS int *)(wbase + O_SCNT);
+    LDS int *flag = (LDS int *)(wbase + O_FLAG);
+    LDS uint32_t *recq = (LDS uint32_t *)(wbase + O_RECQ);
+    LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
+    LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
@@ -212,85 +242,133 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         hsh[i] = a.hash[i];
         hps[i] = a.hash_ps[i];
     }
-    for (int i = tid; i < B * 8; i += blockDim.x) peq[i] = a.peq8[i];
+    for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
     for (int i = tid; i < B; i += blockDim.x) meta[i] = a.meta[i];
     for (int i = tid; i < a.hist_entries; i += blockDim.x) hist[i] = 0;
     __syncthreads();
 
     const uint32_t peq_base = (uint32_t)(uintptr_t)peq;
-    const long long ntiles = (a.n_reads + RW - 1) / RW;
-    const long long nchunks = (ntiles + CH - 1) / CH;
+    const int ntiles = (int)((a.n_reads + RW - 1) / RW);  // (< 2^29: a batch holds fewer than 2^32 reads)
     const uint32_t hmask = (1u << a.hash_log2) - 1u;
-    const int kw = 2 * q - 3;  // width of a probe's byte address
 
-    int next_chunk = 0;
-    if (lane == 0) next_chunk = atomicAdd(a.tile_counter, 1);
-    for (;;) {
-        const long long chunk = __builtin_amdgcn_readfirstlane(next_chunk);
-        if (chunk >= nchunks) break;
-        if (lane == 0) next_chunk = atomicAdd(a.tile_counter, 1);  // (read at the top of the next trip)
-        for (int ti = 0; ti < CH; ++ti) {
-            const long long tile = chunk * CH + ti;
-            if (tile >= ntiles) break;
-            const long long r0 = tile * RW;
-            const int nr = (int)(a.n_reads - r0 < RW ? a.n_reads - r0 : RW);
-
-            // ---- offsets; flat geometry of the tile's span ----
-            const long long ov = lane <= nr ? a.off[r0 + lane] : 0;
-            const uint32_t ov_lo = (uint32_t)ov, ov_hi = (uint32_t)(ov >> 32);
-            const long long span0 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, 0) << 32) | __builtin_amdgcn_readlane(ov_lo, 0));
-            const long long span1 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, nr) << 32) | __builtin_amdgcn_readlane(ov_lo, nr));
-            const uintptr_t g0 = (uintptr_t)(a.seq + span0);
-            const uintptr_t g0a = g0 & ~(uintptr_t)15;
-            const int head = (int)(g0 - g0a);
-            const long long need = (span1 - span0) + head;
-            const bool tile_ok = need + 16 <= (long long)a.span_cap;  // wave-uniform
-            if (lane <= nr) fb[lane] = tile_ok ? head + (int)(ov - span0) : 0;
-            if (lane < RW) {
-                scnt[lane] = 0;
-                flag[lane] = 0;
-            }
-            for (int i = lane; i < RW * RCAP; i += 64) {
-                rid[i] = 0u;
-                rlo[i] = 0x7FFFFFFF;
-                rhi[i] = 0;
-            }
-            if (lane == 0) cn[0] = 0;
-            const int total = tile_ok ? (int)need : 0;  // flat bases of the tile (head included)
-            const int nvec = (total + 15) >> 4;
-
-            // ---- bytes: HBM -> registers -> 2-bit / 4-bit images ----
-            {
-                const GlobalVec16 src = (GlobalVec16)g0a;
-                for (int k0 = 0; k0 < nvec; k0 += 256) {
-                    u32x4 v[4];
+    // Tiles are dealt round robin over all waves of the grid (tile = wave + k x waves): no queue, no atomics.  The
+    // bytes of tile k + 1 are requested while tile k is worked on, its offsets one tile earlier still, so the HBM
+    // latency of neither is ever at the head of a tile.
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));  // (32-bit: tile numbers stay in scalar registers)
+    int tile = (int)(blockIdx.x * (blockDim.x >> 6)) + wv;
+    // geometry of a tile's span from its offsets (lanes 0 .. nr hold off[r0 + lane]); everything wave-uniform
+    struct Geo {
+        long long span0;
+        uintptr_t g0a;
+        int head, total, nvec, nr;
+        bool ok;
+    };
+    const auto geometry = [&](const int t, const long long ov) -> Geo {
+        Geo g;
+        const long long r0 = (long long)t * RW;
+        g.nr = (int)(a.n_reads - r0 < RW ? a.n_reads - r0 : RW);
+        const uint32_t ov_lo = (uint32_t)ov, ov_hi = (uint32_t)(ov >> 32);
+        g.span0 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, 0) << 32) | __builtin_amdgcn_readlane(ov_lo, 0));
+        const long long span1 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, g.nr) << 32) | __builtin_amdgcn_readlane(ov_lo, g.nr));
+        const uintptr_t g0 = (uintptr_t)(a.seq + g.span0);
+        g.g0a = g0 & ~(uintptr_t)15;
+        g.head = (int)(g0 - g.g0a);
+        const long long need = (span1 - g.span0) + g.head;
+        g.ok = need + 16 <= (long long)a.span_cap && need <= (long long)NV * 1024;  // wave-uniform
+        g.total = g.ok ? (int)need : 0;  // flat bases of the tile (head included)
+        g.nvec = (g.total + 15) >> 4;
+        return g;
+    };
+    const auto load_offsets = [&](const int t) -> long long {  // (t < 2^30 also when it runs past the last tile)
+        const long long r0 = (long long)t * RW;
+        const long long left = a.n_reads - r0;
+        const int cnt = t < ntiles ? (int)(left < RW ? left : RW) : -1;  // lanes 0 .. cnt load
+        // wave-uniform base in scalar registers + a 32-bit lane offset
+        const uintptr_t bp = (uintptr_t)(a.off + r0);
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bp), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+        const long long *base = (const long long *)(((uintptr_t)bhi << 32) | blo);
+        return lane <= cnt ? base[lane] : 0;
+    };
+    u32x4 v[NV];
+    LDS uint32_t *const img2_lane = img2 + lane;      // (one base register each: the unrolled stores differ by immediates)
+    LDS uint32_t *const img4_lane = img4 + 2 * lane;
+    const auto load_bytes = [&](const Geo &g) {
+        const GlobalVec16 src = (GlobalVec16)g.g0a;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = k0 + 64 * u + lane;
-                        if (k < nvec) v[u] = __builtin_nontemporal_load(src + k);
-                    }
+        for (int u = 0; u < NV; ++u) {
+            const int k = 64 * u + lane;
+            if (k < g.nvec && !BDX_DBG(64)) v[u] = __builtin_nontemporal_load(src + k);
+        }
+    };
+    for (int i = lane; i < RW * RCAP; i += 64) {  // (a sweep clears its record: the tables are empty at the top of every tile)
+        rid[i] = 0u;
+        rmk[i] = 0u;
+    }
+    long long ov = load_offsets(tile);
+    Geo geo{};
+    if (tile < ntiles) {
+        geo = geometry(tile, ov);
+        load_bytes(geo);
+    }
+    long long ov_next = load_offsets(tile + nwaves);
+
+    while (tile < ntiles) {
+        const long long r0 = (long long)tile * RW;
+        const int nr = geo.nr;
+        const bool tile_ok = geo.ok;
+        const int total = geo.total, nvec = geo.nvec;
+
+        // ---- per-tile tables ----
+        if (lane <= nr) fb[lane] = tile_ok ? geo.head + (int)(ov - geo.span0) : 0;
+        if (lane < RW) {
+            scnt[lane] = 0;
+            flag[lane] = 0;
+        }
+
+        // ---- bytes (requested one tile ago): registers -> 2-bit / 4-bit images ----
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = k0 + 64 * u + lane;
-                        if (k0 + 64 * u < nvec) {  // wave-uniform
-                            uint32_t p2 = 0, nlo = 0, nhi = 0, sad = 0;
-                            if (k < nvec) pack16<false>(v[u], p2, nlo, nhi, sad);
-                            if (__builtin_amdgcn_ballot_w64(sad != 0)) {  // some byte is neither A, C, G, T nor N (rare)
-                                if (sad != 0) pack16<true>(v[u], p2, nlo, nhi, sad);
-                            }
-                            if (k < nvec) {
-                                img2[k] = p2;
-                                img4[2 * k] = nlo;
-                                img4[2 * k + 1] = nhi;
-                            }
-                        }
-                    }
+        for (int u = 0; u < NV; ++u) {
+            const int k = 64 * u + lane;
+            if (64 * u < nvec) {  // wave-uniform
+                uint32_t p2 = 0, nlo = 0, nhi = 0, sad = 0;
+                if (k < nvec && !BDX_DBG(32)) pack16<false>(v[u], p2, nlo, nhi, sad);
+                if (__builtin_amdgcn_ballot_w64(sad != 0)) {  // some byte is neither A, C, G, T nor N (rare)
+                    if (sad != 0) pack16<true>(v[u], p2, nlo, nhi, sad);
+                }
+                if (k < nvec) {
+                    img2_lane[64 * u] = p2;
+                    *(LDS u32x2 *)(img4_lane + 128 * u) = u32x2{nlo, nhi};
                 }
             }
-            WAVE_SYNC();
+        }
+        // ---- request the next tile's bytes and the offsets of the one after ----
+        const int tile_next = tile + nwaves;
+        Geo geo_next{};
+        if (tile_next < ntiles) {
+            geo_next = geometry(tile_next, ov_next);
+            load_bytes(geo_next);
+        }
+        const long long ov_after = load_offsets(tile_next + nwaves);
+        WAVE_SYNC();
 
-            // ---- seed scan: lane = 16 consecutive flat positions, one bitmap probe per position ----
-            for (int g0i = 0; g0i < nvec; g0i += 64) {
+        // uniform read length of the tile (0: mixed) for the hit -> read mapping
+        int ulen = 0;
+        {
+            const int my = lane < nr ? fb[lane + 1] - fb[lane] : 0;
+            const int l0 = __builtin_amdgcn_readfirstlane(my);
+            ulen = (l0 > 0 && !__builtin_amdgcn_ballot_w64(lane < nr && my != l0)) ? l0 : 0;
+        }
+
+        // ---- seed scan: lane = 16 consecutive flat positions, one bitmap probe per position ----
+        // The bitmap is read as 32-bit words (word = key >> 5 at LDS address 0 + 4 word, bit = key & 31): the shift
+        // that brings the key to bit 0 also is the shift amount of the bit test (the hardware takes its low five bits).
+        int nhq = 0;  // seed hits of the tile so far (wave-uniform)
+        {
+            constexpr uint32_t AMASK = ((1u << (2 * Q - 5)) - 1u) << 2;
+            constexpr uint32_t KMASK = (1u << (2 * Q)) - 1u;
+            uint32_t amask = AMASK;
+            asm volatile("" : "+v"(amask));  // (in a vector register: a literal or scalar operand slows the AND down)
+            for (int g0i = 0; g0i < (BDX_DBG(8) ? 0 : nvec); g0i += 64) {
                 const int g = g0i + lane;
                 uint32_t hits = 0;
                 uint32_t w0 = 0, w1 = 0;
@@ -298,241 +376,300 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     w0 = img2[g];
                     w1 = img2[g + 1];
                     const uint32_t wm = __builtin_amdgcn_alignbit(w1, w0, 16);  // bases 8 .. 23 of the group's window
+                    uint32_t Wk[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const uint32_t src = i <= 8 ? w0 : wm;
-                        const int sh = i <= 8 ? 2 * i : 2 * (i - 8);
-                        const uint32_t addr = __builtin_amdgcn_ubfe(src, sh + 3, kw);
-                        const uint32_t k3 = __builtin_amdgcn_ubfe(src, sh, 3);
-                        const uint32_t byte = *(const LDS unsigned char *)(uintptr_t)addr;
-                        hits |= __builtin_amdgcn_ubfe(byte, k3, 1) << i;
+                    for (int i = 0; i < 16; ++i) Wk[i] = i == 0 ? w0 : (i <= 8 ? w0 >> (2 * i) : wm >> (2 * (i - 8)));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t word[8], addr[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) addr[i] = (Wk[8 * h + i] >> 3) & amask;
+                        lds_read8(word, addr);
+                        lds_wait8(word);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hits = __builtin_amdgcn_alignbit(word[i] >> (Wk[8 * h + i] & 31u), hits, 1);
                     }
+                    hits >>= 16;
                 }
-                if (hits) {
-                    const int cnt = __builtin_popcount(hits);
-                    int k = __hip_atomic_fetch_add(&cn[0], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    while (hits) {
+                // append: one trip per "layer" of hits (the lowest remaining hit of every lane that has one)
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(hits != 0u);
+                while (mk) {
+                    const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    if (hits) {
                         const int i = __builtin_ctz(hits);
                         hits &= hits - 1u;
-                        if (k < HQ)
-                            hq[k] = ((uint32_t)(16 * g + i) << 16) | __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w1, w0, 2 * i), 0, 2 * q);
-                        ++k;
+                        if (k < HQ) hq[k] = ((uint32_t)(16 * g + i) << 16) | (__builtin_amdgcn_alignbit(w1, w0, 2 * i) & KMASK);
                     }
+                    nhq += (int)__builtin_popcountll(mk);
+                    mk = __builtin_amdgcn_ballot_w64(hits != 0u);
                 }
             }
-            WAVE_SYNC();
-            const int nh_all = cn[0];
-            const bool hq_ok = nh_all <= HQ;  // else: the whole tile goes to the list
-            const int nh = hq_ok ? nh_all : 0;
+        }
+        WAVE_SYNC();
+        const bool hq_ok = nhq <= HQ;  // else: the whole tile goes to the list
+        const int nh = (hq_ok && !BDX_DBG(4)) ? nhq : 0;
 
-            // ---- resolve: one lane per hit -> (read, barcode, diagonal) -> the read's record table ----
-            {
-                const float ginv = total > 0 ? (float)nr / (float)total : 0.0f;
-                for (int k = lane; k < nh; k += 64) {
+        // ---- resolve: one lane per hit -> (read, barcode, diagonal) -> the read's record table ----
+        // A record is one (barcode, cluster of diagonals): hits of the barcode whose diagonal lies within kb of the
+        // record's first one are merged into it (the intact pieces of ONE alignment within the budget lie on diagonals
+        // at most kb apart, so they always share a record and its window stays within 32 columns); a hit further away
+        // opens a record of its own — each record's window alone holds every alignment its own hits can belong to, and
+        // the replay takes the smallest of a barcode's entries (bdx_core.h run_pass_known).  The lane that opens a
+        // record appends its slot number to the tile's record list: the records ARE the sweeps.
+        int ns = 0;  // records of the tile so far (wave-uniform)
+        {
+            const int fb0 = fb[0];
+            const float rinv = ulen > 0 ? 1.0f / (float)ulen : 0.0f;
+            const float ginv = total > 0 ? (float)nr / (float)total : 0.0f;
+            for (int k0 = 0; k0 < nh; k0 += 64) {
+                const int k = k0 + lane;
+                int new0 = -1, new1 = -1;  // record slots this lane opened
+                if (k < nh) {
                     const uint32_t h = hq[k];
                     const int pos = (int)(h >> 16);
                     const uint32_t key = h & 0xFFFFu;
-                    int t = (int)((float)pos * ginv);
-                    t = t > nr - 1 ? nr - 1 : t;
-                    while (t > 0 && pos < fb[t]) --t;
-                    while (t < nr - 1 && pos >= fb[t + 1]) ++t;
+                    int t;
+                    bool ok = true;
+                    if (ulen > 0) {
+                        const int x = pos - fb0;
+                        t = (int)((float)x * rinv);
+                        t = t * ulen > x ? t - 1 : t;
+                        t = (t + 1) * ulen <= x ? t + 1 : t;
+                        ok = x >= 0 && t < nr;
+                        t = ok ? t : 0;
+                    } else {
+                        t = (int)((float)pos * ginv);
+                        t = t > nr - 1 ? nr - 1 : t;
+                        while (t > 0 && pos < fb[t]) --t;
+                        while (t < nr - 1 && pos >= fb[t + 1]) ++t;
+                    }
                     const int f0 = fb[t], f1 = fb[t + 1];
                     const int p = pos - f0, n = f1 - f0;
                     // a seed lies inside its read (final_search_range = 1:n for this kernel's configs, classification.jl:795-800)
-                    if (p < 0 || p + q > n) continue;
-                    uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.hash_log2);
-                    for (;;) {
-                        const uint32_t e = hsh[slot];
-                        if (e == 0u) break;
-                        if ((e >> 16) == key) {
-                            const uint32_t pb = e & 0xFFFFu;  // barcode + 1
-                            const uint32_t mt = meta[pb - 1u];
-                            const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
-                            const int diag = p - (int)hps[slot];
-                            int lo = diag - kk - 1, hi = diag + mm + kk + 1;  // [lo, hi): 0-based columns of the sweep
-                            lo = lo < 0 ? 0 : lo;
-                            hi = hi > n ? n : hi;
-                            int rs = (int)(pb & (RCAP - 1));
-                            bool placed = false;
-                            for (int tries = 0; tries < RCAP && !placed; ++tries) {
-                                LDS uint32_t *id = rid + t * RCAP + rs;
-                                uint32_t old = *id;
-                                if (old == 0u) {
-                                    uint32_t expect = 0u;
-                                    __hip_atomic_compare_exchange_strong(id, &expect, pb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    old = expect == 0u ? pb : expect;
+                    if (ok && p >= 0 && p + q <= n) {
+                        uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.hash_log2);
+                        for (;;) {
+                            const uint32_t e = hsh[slot];
+                            if (e == 0u) break;
+                            if ((e >> 16) == key) {
+                                const uint32_t pb = e & 0xFFFFu;  // barcode + 1
+                                const int kk = (int)((meta[pb - 1u] >> 8) & 255u);
+                                const int diag = p - (int)hps[slot];
+                                const uint32_t mine = pb | ((uint32_t)(diag + 64) << 16);
+                                int rs = (int)((pb + (uint32_t)(diag >> 3)) & (RCAP - 1));
+                                bool placed = false;
+                                for (int tries = 0; tries < RCAP && !placed; ++tries) {
+                                    LDS uint32_t *id = rid + t * RCAP + rs;
+                                    uint32_t old = *id;
+                                    bool opened = false;
+                                    if (old == 0u) {
+                                        uint32_t expect = 0u;
+                                        __hip_atomic_compare_exchange_strong(id, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        opened = expect == 0u;
+                                        old = opened ? mine : expect;
+                                    }
+                                    const int dd = diag - ((int)(old >> 16) - 64);
+                                    if ((old & 0xFFFFu) == pb && dd >= -kk && dd <= kk) {
+                                        __hip_atomic_fetch_or(&rmk[t * RCAP + rs], 1u << (dd + kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        placed = true;
+                                        if (opened) {
+                                            if (new0 < 0)
+                                                new0 = t * RCAP + rs;
+                                            else if (new1 < 0)
+                                                new1 = t * RCAP + rs;
+                                            else {  // a third record opened by one hit: not swept, the read goes to the list
+                                                flag[t] = 1;
+                                                rid[t * RCAP + rs] = 0u;
+                                                rmk[t * RCAP + rs] = 0u;
+                                            }
+                                        }
+                                    }
+                                    rs = (rs + 1) & (RCAP - 1);
                                 }
-                                if (old == pb) {
-                                    __hip_atomic_fetch_min(&rlo[t * RCAP + rs], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    __hip_atomic_fetch_max(&rhi[t * RCAP + rs], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    placed = true;
-                                }
-                                rs = (rs + 1) & (RCAP - 1);
+                                if (!placed) flag[t] = 1;  // more than RCAP records in this read
                             }
-                            if (!placed) flag[t] = 1;  // more than RCAP distinct barcodes seeded in this read
+                            slot = (slot + 1) & hmask;
                         }
-                        slot = (slot + 1) & hmask;
                     }
                 }
-            }
-            WAVE_SYNC();
-
-            // ---- emit: occupied records -> sweep queue (wave prefix over the ballot) ----
-            int ns = 0;  // wave-uniform
-            for (int i0 = 0; i0 < RW * RCAP; i0 += 64) {
-                const int idx = i0 + lane;
-                const uint32_t pb = idx < RW * RCAP ? rid[idx] : 0u;
-                const int lo = idx < RW * RCAP ? rlo[idx] : 0, hi = idx < RW * RCAP ? rhi[idx] : 0;
-                const bool has = pb != 0u && hi > lo;
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
-                const int kq = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                if (has) {
-                    const int t = idx / RCAP;
-                    if (kq < SQ) {
-                        sq[kq] = ((uint32_t)t << 16) | pb;
-                        sw[kq] = ((uint32_t)lo << 16) | (uint32_t)hi;
-                    } else {
-                        flag[t] = 1;
-                    }
-                }
-                ns += (int)__builtin_popcountll(mk);
-            }
-            ns = ns < SQ ? ns : SQ;
-            WAVE_SYNC();
-
-            // ---- sweeps: lane = one (read, barcode, window) ----
-            for (int s0 = 0; s0 < ns; s0 += 64) {
-                const int k = s0 + lane;
-                const bool valid = k < ns;
-                const uint32_t e = valid ? sq[k] : 0u, wn = valid ? sw[k] : 0u;
-                const int t = (int)(e >> 16), b = valid ? (int)(e & 0xFFFFu) - 1 : 0;
-                const int lo = (int)(wn >> 16), hi = (int)(wn & 0xFFFFu);
-                const int ncol = valid ? hi - lo : 0;
-                const uint32_t mt = meta[b];
-                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
-                uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
-                uint32_t Mv = 0;
-                int score = mm, best = 0x7FFFFFFF;
-                const uint32_t pbase = peq_base + (uint32_t)b * 32u;
-                const int sb0 = fb[t] + lo;  // flat index of the window's first base
-                for (int blk = 0;; ++blk) {
-                    const int rem = ncol - 32 * blk;
-                    if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
-                    const int sb = sb0 + 32 * blk;
-                    const int d0 = sb >> 3, shb = (sb & 7) * 4;
-                    uint32_t W[5];
+                // the slots opened in this round -> the record list (at most two layers)
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) W[u] = valid ? img4[d0 + u] : 0u;
-                    uint32_t A[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
-                        // columns beyond the window become "other" symbols: they match no barcode row, and a column that
-                        // matches nothing never lowers the running minimum (D[i][j] >= D[i][j-1] for every row)
-                        const int nv = rem - 8 * u;
-                        const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
-                        A[u] |= junk;
-                    }
-                    if (blk == 0)
-                        sweep_block<TF>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
-                    else
-                        sweep_block<0>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
-                }
-                if (valid && best <= kk) {
-                    const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
-                }
-            }
-            WAVE_SYNC();
-
-            // ---- verdicts: lane = read; reducer replay on the survivors' unit distances ----
-            const bool active = lane < nr;
-            const long long ridx = r0 + lane;
-            Verdict v{0, 0, -1, -1};
-            PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
-            bool done = false;
-            if (active && tile_ok && hq_ok) {
-                const int n = fb[lane + 1] - fb[lane];
-                const int cnt = scnt[lane];
-                // known-score class per read: this kernel only runs for configs whose ranges resolve to
-                // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
-                if (!flag[lane] && cnt <= 4 && n >= 1) {
-                    const LDS uint32_t *e0 = slots + lane * 4;
-                    const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
-                    const KnownPass kn1{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
-                    const auto m0 = [&](const int bb) { return (int)(meta[bb] & 255u); };
-                    BdxDevCfg cfg;  // (only the fields the replay reads; single pass)
-                    cfg.is_dual = 0;
-                    cfg.max_error_rate = a.max_error_rate;
-                    cfg.min_delta = a.min_delta;
-                    classify_known(cfg, m0, m0, n, kn0, kn1, v, p1, p2);
-                    done = true;
-                    if (a.tier) {
-                        // tier settle rule (same code as bdx_bitpar.hip)
-                        const bool nd = a.min_delta == 0.0;
-                        bool ok = cnt >= 1 && (p1.score < a.tier_slo);
-                        if (ok && !nd) {
-                            ok = (cnt >= 2 && p1.sub <= a.tier_slo) ||
-                                 (a.out.pass_delta == nullptr && (a.tier_slo - p1.score) >= a.min_delta && p1.status == 1);
+                for (int layer = 0; layer < 2; ++layer) {
+                    const int nw = layer == 0 ? new0 : new1;
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(nw >= 0);
+                    if (mk) {
+                        const int kq = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        if (nw >= 0) {
+                            if (kq < SQ) {
+                                recq[kq] = (uint32_t)nw;
+                            } else {  // more records than the tile's sweep list holds: this read goes to the list
+                                flag[nw / RCAP] = 1;
+                                rid[nw] = 0u;
+                                rmk[nw] = 0u;
+                            }
                         }
-                        done = ok;
+                        ns += (int)__builtin_popcountll(mk);
                     }
                 }
             }
-            {
-                const bool hand = active && !done;
-                const unsigned long long mk = __builtin_amdgcn_ballot_w64(hand);
-                if (mk) {
-                    const int leader = __builtin_ctzll(mk);
-                    unsigned int basek = 0;
-                    if (lane == leader) basek = atomicAdd(a.list_count, (unsigned int)__builtin_popcountll(mk));
-                    basek = (unsigned int)__builtin_amdgcn_readlane((int)basek, leader);
-                    if (hand) a.list[basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)ridx;
-                }
-            }
-            if (done) {
-                if (a.out.bc1) a.out.bc1[ridx] = v.bc1;
-                if (a.out.bc2) a.out.bc2[ridx] = v.bc2;
-                if (a.out.keep_start) a.out.keep_start[ridx] = v.keep_start;
-                if (a.out.keep_end) a.out.keep_end[ridx] = v.keep_end;
-                if (a.out.pass_start) {
-                    a.out.pass_start[2 * ridx] = p1.start;
-                    a.out.pass_start[2 * ridx + 1] = p2.start;
-                }
-                if (a.out.pass_end) {
-                    a.out.pass_end[2 * ridx] = p1.end;
-                    a.out.pass_end[2 * ridx + 1] = p2.end;
-                }
-                if (a.out.pass_raw) {
-                    a.out.pass_raw[2 * ridx] = p1.raw;
-                    a.out.pass_raw[2 * ridx + 1] = p2.raw;
-                }
-                if (a.out.pass_bc) {
-                    a.out.pass_bc[2 * ridx] = p1.bc;
-                    a.out.pass_bc[2 * ridx + 1] = p2.bc;
-                }
-                if (a.out.pass_score) {
-                    a.out.pass_score[2 * ridx] = p1.score;
-                    a.out.pass_score[2 * ridx + 1] = p2.score;
-                }
-                if (a.out.pass_delta) {
-                    a.out.pass_delta[2 * ridx] = p1.delta;
-                    a.out.pass_delta[2 * ridx + 1] = p2.delta;
-                }
-                // DemuxStats scalar counters (classification.jl:942-978), accumulated in LDS across the workgroup's tiles
-                if (a.counts) {
-                    const int slot = v.bc1 > 0 ? 4 + (v.bc1 - 1) * a.counts_stride2 : -1;
-                    const int cls = v.bc1 > 0 ? 1 : (v.bc1 == 0 ? 2 : 3);
-                    __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (slot >= 0 && slot < a.hist_entries)
-                        __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else if (slot >= 0)
-                        atomicAdd(&a.counts[slot], 1ULL);
-                }
-            }
-            WAVE_SYNC();  // the next tile reuses the per-read tables
         }
+        ns = ns < SQ ? ns : SQ;
+        if (BDX_DBG(2)) ns = 0;
+        WAVE_SYNC();
+
+        // ---- sweeps: lane = one record = one (read, barcode, window) ----
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int k = s0 + lane;
+            bool valid = k < ns;
+            const uint32_t rslot = valid ? recq[k] : 0u;
+            const uint32_t id = valid ? rid[rslot] : 0u;
+            const uint32_t dmk = valid ? rmk[rslot] : 0u;
+            if (valid) {  // the record is consumed
+                rid[rslot] = 0u;
+                rmk[rslot] = 0u;
+            }
+            valid = valid && id != 0u && dmk != 0u;
+            const int t = (int)(rslot / RCAP), b = valid ? (int)(id & 0xFFFFu) - 1 : 0;
+            const uint32_t mt = meta[b];
+            const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
+            int lo = 0, hi = 0;  // [lo, hi): 0-based columns of the sweep
+            if (valid) {
+                const int d0 = (int)(id >> 16) - 64;
+                const int dmin = d0 + __builtin_ctz(dmk) - kk, dmax = d0 + (31 - __builtin_clz(dmk)) - kk;
+                const int n = fb[t + 1] - fb[t];
+                lo = dmin - kk - 1;
+                hi = dmax + mm + kk + 1;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > n ? n : hi;
+            }
+            valid = valid && hi > lo;
+            const int ncol = valid ? hi - lo : 0;
+            uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
+            uint32_t Mv = 0;
+            int score = mm, best = 0x7FFFFFFF;
+            const uint32_t pbase = peq_base + (uint32_t)b * 36u;
+            const int sb0 = fb[t] + lo;  // flat index of the window's first base
+            for (int blk = 0;; ++blk) {
+                const int rem = ncol - 32 * blk;
+                if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
+                const int sb = sb0 + 32 * blk;
+                const int d0 = sb >> 3, shb = (sb & 7) * 4;
+                uint32_t W[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) W[u] = valid ? img4[d0 + u] : 0u;
+                uint32_t A[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
+                    // columns beyond the window become "other" symbols: they match no barcode row, and a column that
+                    // matches nothing never lowers the running minimum (D[i][j] >= D[i][j-1] for every row)
+                    const int nv = rem - 8 * u;
+                    const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
+                    A[u] |= junk;
+                }
+                if (blk == 0)
+                    sweep_block<TF>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
+                else
+                    sweep_block<0>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
+            }
+            if (valid && best <= kk) {
+                const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
+            }
+        }
+        WAVE_SYNC();
+
+        // ---- verdicts: lane = read; reducer replay on the survivors' unit distances ----
+        const bool active = lane < nr;
+        const long long ridx = r0 + lane;
+        Verdict vd{0, 0, -1, -1};
+        PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
+        bool done = false;
+        if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
+            const int n = fb[lane + 1] - fb[lane];
+            const int cnt = scnt[lane];
+            // known-score class per read: this kernel only runs for configs whose ranges resolve to
+            // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
+            if (!flag[lane] && cnt <= 4 && n >= 1) {
+                const LDS uint32_t *e0 = slots + lane * 4;
+                const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
+                const KnownPass kn1{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+                const auto m0 = [&](const int bb) { return (int)(meta[bb] & 255u); };
+                BdxDevCfg cfg;  // (only the fields the replay reads; single pass)
+                cfg.is_dual = 0;
+                cfg.max_error_rate = a.max_error_rate;
+                cfg.min_delta = a.min_delta;
+                classify_known(cfg, m0, m0, n, kn0, kn1, vd, p1, p2);
+                done = true;
+                if (a.tier) {
+                    // tier settle rule (same code as bdx_bitpar.hip)
+                    const bool nd = a.min_delta == 0.0;
+                    bool ok = cnt >= 1 && (p1.score < a.tier_slo);
+                    if (ok && !nd) {
+                        ok = (cnt >= 2 && p1.sub <= a.tier_slo) ||
+                             (a.out.pass_delta == nullptr && (a.tier_slo - p1.score) >= a.min_delta && p1.status == 1);
+                    }
+                    done = ok;
+                }
+            }
+        }
+        {
+            const bool hand = active && !done && !BDX_DBG(1);
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(hand);
+            if (mk) {
+                const int leader = __builtin_ctzll(mk);
+                unsigned int basek = 0;
+                if (lane == leader) basek = atomicAdd(a.list_count, (unsigned int)__builtin_popcountll(mk));
+                basek = (unsigned int)__builtin_amdgcn_readlane((int)basek, leader);
+                if (hand) a.list[basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)ridx;
+            }
+        }
+        if (done) {
+            if (a.out.bc1) a.out.bc1[ridx] = vd.bc1;
+            if (a.out.bc2) a.out.bc2[ridx] = vd.bc2;
+            if (a.out.keep_start) a.out.keep_start[ridx] = vd.keep_start;
+            if (a.out.keep_end) a.out.keep_end[ridx] = vd.keep_end;
+            if (a.out.pass_start) {
+                a.out.pass_start[2 * ridx] = p1.start;
+                a.out.pass_start[2 * ridx + 1] = p2.start;
+            }
+            if (a.out.pass_end) {
+                a.out.pass_end[2 * ridx] = p1.end;
+                a.out.pass_end[2 * ridx + 1] = p2.end;
+            }
+            if (a.out.pass_raw) {
+                a.out.pass_raw[2 * ridx] = p1.raw;
+                a.out.pass_raw[2 * ridx + 1] = p2.raw;
+            }
+            if (a.out.pass_bc) {
+                a.out.pass_bc[2 * ridx] = p1.bc;
+                a.out.pass_bc[2 * ridx + 1] = p2.bc;
+            }
+            if (a.out.pass_score) {
+                a.out.pass_score[2 * ridx] = p1.score;
+                a.out.pass_score[2 * ridx + 1] = p2.score;
+            }
+            if (a.out.pass_delta) {
+                a.out.pass_delta[2 * ridx] = p1.delta;
+                a.out.pass_delta[2 * ridx + 1] = p2.delta;
+            }
+            // DemuxStats scalar counters (classification.jl:942-978), accumulated in LDS across the workgroup's tiles
+            if (a.counts) {
+                const int slot = vd.bc1 > 0 ? 4 + (vd.bc1 - 1) * a.counts_stride2 : -1;
+                const int cls = vd.bc1 > 0 ? 1 : (vd.bc1 == 0 ? 2 : 3);
+                __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (slot >= 0 && slot < a.hist_entries)
+                    __hip_atomic_fetch_add(&hist[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (slot >= 0)
+                    atomicAdd(&a.counts[slot], 1ULL);
+            }
+        }
+        WAVE_SYNC();  // the next tile reuses the per-read tables
+        tile = tile_next;
+        geo = geo_next;
+        ov = ov_next;
+        ov_next = ov_after;
     }
 
     if (a.counts) {
@@ -544,17 +681,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF>
+template <int RW, int TF, int NV, int Q>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -563,22 +700,22 @@ hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long block
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
-    return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 32) +
+    return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 36) +
            al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
 size_t bdx_wave_area_bytes(int rw, int span_cap) {
-    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t nvec = (size_t)span_cap >> 4;
-    size_t o = al((nvec + 2) * 4) + al((2 * nvec + 6) * 4) + al((size_t)(rw + 1) * 4) + al((size_t)6 * rw * 4) + 3 * al((size_t)rw * 4 * 4) +
-               2 * al((size_t)3 * rw * 4) + al((size_t)rw * 16) + 2 * al((size_t)rw * 4) + al(16);
+    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 2 * (size_t)rw * 4 + (size_t)3 * rw * 4;
+    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
     return (o + 31) & ~(size_t)31;
 }
 
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream) {
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg) {
     if (n_reads <= 0) return hipSuccess;
+    (void)d_tile_counter;  // (tiles are dealt round robin: no queue)
     WaveArgs a;
     a.max_error_rate = cfg.max_error_rate;
     a.min_delta = cfg.min_delta;
@@ -600,23 +737,26 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.q = wp.q;
     a.span_cap = wp.span_cap;
     a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap);
-    a.tile_counter = d_tile_counter;
     a.tier = tier1;
     a.tier_slo = tier_slo;
     a.list = list;
     a.list_count = list_count;
+    a.dbg = dbg;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
     long long blocks = (long long)wp.blocks;
-    const long long useful = (tiles + 8LL * wp.waves - 1) / (8LL * wp.waves);  // a wave fetches chunks of 8 tiles
+    const long long useful = (tiles + wp.waves - 1) / wp.waves;  // one tile per wave at least
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
     const int tf = wp.track_from;
-#define BDX_WAVE_TF(RWV)                                                                 \
-    return tf >= 20 ? launch_wave<RWV, 20>(a, lds, wp.waves, blocks, stream)              \
-           : tf >= 12 ? launch_wave<RWV, 12>(a, lds, wp.waves, blocks, stream)            \
-           : tf >= 4 ? launch_wave<RWV, 4>(a, lds, wp.waves, blocks, stream)              \
-                     : launch_wave<RWV, 0>(a, lds, wp.waves, blocks, stream)
+    // instantiated: seeds of 8 bases with every score-tracking start, 7 and 6 bases with the plain ones
+#define BDX_WAVE_NV(RWV, TFV, QV)                                                                   \
+    (wp.span_cap <= 5 * 1024 ? launch_wave<RWV, TFV, 5, QV>(a, lds, wp.waves, blocks, stream)           \
+                             : launch_wave<RWV, TFV, 10, QV>(a, lds, wp.waves, blocks, stream))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
     switch (wp.rw) {
         case 32:
             BDX_WAVE_TF(32);
@@ -627,5 +767,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
         default:
             return hipErrorInvalidValue;
     }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
 #undef BDX_WAVE_TF
 }
