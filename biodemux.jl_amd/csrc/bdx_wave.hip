@@ -223,7 +223,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int O_SCNT = O_SLOTS + RW * 16;                // int[RW]
     constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
     constexpr int O_RECQ = O_FLAG + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
-    constexpr int O_IMG2 = O_RECQ + SQ * 4;                  // u32[nvec_cap + 2]: 2-bit image
+    constexpr int O_LBUF = O_RECQ + SQ * 4;                  // u32[64]: reads for the list, flushed in batches
+    constexpr int O_IMG2 = O_LBUF + 64 * 4;                  // u32[nvec_cap + 2]: 2-bit image
     const int nvec_cap = a.span_cap >> 4;
     LDS int *fb = (LDS int *)(wbase + O_FB);
     LDS uint32_t *hq = (LDS uint32_t *)(wbase + O_HQ);
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS int *scnt = (LDS int *)(wbase + O_SCNT);
     LDS int *flag = (LDS int *)(wbase + O_FLAG);
     LDS uint32_t *recq = (LDS uint32_t *)(wbase + O_RECQ);
+    LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
     LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
 
@@ -304,6 +306,18 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         rid[i] = 0u;
         rmk[i] = 0u;
     }
+    int lcnt = 0;  // entries waiting in lbuf (wave-uniform)
+    const auto flush_list = [&]() {
+        if (lcnt > 0) {
+            WAVE_SYNC();
+            unsigned int basek = 0;
+            if (lane == 0) basek = atomicAdd(a.list_count, (unsigned int)lcnt);
+            basek = (unsigned int)__builtin_amdgcn_readfirstlane((int)basek);
+            if (lane < lcnt) a.list[basek + lane] = lbuf[lane];
+            WAVE_SYNC();
+            lcnt = 0;
+        }
+    };
     long long ov = load_offsets(tile);
     Geo geo{};
     if (tile < ntiles) {
@@ -514,7 +528,6 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
         }
         ns = ns < SQ ? ns : SQ;
-        if (BDX_DBG(2)) ns = 0;
         WAVE_SYNC();
 
         // ---- sweeps: lane = one record = one (read, barcode, window) ----
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 lo = lo < 0 ? 0 : lo;
                 hi = hi > n ? n : hi;
             }
-            valid = valid && hi > lo;
+            valid = valid && hi > lo && !BDX_DBG(2);
             const int ncol = valid ? hi - lo : 0;
             uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
             uint32_t Mv = 0;
@@ -614,14 +627,16 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
         }
         {
+            // reads for the list: collected in LDS and handed over in batches — one returning global atomic per batch
+            // (same-address atomics retire one per ~10 ns chip-wide, and waiting for the returned value also waits for
+            // the byte loads of the next tile that are in flight)
             const bool hand = active && !done && !BDX_DBG(1);
             const unsigned long long mk = __builtin_amdgcn_ballot_w64(hand);
             if (mk) {
-                const int leader = __builtin_ctzll(mk);
-                unsigned int basek = 0;
-                if (lane == leader) basek = atomicAdd(a.list_count, (unsigned int)__builtin_popcountll(mk));
-                basek = (unsigned int)__builtin_amdgcn_readlane((int)basek, leader);
-                if (hand) a.list[basek + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)ridx;
+                const int n_new = (int)__builtin_popcountll(mk);
+                if (lcnt + n_new > 64) flush_list();
+                if (hand) lbuf[lcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint32_t)ridx;
+                lcnt += n_new;
             }
         }
         if (done) {
@@ -672,6 +687,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         ov_next = ov_after;
     }
 
+    flush_list();
     if (a.counts) {
         __syncthreads();
         for (int i = tid; i < a.hist_entries; i += blockDim.x) {
@@ -706,7 +722,7 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
 
 size_t bdx_wave_area_bytes(int rw, int span_cap) {
     const size_t nvec = (size_t)span_cap >> 4;
-    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 2 * (size_t)rw * 4 + (size_t)3 * rw * 4;
+    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 2 * (size_t)rw * 4 + (size_t)3 * rw * 4 + 256;
     const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
     return (o + 31) & ~(size_t)31;
 }
