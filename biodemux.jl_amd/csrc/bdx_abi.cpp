@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <string>
 #include <thread>
@@ -16,6 +17,7 @@
 #include "bdx_ctx.h"
 
 thread_local std::string g_create_error;
+static std::atomic<long long> g_rejected_windows{0};  // summed over the contexts destroyed so far (see bdx_debug_rejected_windows_total)
 
 int bdx_fail(bdx_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -44,6 +46,7 @@ BdxTuning read_tuning() {
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_wave = getenv("BDX_NO_WAVE") != nullptr;
+    t.poison = getenv("BDX_POISON") != nullptr;
     if (const char *e = getenv("BDX_WAVE_RW")) t.wave_rw = atoi(e);
     if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
     if (const char *e = getenv("BDX_CU_COUNT")) t.cu_count = atoi(e);
@@ -985,7 +988,15 @@ int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // zeroing and copying run on the context's stream (the kernels that add to the tables do, and a non-blocking or
+    // caller-supplied stream has no implicit order with the NULL stream); old tables are freed after one more sync
     const int npass = ctx->dev.is_dual ? 2 : 1;
+    std::vector<DevBuf> retired;
+    auto retire_all = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (DevBuf &b : retired) b.release();
+        retired.clear();
+    };
     if (!ctx->st_len_fixed) {
         // the transposed len table grows by its key stride: every barcode's run of counters moves to the new pitch
         const int old_stride = bdx_stats_stride(ctx, 1);
@@ -996,16 +1007,17 @@ int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
             const size_t B = (size_t)ctx->dev.pass[p].n_barcodes;
             DevBuf nb;
             hipError_t e1 = nb.ensure((size_t)new_stride * B * 8);
-            if (e1 == hipSuccess) e1 = hipMemset(nb.p, 0, (size_t)new_stride * B * 8);
+            if (e1 == hipSuccess) e1 = hipMemsetAsync(nb.p, 0, (size_t)new_stride * B * 8, ctx->stream);
             if (e1 == hipSuccess && old_rows > 0 && ctx->st_tab[p][1].p)
-                e1 = hipMemcpy2D(nb.p, (size_t)new_stride * 8, ctx->st_tab[p][1].p, (size_t)old_stride * 8, (size_t)old_stride * 8, B,
-                                 hipMemcpyDeviceToDevice);
+                e1 = hipMemcpy2DAsync(nb.p, (size_t)new_stride * 8, ctx->st_tab[p][1].p, (size_t)old_stride * 8, (size_t)old_stride * 8, B,
+                                      hipMemcpyDeviceToDevice, ctx->stream);
             if (e1 != hipSuccess) {
+                retire_all();
                 nb.release();
                 ctx->st_len_rows = old_rows;
                 return fail(ctx, BDX_E_DEVICE, "growing the statistics tables failed: %s", hipGetErrorString(e1));
             }
-            ctx->st_tab[p][1].release();
+            retired.push_back(ctx->st_tab[p][1]);
             ctx->st_tab[p][1] = nb;
         }
     }
@@ -1014,16 +1026,18 @@ int bdx_stats_reserve(bdx_ctx *ctx, long long rows, bool exact) {
             const size_t old_bytes = bdx_stats_phys_words(ctx, p, w, ctx->st_rows) * 8;
             const size_t new_bytes = bdx_stats_phys_words(ctx, p, w, want) * 8;
             DevBuf nb;
-            HIP_TRY(ctx, nb.ensure(new_bytes));
-            hipError_t e1 = hipMemset(nb.p, 0, new_bytes);
-            if (e1 == hipSuccess && old_bytes) e1 = hipMemcpy(nb.p, ctx->st_tab[p][w].p, old_bytes, hipMemcpyDeviceToDevice);
+            hipError_t e1 = nb.ensure(new_bytes);
+            if (e1 == hipSuccess) e1 = hipMemsetAsync(nb.p, 0, new_bytes, ctx->stream);
+            if (e1 == hipSuccess && old_bytes) e1 = hipMemcpyAsync(nb.p, ctx->st_tab[p][w].p, old_bytes, hipMemcpyDeviceToDevice, ctx->stream);
             if (e1 != hipSuccess) {
+                retire_all();
                 nb.release();
                 return fail(ctx, BDX_E_DEVICE, "growing the statistics tables failed: %s", hipGetErrorString(e1));
             }
-            ctx->st_tab[p][w].release();
+            retired.push_back(ctx->st_tab[p][w]);
             ctx->st_tab[p][w] = nb;  // row-major by key: the old table is a prefix of the new one
         }
+    retire_all();
     ctx->st_rows = want;
     return BDX_OK;
 }
@@ -1056,10 +1070,11 @@ int init_stats(bdx_ctx *ctx) {
         for (int w = (ctx->st_len_fixed ? 1 : 2); w < 3; ++w) {
             const size_t bytes = bdx_stats_phys_words(ctx, p, w, 0) * 8;
             HIP_TRY(ctx, ctx->st_tab[p][w].ensure(bytes));
-            HIP_TRY(ctx, hipMemset(ctx->st_tab[p][w].p, 0, bytes));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->st_tab[p][w].p, 0, bytes, ctx->stream));
         }
     HIP_TRY(ctx, ctx->st_flag.ensure(256));
-    HIP_TRY(ctx, hipMemset(ctx->st_flag.p, 0, 256));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st_flag.p, 0, 256, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (ordered on the stream the kernels use, and done before create returns)
     return BDX_OK;
 }
 
@@ -1102,6 +1117,10 @@ static int run_and_download(bdx_ctx *ctx, const uint8_t *d_seq, const int64_t *d
     }
     HIP_TRY(ctx, ctx->d_out_i32.ensure(n * 4 * 12));
     HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
+    if (ctx->tune.poison) {  // test switch: an output element no kernel writes comes back as garbage, never as a stale right answer
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_out_i32.p, 0xA5, n * 4 * 12, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_out_f64.p, 0xA5, n * 8 * 4, ctx->stream));
+    }
     int32_t *bi = (int32_t *)ctx->d_out_i32.p;
     bdx_outputs_t d{};
     d.bc1 = bi;
@@ -1175,26 +1194,8 @@ static int classify_host_pipelined(bdx_ctx *ctx, const uint8_t *seq_bytes, const
     HIP_TRY(ctx, ctx->d_out_f64.ensure(n * 8 * 4));
     int32_t *bi = (int32_t *)ctx->d_out_i32.p;
     double *bf = (double *)ctx->d_out_f64.p;
-    // the longest read, on a few host threads (a device-side measurement per chunk would synchronise the stream and
-    // undo the overlap)
-    {
-        const size_t nthr = 8;
-        std::vector<int64_t> mx(nthr, 0);
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nthr; ++t)
-            th.emplace_back([&, t]() {
-                int64_t m = 0;
-                for (size_t i = n * t / nthr; i < n * (t + 1) / nthr; ++i) {
-                    const int64_t d = seq_off[i + 1] - seq_off[i];
-                    m = d > m ? d : m;
-                }
-                mx[t] = m;
-            });
-        for (std::thread &x : th) x.join();
-        int64_t m = 1;
-        for (int64_t v : mx) m = v > m ? v : m;
-        ctx->host_maxlen = (int)(m > (1LL << 30) ? (1LL << 30) : m);
-    }
+    // (the longest read is known: bdx_classify_host has scanned the offsets — a device-side measurement per chunk would
+    // synchronise the stream and undo the overlap)
     struct Reset {
         bdx_ctx *c;
         ~Reset() { c->host_maxlen = 0; }
@@ -1250,6 +1251,43 @@ static int classify_host_pipelined(bdx_ctx *ctx, const uint8_t *seq_bytes, const
 // setup of bdx_bitpar.hip): the 0-based half-open byte range [ulo, uhi) of a read of n code units that ANY pass may
 // touch — final_search_range first:last per pass (classification.jl:795-809), + max_m - 1 beyond the last start
 // position for :hamming / :exact.
+// Longest read and monotonicity of a host offset vector (threads for large batches: the pass is memory-bound).
+static bool scan_offsets(const int64_t *seq_off, int64_t n_reads, int64_t &mx_out, bool &monotone_out) {
+    const int nt = n_reads > 262144 ? 8 : 1;
+    std::vector<int64_t> mx((size_t)nt, 0);
+    std::vector<char> bad((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t lo = n_reads * t / nt, hi = n_reads * (t + 1) / nt;
+        int64_t m = 0;
+        bool neg = false;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t d = seq_off[i + 1] - seq_off[i];
+            neg |= d < 0;
+            m = d > m ? d : m;
+        }
+        mx[(size_t)t] = m;
+        bad[(size_t)t] = neg ? 1 : 0;
+    };
+    try {
+        if (nt == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+    } catch (...) {
+        return false;
+    }
+    mx_out = 0;
+    monotone_out = true;
+    for (int t = 0; t < nt; ++t) {
+        mx_out = mx[(size_t)t] > mx_out ? mx[(size_t)t] : mx_out;
+        monotone_out = monotone_out && !bad[(size_t)t];
+    }
+    return true;
+}
+
 static void host_union_window(const BdxDevCfg &cfg, long long n_ll, long long &ulo, long long &uhi) {
     const long long n = n_ll > (1LL << 30) ? (1LL << 30) : n_ll;
     const auto resolve = [&](const BdxDevRange &dr, long long &first, long long &last) {
@@ -1417,6 +1455,11 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     }
     rc = upload_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
+    if (ctx->d_dbg.ensure(256) != hipSuccess || hipMemset(ctx->d_dbg.p, 0, 256) != hipSuccess) {
+        ctx->err = "hipMalloc failed";
+        return bail(BDX_E_DEVICE);
+    }
+    ctx->dev.dbg_rejected = (unsigned int *)ctx->d_dbg.p;
     rc = plan_generic(ctx);  // needs the caller's host tables: run before they are dropped
     if (rc != BDX_OK) return bail(rc);
     ctx->plan.n_cu = ctx->n_cu;
@@ -1551,6 +1594,11 @@ void bdx_destroy(bdx_ctx *ctx) {
             if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+    if (ctx->d_dbg.p) {
+        unsigned int rej[2] = {0, 0};
+        if (hipMemcpy(rej, ctx->d_dbg.p, sizeof rej, hipMemcpyDeviceToHost) == hipSuccess) g_rejected_windows += (long long)rej[0] + rej[1];
+    }
+    ctx->d_dbg.release();
     for (int k = 0; k < 2; ++k) {
         ctx->bc_bytes[k].release();
         ctx->bc_off[k].release();
@@ -1727,6 +1775,18 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, ctx->d_exc.ensure((size_t)n_reads * 4 + 64));
             exc_list = (uint32_t *)ctx->d_exc.p;
         }
+        if (ctx->tune.poison) {
+            // test switch: whatever a consumer reads without a producer having written it is garbage on EVERY run
+            if (tiered) HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
+            if (ctx->fs[0].wplan.enabled) HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            // every hand-over buffer is filled with 0xA5; between each producer and its consumer a checker kernel
+            // (bdx_poison_check_kernel) then looks at exactly the elements the consumer is going to read — an element that
+            // still holds the fill was never written: counted (bdx_rejected_windows) and made harmless
+            DevBuf *bufs[] = {&ctx->d_cand[0], &ctx->d_cand[1], &ctx->d_wins[0], &ctx->d_wins[1], &ctx->d_wcnt[0], &ctx->d_wcnt[1],
+                              &ctx->d_exc, &ctx->d_tier, &ctx->d_wlist};
+            for (DevBuf *b : bufs)
+                if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, ctx->stream));
+        }
         if (!ctx->scratch_zeroed) HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
         ctx->scratch_zeroed = false;
         // restricted runs of passes that only report score (+ end) through the clean-class DP start m + kb columns before
@@ -1757,6 +1817,20 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 dv.band_lb[k] = short_lb[k] ? ctx->dev.max_m + kb : 2 * (ctx->dev.max_m + kb) + 1;
             }
             return dv;
+        };
+        // test switch BDX_POISON: between a producer and its consumer, every element the consumer will read must have
+        // been written (bdx_poison_check_kernel); `with_windows`: also the window hand-over of both passes for these reads
+        const auto poison_check = [&](uint32_t *list, const unsigned int *count, bool check_list, bool with_windows) -> hipError_t {
+            if (!ctx->tune.poison) return hipSuccess;
+            unsigned int *dbg = (unsigned int *)ctx->d_dbg.p;
+            if (!with_windows || !windows)
+                return list ? bdx_launch_poison_check(list, count, n_reads, nullptr, nullptr, nullptr, 0, 0, check_list ? 1 : 0, dbg, ctx->stream) : hipSuccess;
+            for (int k = 0; k < npass; ++k) {
+                hipError_t e = bdx_launch_poison_check(list, count, n_reads, k ? w1 : w0, k ? n1 : n0, k ? c1 : c0, ctx->dev.pass[k].cand_words,
+                                                       ctx->dev.pass[k].n_barcodes, (check_list && k == 0) ? 1 : 0, dbg, ctx->stream);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
         };
         BdxTierArgs t0{0, nullptr, nullptr, nullptr, nullptr};
         // Wave-autonomous kernel (bdx_wave.hip) in front of the general one: it answers the reads of the known-score
@@ -1794,6 +1868,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             } else
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
                                            o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0, n1, split ? 1 : 0, exc_list, exc_count, &t1));
+            if (split) HIP_TRY(ctx, poison_check(nullptr, nullptr, false, true));
             if (split)  // the exact kernel answers what tier 1 settles and lists the rest (known-score configs: the fused kernel did)
                 HIP_TRY(ctx, bdx_launch_generic(band_cfg(f1), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o, ctx->counts,
                                                 c0, npass > 1 ? c1 : nullptr, ctx->stream, w0, npass > 1 ? w1 : nullptr, n0,
@@ -1803,6 +1878,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_list = (const uint32_t *)ctx->d_tier.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
+        if (tiered || wave0) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false));
         ctx->F().bplan.d_tile_counter = (int *)(scratch + 64);
         ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
@@ -1810,6 +1886,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
                                        n1, split ? 1 : 0, exc_list, exc_count, (tiered || wave0) ? &t0 : nullptr));
+        if (split)
+            HIP_TRY(ctx, poison_check(tiered ? (uint32_t *)t0.in_list : nullptr, tiered ? t0.in_count : nullptr, false, true));
+        else
+            HIP_TRY(ctx, poison_check(exc_list, exc_count, true, false));
         if (split)  // (tiered: list mode over the reads tier 1 handed on)
             HIP_TRY(ctx, bdx_launch_generic(band_cfg(ctx->F()), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
@@ -1867,13 +1947,13 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
     // The batch's longest read, for the launch plan and the statistics tables: the offsets are on the host anyway
     // (saves the device-side measurement — a tiny kernel, a 4-byte copy and a stream synchronisation per call, which
     // matters at the reference's chunk size of 4000 reads)
-    if (n_reads <= 262144) {  // (large batches: the device-side measurement is cheaper than a pass over the offsets)
+    {
+        // one pass over the offsets: they must be non-decreasing (a negative length would reach the kernels' address
+        // arithmetic), and the longest read comes out of the same pass; large batches are scanned by a few threads
         int64_t mx = 0;
-        for (int64_t i = 0; i < n_reads; ++i) {
-            const int64_t d = seq_off[i + 1] - seq_off[i];
-            if (d < 0) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
-            mx = d > mx ? d : mx;
-        }
+        bool monotone = true;
+        if (!scan_offsets(seq_off, n_reads, mx, monotone)) return fail(ctx, BDX_E_DEVICE, "out of host memory");
+        if (!monotone) return fail(ctx, BDX_E_INVALID, "seq_off is not non-decreasing");
         ctx->host_maxlen = (int)(mx > (1LL << 30) ? (1LL << 30) : (mx < 1 ? 1 : mx));
     }
     struct HostLenReset {
@@ -1973,28 +2053,35 @@ int32_t bdx_get_stats(bdx_ctx *ctx, int32_t pass, int32_t which, int32_t reduced
     if (!ctx || !out) return BDX_E_INVALID;
     if (pass < 0 || pass > 1 || which < BDX_STATS_POS || which > BDX_STATS_RAW) return fail(ctx, BDX_E_INVALID, "bad statistics table selector");
     if (!ctx->dev.need_traceback || (pass == 1 && !ctx->dev.is_dual)) return fail(ctx, BDX_E_STATE, "the config collects no statistics for this pass (need_traceback = 0)");
-    const long long rows = reduced ? ctx->st_sum_rows : ctx->st_rows;
-    const size_t words = bdx_stats_words(ctx, pass, which, rows);
+    // the shape handed out is the CURRENT one (bdx_stats_shape); the summed twins were filled at the shape of the last
+    // all-reduce — fewer pos rows, and for a growing length table fewer keys at a smaller pitch: rows / keys appended
+    // since then read as zero
+    const size_t B = (size_t)ctx->dev.pass[pass].n_barcodes;
+    const size_t words = bdx_stats_words(ctx, pass, which, ctx->st_rows);
     if ((size_t)n_words < words) return fail(ctx, BDX_E_INVALID, "statistics buffer too small: need %zu words", words);
     const DevBuf &src = reduced ? ctx->st_sum[pass][which] : ctx->st_tab[pass][which];
     if (reduced && !src.p) return fail(ctx, BDX_E_STATE, "bdx_allreduce_counts has not been called");
+    const long long pos_rows = reduced ? ctx->st_sum_rows : ctx->st_rows;
+    const size_t keys_now = which == BDX_STATS_RAW ? (size_t)ctx->st_raw_rows : (size_t)ctx->st_len_rows;
+    const size_t keys_src = which == BDX_STATS_LEN && reduced ? (size_t)ctx->st_sum_len_rows : keys_now;
+    const size_t stride_src = (keys_src + 15) & ~(size_t)15;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->st_flag.p, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<int64_t> phys;  // len / raw: [barcode][key stride] on the device
     if (which == BDX_STATS_POS) {
-        if (words) HIP_TRY(ctx, hipMemcpyAsync(out, src.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        const size_t have = (size_t)pos_rows * B;
+        if (have) HIP_TRY(ctx, hipMemcpyAsync(out, src.p, have * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (words > have) memset(out + have, 0, (words - have) * 8);
     } else {
-        phys.resize(bdx_stats_phys_words(ctx, pass, which, rows));
+        phys.resize(stride_src * B);
         if (!phys.empty()) HIP_TRY(ctx, hipMemcpyAsync(phys.data(), src.p, phys.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (flag) return fail(ctx, BDX_E_STATE, "a statistics key fell outside its table (internal sizing error)");
     if (which != BDX_STATS_POS) {
-        const size_t B = (size_t)ctx->dev.pass[pass].n_barcodes, stride = (size_t)bdx_stats_stride(ctx, which);
-        const size_t keys = which == BDX_STATS_RAW ? (size_t)ctx->st_raw_rows : (size_t)ctx->st_len_rows;
-        for (size_t k = 0; k < keys; ++k)
-            for (size_t b = 0; b < B; ++b) out[k * B + b] = phys[b * stride + k];
+        for (size_t k = 0; k < keys_now; ++k)
+            for (size_t b = 0; b < B; ++b) out[k * B + b] = k < keys_src ? phys[b * stride_src + k] : 0;
     }
     return BDX_OK;
 }
@@ -2014,6 +2101,19 @@ int64_t bdx_window_uploads(const bdx_ctx *ctx) { return ctx ? ctx->window_upload
 int64_t bdx_band_launches(const bdx_ctx *ctx) { return ctx ? ctx->band_launches : 0; }
 
 int64_t bdx_wave_launches(const bdx_ctx *ctx) { return ctx ? ctx->wave_launches : 0; }
+
+int64_t bdx_pipelined_calls(const bdx_ctx *ctx) { return ctx ? ctx->pipelined_calls : 0; }
+
+int64_t bdx_rejected_windows(bdx_ctx *ctx) {
+    if (!ctx || !ctx->d_dbg.p) return 0;
+    unsigned int rej[2] = {0, 0};  // [0] refused by the exact kernel, [1] found unwritten by the poison checker
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(rej, ctx->d_dbg.p, sizeof rej, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return (int64_t)rej[0] + (int64_t)rej[1];
+}
+
+int64_t bdx_debug_rejected_windows_total(void) { return (int64_t)g_rejected_windows.load(); }
 
 int32_t bdx_launch_info(const bdx_ctx *ctx, bdx_launch_info_t *out) {
     if (!ctx || !out) return BDX_E_INVALID;

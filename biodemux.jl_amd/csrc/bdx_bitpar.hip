@@ -514,7 +514,11 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
             // (split mode reuses scnt / slots as its window counters / re-sweep queue: a dual config with ONE pass in the
             // known-score class — e.g. trim_side 5 + no trim_side2 — must not push replay slots there, or the window
             // counts handed to the exact kernel cover entries nobody wrote)
+#ifdef BDX_REVERT_5CB01F9  // evidence builds only (tools/red_green_53109.sh): the defect fixed in 5cb01f9, back in
+            if (full[w.p * R + w.r]) {
+#else
             if (!a.split && full[w.p * R + w.r]) {
+#endif
                 const int k = __hip_atomic_fetch_add(&scnt[w.p * R + w.r], 1, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (dense)

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>  // types and prototypes only; nothing here is linked against librccl
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -34,6 +35,7 @@ namespace {
 
 struct Rccl {
     void *handle = nullptr;
+    bool forced = false;  // bound to the library BDX_RCCL_LIB names (a test stand-in: ranks may share a device)
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -50,6 +52,17 @@ std::once_flag g_rccl_once;
 
 void load_rccl() {
     Rccl &r = g_rccl;
+    // test seam: BDX_RCCL_LIB names the library to bind instead (tests/fake_rccl.cpp lets several contexts on ONE
+    // device run the N > 1 branches below); read once per process, here and nowhere else
+    if (const char *forced = getenv("BDX_RCCL_LIB")) {
+        r.forced = true;
+        r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) {
+            const char *e = dlerror();
+            r.error = std::string("BDX_RCCL_LIB could not be opened: ") + (e ? e : "unknown error");
+            return;
+        }
+    }
     // an instance that is already part of the process first (RTLD_NOLOAD), then the system's
     const char *names[] = {"librccl.so", "librccl.so.1"};
     for (const char *n : names)
@@ -156,6 +169,32 @@ int32_t bdx_comm_init_rank(bdx_ctx *ctx, const void *id, int32_t rank, int32_t n
     st->rank = rank;
     st->n_ranks = n_ranks;
     ctx->comm = st;
+    // every rank must have been built from the same config: the collectives run with per-rank element counts, and a
+    // mismatch would hang or corrupt the sums.  One tiny max-all-reduce of {v, -v} per quantity: all equal <=> max(v) == -max(-v).
+    {
+        const int npass = ctx->dev.is_dual ? 2 : 1;
+        long long probe[6] = {ctx->dev.n_counts, -(long long)ctx->dev.n_counts, ctx->dev.pass[0].n_barcodes, -(long long)ctx->dev.pass[0].n_barcodes,
+                              npass > 1 ? ctx->dev.pass[1].n_barcodes : 0, npass > 1 ? -(long long)ctx->dev.pass[1].n_barcodes : 0};
+        int rc = ensure_sum_buffer(ctx);
+        DevBuf tmp;
+        if (rc == BDX_OK && tmp.ensure(sizeof probe) != hipSuccess) rc = bdx_fail(ctx, BDX_E_DEVICE, "hipMalloc failed");
+        if (rc == BDX_OK && hipMemcpyAsync(tmp.p, probe, sizeof probe, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = bdx_fail(ctx, BDX_E_DEVICE, "hipMemcpyAsync failed");
+        if (rc == BDX_OK) {
+            ncclResult_t r2 = R->AllReduce(tmp.p, tmp.p, 6, ncclInt64, ncclMax, st->comm, ctx->stream);
+            if (r2 != ncclSuccess) rc = bdx_fail(ctx, BDX_E_COMM, "ncclAllReduce failed: %s", R->GetErrorString(r2));
+        }
+        long long got[6] = {0, 0, 0, 0, 0, 0};
+        if (rc == BDX_OK && (hipMemcpyAsync(got, tmp.p, sizeof got, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                             hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = bdx_fail(ctx, BDX_E_DEVICE, "reading the agreement probe failed");
+        tmp.release();
+        if (rc == BDX_OK && (got[0] != -got[1] || got[2] != -got[3] || got[4] != -got[5]))
+            rc = bdx_fail(ctx, BDX_E_INVALID, "the ranks of one communicator must share the config (counter vectors / barcode counts differ)");
+        if (rc != BDX_OK) {
+            bdx_comm_release(ctx);
+            return rc;
+        }
+    }
     return BDX_OK;
 }
 
@@ -167,19 +206,26 @@ int32_t bdx_comm_init_all(bdx_ctx *const *ctxs, int32_t n) {
         if (ctxs[i]->dev.n_counts != ctxs[0]->dev.n_counts)
             return fail_group(ctxs, i + 1, BDX_E_INVALID, "contexts of one communicator must share the config (counter vectors differ: %d vs %d)",
                               ctxs[i]->dev.n_counts, ctxs[0]->dev.n_counts);
-        for (int j = 0; j < i; ++j)
-            if (ctxs[j]->device == ctxs[i]->device)
-                return fail_group(ctxs, i + 1, BDX_E_INVALID, "contexts %d and %d share device %d (RCCL wants one rank per device)", j, i, ctxs[i]->device);
     }
     Rccl *R = rccl(ctxs[0]);
     if (!R) return BDX_E_COMM;
+    if (!R->forced)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                if (ctxs[j]->device == ctxs[i]->device)
+                    return fail_group(ctxs, i + 1, BDX_E_INVALID, "contexts %d and %d share device %d (RCCL wants one rank per device)", j, i, ctxs[i]->device);
     std::vector<int> devs((size_t)n);
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
     NCCL_TRY(ctxs[0], R, R->CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; ++i) {
         bdx_comm_state *st = new (std::nothrow) bdx_comm_state();
-        if (!st) return bdx_fail(ctxs[i], BDX_E_DEVICE, "out of host memory");
+        if (!st) {  // the communicators not yet handed to a context would leak
+            for (int j = i; j < n; ++j)
+                if (comms[(size_t)j] && R->CommDestroy) (void)R->CommDestroy(comms[(size_t)j]);
+            for (int j = 0; j < i; ++j) bdx_comm_release(ctxs[j]);
+            return bdx_fail(ctxs[i], BDX_E_DEVICE, "out of host memory");
+        }
         st->comm = comms[(size_t)i];
         st->rank = i;
         st->n_ranks = n;
@@ -226,6 +272,7 @@ static int stats_agree_finish(bdx_ctx *ctx) {
     for (int p = 0; p < npass; ++p)
         for (int w = 0; w < 3; ++w) HIP_TRY(ctx, ctx->st_sum[p][w].ensure(bdx_stats_phys_words(ctx, p, w, ctx->st_rows) * 8 + 8));
     ctx->st_sum_rows = ctx->st_rows;
+    ctx->st_sum_len_rows = ctx->st_len_rows;
     return BDX_OK;
 }
 
@@ -262,6 +309,7 @@ int32_t bdx_allreduce_counts(bdx_ctx *ctx) {
     if (ctx->comm && !(R = rccl(ctx))) return BDX_E_COMM;
     int rc = stats_agree_enqueue(ctx, R);
     if (rc == BDX_OK) rc = stats_agree_finish(ctx);
+    if (rc == BDX_OK) rc = ensure_sum_buffer(ctx);  // (allocations stay outside the group, as in the _all form)
     if (rc != BDX_OK) return rc;
     if (R) NCCL_TRY(ctx, R, R->GroupStart());  // counters + tables as one fused launch
     rc = enqueue_allreduce(ctx, R);

@@ -852,6 +852,7 @@ __device__ __forceinline__ PassOut run_pass_phased(const BdxDevCfg &cfg, const B
             e_lo = (int)(e & 0xFFFFu) - 1024 + lb;
             e_hi = (int)(e >> 16);
             if (e_hi < 1 || e_hi > n_read || e_lo > e_hi) {  // not a window (defence in depth): the whole pass window, in chunks
+                if (cfg.dbg_rejected) atomicAdd(cfg.dbg_rejected, 1u);
                 e_lo = jf;
                 e_hi = jl_last;
             }
@@ -993,6 +994,7 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
         // a hand-over window ends inside the read; anything else is not a window (defence in depth: columns drive
         // addresses in the band form) -> no restriction
         if (cjhi < 0x40000000 && (cjhi < 1 || cjhi > n || cjlo > cjhi)) {
+            if (cfg.dbg_rejected) atomicAdd(cfg.dbg_rejected, 1u);
             cjlo = -0x40000000;
             cjhi = 0x40000000;
         }

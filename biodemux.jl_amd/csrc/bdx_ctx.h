@@ -47,6 +47,7 @@ struct BdxTuning {
     int no_pipeline = 0;  // BDX_NO_PIPELINE: the host entry point uploads large batches in one piece
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
+    int poison = 0;       // BDX_POISON: every hand-over buffer is filled with 0xA5 before each classify call (tests: a consumer that reads what no producer wrote gets garbage on every run, not only when the allocator happens to hand back dirty memory)
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;
@@ -88,6 +89,7 @@ struct bdx_ctx {
     int device = 0;
     int n_cu = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount, read in bdx_create)
     int64_t wave_launches = 0;  // launches of the wave-autonomous kernel
+    DevBuf d_dbg;            // [0] hand-over windows the exact kernel refused (not a window: defence in depth; must stay 0)
     DevBuf d_wlist;          // reads the wave kernel hands to the general kernel (plain configs; tiered ones use d_tier)
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;   // host entry point, large batches: chunk uploads beside the previous chunk's kernels
@@ -123,6 +125,7 @@ struct bdx_ctx {
     // rows x n_barcodes, their all-reduced twins, and the overflow flag
     DevBuf st_tab[2][3], st_sum[2][3], st_flag;
     long long st_rows = 0, st_sum_rows = 0;
+    int st_sum_len_rows = 0;  // height of the length table when the summed twins were last filled (its pitch follows from it)
     int st_raw_rows = 0, st_len_rows = 0;
     bool st_len_fixed = false;  // the length table has a height known from the config (else it grows with the reads)
     // multi-GPU: communicator + the reduced counter vector (bdx_comm.cpp)

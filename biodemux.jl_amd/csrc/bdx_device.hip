@@ -330,7 +330,61 @@ __global__ void bdx_copy_kernel(bdx_copy_v4 *dst, const bdx_copy_v4 *src, long l
     if (blockIdx.x == 0 && zero)
         for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0u;
 }
+// TEST SWITCH (BDX_POISON): between a producer and its consumer, look at what the producer handed over — every
+// element the consumer is going to read must have been WRITTEN (the buffers were filled with 0xA5 before the call):
+//   * a list: entries [0, *count) — an unwritten one is counted and replaced by read 0 (a wild index would be followed);
+//   * window hand-over of one pass, for the reads of this launch (all of them, or the listed ones): the count byte
+//     itself, the entries it announces (barcode field), or — dense table (254) — the entry of every candidate barcode;
+//     a read with an unwritten element is counted and set to "no windows" (255).
+// Violations are added to dbg[1]; the suite fails when it is not 0 (bdx_rejected_windows).
+__global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list_count, long long n_reads, const uint32_t *wins, uint8_t *wcnt,
+                                        const uint32_t *cand, int cand_words, int n_barcodes, int check_list, unsigned int *dbg) {
+    const long long n = list ? (long long)(*list_count < (unsigned long long)n_reads ? *list_count : n_reads) : n_reads;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long rid = i;
+        if (list) {
+            uint32_t e = list[i];
+            if (check_list && (e == 0xA5A5A5A5u || (long long)e >= n_reads)) {
+                atomicAdd(dbg + 1, 1u);
+                list[i] = 0u;
+                e = 0u;
+            }
+            rid = e;
+        }
+        if (!wcnt || !wins) continue;
+        const unsigned w = wcnt[rid];
+        bool bad = false;
+        if (w == 0xA5u) {
+            bad = true;
+        } else if (w <= (unsigned)BDX_WCAP) {
+            for (unsigned k = 0; k < w; ++k) bad |= wins[((size_t)rid * BDX_WCAP + k) * 3] == 0xA5A5A5A5u;
+        } else if (w == 254u && cand) {
+            for (int cw = 0; cw < cand_words; ++cw) {
+                uint32_t bits = cand[(size_t)rid * cand_words + cw];
+                while (bits) {
+                    const int b = cw * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (b < n_barcodes) bad |= wins[(size_t)rid * n_barcodes + b] == 0xA5A5A5A5u;
+                }
+            }
+        }
+        if (bad) {
+            atomicAdd(dbg + 1, 1u);
+            wcnt[rid] = 255;
+        }
+    }
+}
 }  // namespace
+
+hipError_t bdx_launch_poison_check(uint32_t *list, const unsigned int *list_count, long long n_reads, const uint32_t *wins, uint8_t *wcnt,
+                                   const uint32_t *cand, int cand_words, int n_barcodes, int check_list, unsigned int *dbg, hipStream_t stream) {
+    if (n_reads <= 0 || !dbg) return hipSuccess;
+    long long blocks = (n_reads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bdx_poison_check_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, list, list_count, n_reads, wins, wcnt, cand, cand_words,
+                       n_barcodes, check_list, dbg);
+    return hipGetLastError();
+}
 
 hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream, void *d_zero, int zero_bytes) {
     const long long n16 = (long long)((bytes + 15) / 16);

@@ -64,6 +64,7 @@ struct BdxDevCfg {
     int band_lb[2];
     int dense_w;       // per launch: the column windows are a dense table wins[pass][read][barcode] (lo + 1024 | hi << 16), wcnt = 254
     int band_m;        // the common barcode length the band bodies run with (8, 10, 12, 16, 20, 24 or 32)
+    unsigned int *dbg_rejected;  // device counter: hand-over windows the exact kernel refused as "not a window" (must stay 0)
     BdxDevPass pass[2];
 };
 
@@ -227,3 +228,6 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               const unsigned int *d_list_count = nullptr, const BdxDevStats *stats = nullptr,
                               const BdxTierArgs *tier = nullptr, const double *tier_slo = nullptr);
 hipError_t bdx_generic_set_lds_limit(size_t bytes);
+// test switch BDX_POISON: checks (and sanitises) one hand-over between a producer and its consumer (bdx_device.hip)
+hipError_t bdx_launch_poison_check(uint32_t *list, const unsigned int *list_count, long long n_reads, const uint32_t *wins, uint8_t *wcnt,
+                                   const uint32_t *cand, int cand_words, int n_barcodes, int check_list, unsigned int *dbg, hipStream_t stream);

@@ -15,7 +15,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbiodemux_hip.so")
+LIB_PATH = os.environ.get("BDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbiodemux_hip.so")  # (override: test builds)
 
 BDX_ABI_VERSION = 1
 ALG = {"semiglobal": 0, "hamming": 1, "exact": 2}
@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
-    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches",
+    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pipelined_calls", "bdx_rejected_windows",
+    "bdx_debug_rejected_windows_total",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
 BDX_COMM_ID_BYTES = 128
@@ -216,6 +217,12 @@ def load_library(path: Optional[str] = None):
     L.bdx_band_launches.argtypes = [vp]
     L.bdx_wave_launches.restype = C.c_int64
     L.bdx_wave_launches.argtypes = [vp]
+    L.bdx_pipelined_calls.restype = C.c_int64
+    L.bdx_pipelined_calls.argtypes = [vp]
+    L.bdx_rejected_windows.restype = C.c_int64
+    L.bdx_rejected_windows.argtypes = [vp]
+    L.bdx_debug_rejected_windows_total.restype = C.c_int64
+    L.bdx_debug_rejected_windows_total.argtypes = []
     if path is None:
         _lib = L
     return L
@@ -464,6 +471,16 @@ class HipClassifier:
     def band_launches(self) -> int:
         """(pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled."""
         return int(self.lib.bdx_band_launches(self.h))
+
+    @property
+    def pipelined_calls(self) -> int:
+        """classify() calls that uploaded their batch in chunks beside the previous chunk's kernels."""
+        return int(self.lib.bdx_pipelined_calls(self.h))
+
+    @property
+    def rejected_windows(self) -> int:
+        """Hand-over windows the exact kernel refused as "not a window" (must be 0; synchronises the stream)."""
+        return int(self.lib.bdx_rejected_windows(self.h))
 
     @property
     def wave_launches(self) -> int:

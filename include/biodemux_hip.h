@@ -277,6 +277,18 @@ int64_t bdx_band_launches(const bdx_ctx *ctx);
  * tests can tell which kernel ran. */
 int64_t bdx_wave_launches(const bdx_ctx *ctx);
 
+/* How many bdx_classify_host calls uploaded their batch in chunks on a copy stream beside the previous chunk's kernels
+ * (large batches of configs with heavier kernels; env BDX_NO_PIPELINE switches it off).  Results are identical. */
+int64_t bdx_pipelined_calls(const bdx_ctx *ctx);
+
+/* Hand-over windows the exact kernel refused because they do not end inside the read ("not a window": defence in
+ * depth behind the filter kernels, classification.jl:238-445 then runs over the whole pass window).  A correct
+ * producer / consumer pair never leaves one: the counter must read 0 (synchronises the stream); the test-suite runs
+ * with BDX_POISON, which fills every hand-over buffer with 0xA5 before each call, and checks it.
+ * bdx_debug_rejected_windows_total: the same, summed over every context this process has destroyed. */
+int64_t bdx_rejected_windows(bdx_ctx *ctx);
+int64_t bdx_debug_rejected_windows_total(void);
+
 typedef struct {
     int32_t threads_per_block;
     int32_t lds_bytes_per_block;

@@ -274,6 +274,22 @@ def test_error_paths():
         H.bdx.HipClassifier(_c2_config(["ACGT"], indel=0))
 
 
+@pytest.mark.parametrize("n", [3000, 300_000, 1_200_000])
+def test_offsets_that_decrease_are_refused(n):
+    """bdx_classify_host checks the offsets of EVERY batch size (small: one pass; large: a threaded scan that also finds
+    the longest read): a negative length must never reach the kernels' address arithmetic."""
+    bcs = synth.make_barcodes(24, 24, seed=5)
+    seq, off, _ = synth.make_reads(bcs, n, 100, seed=6)
+    for kw in (dict(), dict(max_error_rate=0.2, trim_side=5)):
+        with H.bdx.HipClassifier(_c2_config(bcs, **kw)) as hc:
+            bad = off.copy()
+            bad[n // 2] += 150  # read n/2 - 1 grows over its successor, read n/2 gets a negative length
+            with pytest.raises(H.bdx.BdxError, match="not non-decreasing"):
+                hc.classify(seq, bad)
+            good = hc.classify(seq, off)  # the context stays usable
+            assert good["bc1"].shape[0] == n
+
+
 def test_counts_accumulate_and_reset():
     bcs = synth.make_barcodes(16, 16, seed=9, min_hamming=5)
     seq, off, _ = synth.make_reads(bcs, 20000, 80, seed=9)
@@ -1144,6 +1160,10 @@ def test_pipelined_host_upload_equals_the_single_upload(monkeypatch):
             with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
                 out = hc.classify(seq, off)
                 res[piped] = (out, hc.counts.copy(), hc.stats_tables() if cfg.summary else None)
+                # the chunked path really ran (or really did not): a changed threshold must not turn this test into a
+                # comparison of the single upload with itself
+                assert (hc.pipelined_calls > 0) == piped, (kw, piped, hc.pipelined_calls)
+                assert hc.rejected_windows == 0
         for k, v in res[True][0].items():
             assert np.array_equal(v, res[False][0][k], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, res[False][0][k]), (kw, k)
         assert np.array_equal(res[True][1], res[False][1])
