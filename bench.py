@@ -45,6 +45,8 @@ def _parse():
     ap.add_argument("--filter", default="auto", help="auto|off|qgram|bitpar (all give identical results)")
     ap.add_argument("--max-error-rate", type=float, default=None, help="override the config's rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for the other BASELINE configs and the end-to-end figure")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end FASTQ leg (0: skip)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -128,6 +130,171 @@ def build_workload(name: str, n_reads: int, first_read: int, rate_override=None)
                          f"max_error_rate={rate}, ref_search_range=1:200, ScoreOnly",
                     barcodes=24, barcode_len="16..32")
     raise KeyError(name)
+
+
+def _profile_counters(config: str, n: int):
+    """(traffic bytes per step, source, per-kernel VALU figures) from the latest committed rocprofv3 --pmc summary of
+    this config (profiles/*_<config>_*pmc.json, tools/summarize_prof.py), or (None, None, None)."""
+    traffic, src_s, valu = None, None, None
+    try:
+        tagged = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json") and f"_{config}_" in f)
+        if not tagged:
+            return None, None, None
+        pj = json.load(open(os.path.join(ROOT, "profiles", tagged[-1])))
+        if pj.get("reads_per_launch") != n:
+            return None, None, None
+        tot, src = 0.0, []
+        for kname, e in pj["kernels"].items():
+            if "hbm_read_bytes_corrected" in e:
+                tot += e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
+                src.append(kname)
+            c = e.get("counters_per_step", {})
+            if c.get("SQ_INSTS_VALU", 0.0) / n >= 1.0 and c.get("SQ_WAVE_CYCLES"):
+                # VALU wave-instructions per read of the batch (all of the kernel's launches in one step) and the fraction
+                # of its waves' lifetime spent issuing.  SIMD cycles per issued VALU wave-instruction: SQ_BUSY_CYCLES has
+                # 32 counter instances for 1024 SIMDs; the pipe's limit depends on the instruction mix (tools/ubench_ops.hip:
+                # v_and/or/xor/add/sub/lshrrev ~2.4, nearly everything else — v_bfe, v_alignbit, v_perm, v_lshl_or,
+                # carries, v_min — ~4.3 at the clock the chip holds under load)
+                valu = (valu or []) + [{
+                    "kernel": kname, "launches_per_step": e.get("meta", {}).get("dispatches_per_step"),
+                    "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
+                    "simd_cycles_per_valu_instr": (round(c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0 / c["SQ_INSTS_VALU"], 2)
+                                                   if c.get("SQ_BUSY_CYCLES") else None),
+                    "valu_ceiling_cycles_per_instr": 3.2,
+                    "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}]
+        if src:
+            traffic, src_s = tot, f"profiles/{tagged[-1]} ({' + '.join(src)})"
+    except Exception:
+        pass
+    return traffic, src_s, valu
+
+
+def run_leg(name: str, dev, dev_index: int, steps: int = 5, warmup: int = 2, sample: int = 50_000):
+    """One of the other BASELINE configs, short: device-resident throughput over `steps` classify calls, the kernels'
+    HIP-event time, the HBM fraction, the traffic ratio of the committed profile, and an oracle check on a sample."""
+    import numpy as np
+    import torch
+
+    import biodemux_jl_amd as bdx
+
+    t0 = time.time()
+    wl = build_workload(name, 0, 0, None)
+    gen_s = time.time() - t0
+    cfg, seq, off, n = wl["cfg"], wl["seq"], wl["off"], wl["n"]
+    hc = bdx.HipClassifier(cfg, device=dev_index)
+    try:
+        stream = torch.cuda.Stream(dev)
+        hc.set_stream(stream.cuda_stream)
+        hc.set_read_length_hint(wl["read_len"])
+        d_seq = torch.from_numpy(seq).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        d_out = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in wl["outputs"]}
+        ptrs = {k: v.data_ptr() for k, v in d_out.items()}
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(stream):
+            for _ in range(warmup):
+                hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, **ptrs)
+            torch.cuda.synchronize(dev)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            t1 = time.perf_counter()
+            for a, b in ev:
+                a.record(stream)
+                hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, **ptrs)
+                b.record(stream)
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t1
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        path = hc.kernel_path
+        # oracle check on the first `sample` reads (the checker, never the product path)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import bdx_oracle as orc
+
+        L = wl["read_len"]
+        k = min(n, sample if L <= 1000 else max(2000, sample * 150 // L))
+        exp = orc.OracleClassifier(cfg, nthreads=_host_cores(), want_pass=False).classify(seq[:k * L], off[:k + 1])
+        for key in wl["outputs"]:
+            got = d_out[key][:k].cpu().numpy()
+            assert np.array_equal(got, exp[key]), f"bench leg {name}: HIP {key} differs from the oracle on the first {k} reads"
+    finally:
+        hc.close()
+    algo = wl["algo_bytes"]
+    achieved = algo * n / (kern_ms * 1e-3) / 1e9
+    traffic, tsrc, _ = _profile_counters(name, n)
+    return {"name": name, "workload": wl["desc"], "value": n * steps / elapsed, "unit": "reads/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kern_ms, "kernel_path": path,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_read": algo, "survey_bytes_per_read": wl.get("survey_bytes", algo),
+                         "traffic": traffic, "traffic_ratio": (traffic / (algo * n)) if traffic else None, "traffic_source": tsrc},
+            "oracle_checked_reads": int(k), "gen_seconds": round(gen_s, 1)}
+
+
+def run_e2e(n: int, dev_index: int, expect_matched=None):
+    """End to end: a FASTQ file of the C2 shape on tmpfs -> execute_demultiplexing (native reader /
+    packer, ONE C-ABI classify call per 2^20-read batch, native in-order writer) -> 97 files.  reads/s of the whole
+    call, the busy seconds of the three overlapped stages and which of them bounds it."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    import biodemux_jl_amd as bdx
+    from biodemux_jl_amd import synth
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    need = n * 319 * 2.2
+    if base and shutil.disk_usage(base).free < need:
+        base = None
+    root = tempfile.mkdtemp(prefix="bdx_e2e_", dir=base)
+    try:
+        bcs = synth.make_barcodes(96, 24, seed=synth.SEED)
+        seq, off, _ = synth.make_reads(bcs, n, 150, seed=synth.SEED)
+        t0 = time.time()
+        rec = np.empty((n, 319), dtype=np.uint8)  # "@read000000000\n" + 150 bases + "\n+\n" + 150 x 'F' + "\n"
+        rec[:, 0:5] = np.frombuffer(b"@read", dtype=np.uint8)
+        ids = np.arange(n, dtype=np.int64)
+        for k in range(9):
+            rec[:, 13 - k] = (ids // 10 ** k % 10 + 48).astype(np.uint8)
+        rec[:, 14] = 10
+        rec[:, 15:165] = seq.reshape(n, 150)
+        rec[:, 165:168] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 168:318] = ord("F")
+        rec[:, 318] = 10
+        fq = os.path.join(root, "synthetic.fastq")
+        rec.tofile(fq)
+        del rec, seq, off
+        bc = os.path.join(root, "barcodes.csv")
+        with open(bc, "w") as f:
+            f.write("ID,Full_seq,Full_annotation\n" + "".join(f"bc{i + 1:03d},{b},{'B' * 24}\n" for i, b in enumerate(bcs)))
+        write_s = time.time() - t0
+        best = None
+        for rep in range(2):  # (first run: page cache / allocator warm-up)
+            out = os.path.join(root, f"out{rep}")
+            tm = {}
+            t1 = time.perf_counter()
+            st = bdx.execute_demultiplexing(fq, bc, out, max_error_rate=0.1, _io="native", device=dev_index, _timings=tm)
+            dt = time.perf_counter() - t1
+            nfiles = len(os.listdir(out))
+            out_bytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
+            assert st.total_reads == n and out_bytes == n * 319, (st.total_reads, out_bytes)
+            if expect_matched is not None:
+                assert st.matched_reads == expect_matched, (st.matched_reads, expect_matched)
+            shutil.rmtree(out)
+            if best is None or dt < best["seconds"]:
+                stages = {"reader (index + pack)": tm.get("index_s", 0.0) + tm.get("pack_s", 0.0), "classify (bdx_classify_host)": tm.get("classify_s", 0.0),
+                          "writer": tm.get("write_s", 0.0)}
+                best = {"value": n / dt, "unit": "reads/s", "seconds": dt, "reads": n, "fastq_gb": n * 319 / 1e9, "fastq_gb_per_s": n * 319 / dt / 1e9,
+                        "output_files": nfiles, "matched": int(st.matched_reads), "host_threads": tm.get("threads"), "batches": tm.get("batches"),
+                        "stage_busy_seconds": {k: round(v, 3) for k, v in stages.items()}, "bound_by": max(stages, key=stages.get),
+                        "setup_seconds": round(tm.get("setup_s", 0.0), 3), "pipeline_seconds": round(tm.get("wall_s", 0.0), 3),
+                        "close_seconds": round(tm.get("close_s", 0.0), 3),
+                        "where": "tmpfs" if base else "tmp dir (no room on /dev/shm)", "generate_fastq_seconds": round(write_s, 1),
+                        "note": "execute_demultiplexing(fastq, barcodes.csv, out_dir, max_error_rate=0.1) on the C2 shape: overlapped stages "
+                                "(reader thread | classify on the calling thread | writer thread, each with a pool of host threads for its batch); setup = barcode table + device context; "
+                                "output bytes = input bytes, file count and matched reads checked; best of two runs"}
+        return best
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
 
 
 def main():
@@ -324,37 +491,32 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside the process; use the committed
     # rocprofv3 --pmc summary of this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     # x2 correction on FETCH_SIZE — MI355X_MICROARCH.md §HBM), produced by tools/summarize_prof.py.
-    traffic, traffic_src = None, None
-    valu = None  # from the same committed profile, per kernel: what actually bounds the path
-    try:
-        tagged = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                        if f.endswith("_pmc.json") and f"_{args.config}_" in f)
-        if tagged and args.max_error_rate is None and args.filter == "auto":
-            pj = json.load(open(os.path.join(ROOT, "profiles", tagged[-1])))
-            if pj.get("reads_per_launch") == n:
-                tot, src = 0.0, []
-                for kname, e in pj["kernels"].items():
-                    if "hbm_read_bytes_corrected" in e:
-                        tot += e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0.0)
-                        src.append(kname)
-                    c = e.get("counters_per_step", {})
-                    if c.get("SQ_INSTS_VALU", 0.0) / n >= 1.0 and c.get("SQ_WAVE_CYCLES"):
-                        # VALU wave-instructions per read of the batch (all of the kernel's launches in one step) and the
-                        # fraction of its waves' lifetime spent issuing; peak issue = 1024 SIMDs x 1 wave-instruction / 2 cycles
-                        valu = (valu or []) + [{
-                            "kernel": kname, "launches_per_step": e.get("meta", {}).get("dispatches_per_step"),
-                            "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
-                            # SIMD cycles per issued VALU wave-instruction (SQ_BUSY_CYCLES: 32 counter instances, 1024
-                            # SIMDs); the pipe's limit for this instruction mix is ~3.2 (tools/ubench_valu.hip: 2.6-2.8
-                            # for v_and/or/xor/add and 3-source v_bitop3, 3.9-4.4 for shifts, v_add3, carries)
-                            "simd_cycles_per_valu_instr": (round(c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0 / c["SQ_INSTS_VALU"], 2)
-                                                           if c.get("SQ_BUSY_CYCLES") else None),
-                            "valu_ceiling_cycles_per_instr": 3.2,
-                            "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}]
-                if src:
-                    traffic, traffic_src = tot, f"profiles/{tagged[-1]} ({' + '.join(src)})"
-    except Exception:
-        pass
+    traffic, traffic_src, valu = (None, None, None)
+    if args.max_error_rate is None and args.filter == "auto":
+        traffic, traffic_src, valu = _profile_counters(args.config, n)
+
+    # the other BASELINE configs (short legs) and the end-to-end figure ride on the default single-GPU run, so that one
+    # driver invocation carries every config; the headline above is unaffected (it has been timed already)
+    other, e2e = None, None
+    matched_headline = int(counts[1]) if world == 1 else None  # (the counter vector is zeroed at the top of every step)
+    if rank == 0 and world == 1 and args.config == "C2" and not args.no_other_configs and not args.reads and args.max_error_rate is None:
+        del d_seq, d_off
+        torch.cuda.empty_cache()
+        other = []
+        for name in ("C2d", "C4", "C5"):
+            try:
+                other.append(run_leg(name, dev, dev_index))
+            except AssertionError:
+                raise
+            except Exception as e:  # noqa: BLE001 — a leg that cannot run must not take the headline down
+                other.append({"name": name, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+        if args.e2e_reads > 0:
+            try:
+                e2e = run_e2e(args.e2e_reads, dev_index, matched_headline if args.e2e_reads == n else None)
+            except AssertionError:
+                raise
+            except Exception as e:  # noqa: BLE001
+                e2e = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
     if rank == 0:
         reads_total = n * world * args.steps
@@ -383,6 +545,8 @@ def main():
                                  "kernel_ms_avg = HIP events around all launches of one classify call, on the launch stream"},
             "host_buffer_path": host_path,
             "cpu_baseline": cpu,
+            "other_configs": other,
+            "e2e": e2e,
         }
         print(json.dumps(line), flush=True)
 

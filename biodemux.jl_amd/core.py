@@ -28,7 +28,7 @@ _PREFIX_RE = re.compile(r"\.fastq(\.gz)?$")
 
 # Reads handed to the device per C-ABI call.  The reference hands 4000-read chunks to each
 # worker (chunk_size); a GPU wants >= 10^5 reads per launch (256 CUs x 8 waves x 64 lanes).
-DEFAULT_BATCH_READS = 1 << 20
+DEFAULT_BATCH_READS = 1 << 19  # reads per C-ABI call of the file pipeline (the kernels are at full speed from ~10^5 reads on; smaller batches fill the pipeline sooner)
 
 
 def _records(io):
@@ -141,7 +141,8 @@ def _demux(fastq1: str, fastq2: Optional[str], config: DemuxConfig, output_direc
 
 
 def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxConfig], object]] = None,
-                           _batch_reads: int = DEFAULT_BATCH_READS, _io: str = "auto", device: int = 0, **kw):
+                           _batch_reads: int = DEFAULT_BATCH_READS, _io: str = "auto", device: int = 0,
+                           _timings: Optional[dict] = None, **kw):
     """execute_demultiplexing(FASTQ_file, barcode_file, output_directory; kwargs...)      core.jl:500
     execute_demultiplexing(FASTQ_file1, FASTQ_file2, barcode_file, output_directory; ...)  core.jl:360
 
@@ -150,6 +151,7 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
     plain reference implementation below) or "auto" (native when the library was built).
     ``_classifier_factory`` is a test seam: the parity tests on CPU pass the oracle here to
     check this file contract; the product default is the HIP classifier and nothing else.
+    ``_timings`` (a dict) receives the busy seconds of the native pipeline's stages (bench.py's end-to-end figure).
     Returns the DemuxStats scalar counters (the reference returns nothing)."""
     if len(args) == 3:
         fastq1, barcode_file, output_directory = args
@@ -210,6 +212,8 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
     # summary=true: the HIP classifier collects the histograms of classification.jl:827-865 on the device
     # (bdx_get_stats); a test-injected classifier without such tables hands over per-pass outputs instead
     classifier = _classifier_factory(config) if _classifier_factory else HipClassifier(config, device=device)
+    if _timings is not None:  # barcode table + device context: before the first batch can move
+        _timings["setup_s"] = (_dt.datetime.now() - start_time).total_seconds()
     device_stats = hasattr(classifier, "stats_tables")
     hist = DemuxStats() if (config.summary and not device_stats) else None
 
@@ -223,13 +227,16 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
         use_native = _io == "native" or (_io == "auto" and nativeio.available())
         if use_native:
             nativeio.demux_native(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads,
-                                  on_batch)
+                                  on_batch, _timings)
         else:
             _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads, on_batch)
         counts = np.asarray(classifier.counts)
         tables = classifier.stats_tables() if (config.summary and device_stats) else None
     finally:
+        t_close = _dt.datetime.now()
         classifier.close()
+        if _timings is not None:  # releasing the device context (staging buffers, tables)
+            _timings["close_s"] = (_dt.datetime.now() - t_close).total_seconds()
 
     duration = _dt.datetime.now() - start_time  # core.jl:484-485
     if o["log"]:  # core.jl:487-491

@@ -15,6 +15,7 @@
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -27,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -343,46 +345,99 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
         return 0;
     }
     const int64_t want = 4 * max_reads;
-    // bound the scanned region: records average a few hundred bytes; grow until enough lines
-    std::vector<int64_t> nl;  // positions of '\n'
-    int64_t lo = start, scanned_to = start;
+    // Two phases per scanned region, both spread over the threads: (1) every thread notes the newlines of its slice
+    // (32-bit offsets from the slice start: half the memory traffic of 64-bit positions); (2) after a prefix sum over
+    // the slices' counts every thread turns its own newlines straight into line_off / line_len entries — no merged
+    // position vector and no serial pass over millions of lines.  Regions are scanned until enough lines are there.
+    int64_t nlines = 0;          // lines written so far
+    int64_t cur = start;         // start of the next line
+    int64_t scanned_to = start;
     int64_t region = std::min<int64_t>(size - start, std::max<int64_t>(1 << 20, max_reads * 400));
-    while ((int64_t)nl.size() < want && scanned_to < size) {
+    while (nlines < want && scanned_to < size) {
         const int64_t hi = std::min(size, scanned_to + region);
         const int T = std::max(1, std::min<int>(nthreads, (int)((hi - scanned_to) >> 20) + 1));
-        std::vector<std::vector<int64_t>> parts(T);
-        std::vector<std::thread> th;
         const int64_t span = (hi - scanned_to + T - 1) / T;
-        for (int t = 0; t < T; ++t) {
-            th.emplace_back([&, t]() {
-                const int64_t a = scanned_to + span * t, b = std::min(hi, a + span);
-                const uint8_t *p = d + a, *e = d + b;
-                auto &v = parts[t];
-                v.reserve((size_t)((b - a) / 80 + 16));
-                while (p < e) {
-                    const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
-                    if (!q) break;
-                    v.push_back((int64_t)(q - d));
-                    p = q + 1;
-                }
-            });
+        std::vector<std::unique_ptr<uint32_t[]>> pos((size_t)T);
+        std::vector<int64_t> cnt((size_t)T, 0);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t]() {
+                    const int64_t a = std::min(hi, scanned_to + span * t), b = std::min(hi, a + span);
+                    // (a slice has at most one newline per byte; FASTQ lines are long, so a bound that is usually
+                    // generous is tried first and the slice is rescanned with the exact count if it does not hold)
+                    int64_t cap = (b - a) / 24 + 64;
+                    for (;;) {
+                        std::unique_ptr<uint32_t[]> v(new uint32_t[(size_t)cap]);
+                        const uint8_t *p = d + a, *e = d + b;
+                        int64_t n = 0;
+                        bool fits = true;
+                        while (p < e) {
+                            const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+                            if (!q) break;
+                            if (n < cap) v[(size_t)n] = (uint32_t)(q - (d + a));
+                            else fits = false;
+                            ++n;
+                            p = q + 1;
+                        }
+                        if (fits) {
+                            pos[(size_t)t] = std::move(v);
+                            cnt[(size_t)t] = n;
+                            break;
+                        }
+                        cap = n;
+                    }
+                });
+            for (auto &t : th) t.join();
         }
-        for (auto &t : th) t.join();
-        for (auto &v : parts) nl.insert(nl.end(), v.begin(), v.end());
+        // prefix over the slices: first line index and the end of the last line before every slice
+        std::vector<int64_t> first((size_t)T + 1, 0), prev_end((size_t)T, 0);
+        int64_t pe = cur;  // start of the line that the first newline of the region terminates
+        for (int t = 0; t < T; ++t) {
+            first[(size_t)t + 1] = first[(size_t)t] + cnt[(size_t)t];
+            prev_end[(size_t)t] = pe;
+            if (cnt[(size_t)t] > 0) {
+                const int64_t a = std::min(hi, scanned_to + span * t);
+                pe = a + (int64_t)pos[(size_t)t][(size_t)cnt[(size_t)t] - 1] + 1;
+            }
+        }
+        const int64_t room = want - nlines;
+        const int64_t take = std::min<int64_t>(first[(size_t)T], room);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t]() {
+                    const int64_t a = std::min(hi, scanned_to + span * t);
+                    int64_t lcur = prev_end[(size_t)t];
+                    const int64_t k0 = first[(size_t)t], k1 = std::min<int64_t>(first[(size_t)t + 1], take);
+                    for (int64_t k = k0; k < k1; ++k) {
+                        const int64_t e = a + (int64_t)pos[(size_t)t][(size_t)(k - k0)];
+                        int64_t len = e - lcur;
+                        line_off[nlines + k] = lcur;
+                        if (len > 0 && d[e - 1] == '\r') len -= 1;
+                        line_len[nlines + k] = (int32_t)len;
+                        lcur = e + 1;
+                    }
+                });
+            for (auto &t : th) t.join();
+        }
+        if (take > 0) {
+            // the cursor after the last line taken
+            int t_last = 0;
+            while (t_last + 1 < T && first[(size_t)t_last + 1] < take) ++t_last;
+            const int64_t a = std::min(hi, scanned_to + span * t_last);
+            cur = a + (int64_t)pos[(size_t)t_last][(size_t)(take - 1 - first[(size_t)t_last])] + 1;
+        }
+        nlines += take;
         scanned_to = hi;
         region *= 2;
     }
-    (void)lo;
-    int64_t nlines = std::min<int64_t>((int64_t)nl.size(), want);
-    if (!final) nlines -= nlines % 4;  // the rest of a record may still be on its way
-    int64_t cur = start;
-    for (int64_t k = 0; k < nlines; ++k) {
-        int64_t e = nl[k];
-        line_off[k] = cur;
-        int64_t len = e - cur;
-        if (len > 0 && d[e - 1] == '\r') len -= 1;
-        line_len[k] = (int32_t)len;
-        cur = e + 1;
+    if (!final) {  // the rest of a record may still be on its way: only complete records
+        const int64_t drop = nlines % 4;
+        if (drop) {
+            nlines -= drop;
+            cur = line_off[nlines];
+        }
     }
     // data not terminated by '\n': the rest is one more line (readline at EOF)
     if (final && nlines < want && scanned_to >= size && cur < size) {
@@ -450,58 +505,188 @@ int64_t bdx_fq_seq_bytes(const int32_t *line_len, int64_t nrec) {
 // One output stream of a batch: records of file `src` (with its line tables) are appended to
 // class_paths[cls[i]] in input order.  trim != 0: keep_start/keep_end (1-based inclusive, -1 =
 // untrimmed) are applied to sequence and quality (core.jl:162-173).  force_gzip: config.gzip_output.
+// bdx_fq_demux_write_range: only the records whose class lies in [class_lo, class_hi) are written — several writer
+// threads can then share a batch (each output file belongs to exactly one of them, so per-file order stays input
+// order): a file is written by one thread at a time whatever the file system, and the file of the unmatched reads
+// is a tenth of the bytes.
+static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
+                                const int32_t *cls, int32_t n_classes, const char *const *class_paths,
+                                const int32_t *keep_start, const int32_t *keep_end, int32_t trim, int32_t force_gzip,
+                                int32_t nthreads, int32_t class_lo, int32_t class_hi);
+
 int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
                            const int32_t *cls, int32_t n_classes, const char *const *class_paths,
                            const int32_t *keep_start, const int32_t *keep_end, int32_t trim, int32_t force_gzip,
                            int32_t nthreads) {
+    return demux_write_impl(src, line_off, line_len, nrec, cls, n_classes, class_paths, keep_start, keep_end, trim, force_gzip, nthreads, 0,
+                            n_classes);
+}
+
+int32_t bdx_fq_demux_write_range(const bdx_fq_file *src, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
+                                 const int32_t *cls, int32_t n_classes, const char *const *class_paths,
+                                 const int32_t *keep_start, const int32_t *keep_end, int32_t trim, int32_t force_gzip,
+                                 int32_t nthreads, int32_t class_lo, int32_t class_hi) {
+    return demux_write_impl(src, line_off, line_len, nrec, cls, n_classes, class_paths, keep_start, keep_end, trim, force_gzip, nthreads,
+                            class_lo, class_hi);
+}
+
+static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off, const int32_t *line_len, int64_t nrec,
+                                const int32_t *cls, int32_t n_classes, const char *const *class_paths,
+                                const int32_t *keep_start, const int32_t *keep_end, int32_t trim, int32_t force_gzip,
+                                int32_t nthreads, int32_t class_lo, int32_t class_hi) {
     const uint8_t *d = src->data;
-    // pass 1: output size per record and per class; destination offsets keep input order
-    std::vector<int64_t> csize((size_t)n_classes, 0), dst((size_t)nrec);
-    std::vector<int32_t> ta((size_t)(trim ? nrec : 0)), tb((size_t)(trim ? nrec : 0));
-    for (int64_t i = 0; i < nrec; ++i) {
-        const int32_t c = cls[i];
-        if (c < 0 || c >= n_classes) {
-            g_io_err = "class index out of range";
-            return -1;
+    const auto mine = [=](int32_t c) { return c >= class_lo && c < class_hi; };
+    if (nrec <= 0) return 0;
+    static const bool timing = getenv("BDX_IO_TIMING") != nullptr;  // developer switch: phase times of the writer on stderr
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tm0 = now();
+    double tm1 = 0, tm2 = 0, tm3 = 0;
+    // Plain files are written in one of two ways, chosen per class and batch:
+    //  * few bytes (the barcode files: ~3 MB each per 2^20-read batch): the untouched records are handed to the kernel
+    //    as iovecs pointing INTO the input mapping — one copy (input pages -> the file's pages), no gather buffer;
+    //  * many bytes (the file of the unmatched reads: a tenth of a batch), trimmed / "\r"-stripped records, gzip: the
+    //    records are gathered into a heap buffer by all threads, and the buffer goes out with ONE write (a writev over
+    //    130 000 small iovecs is bound by the per-segment cost of the kernel's copy loop, and a file is written by one
+    //    thread at a time whatever the file system).
+    // Per-file order is input order in both: positions come from a prefix sum over the threads' record slices.
+    const int T = std::max(1, std::min<int>(nthreads, (int)(nrec >> 13) + 1));
+    const int64_t per = (nrec + T - 1) / T;
+    // record i: trimmed range (1-based inclusive a..b within the sequence; b = -1: untrimmed)
+    const auto trimmed = [&](int64_t i, int64_t &a, int64_t &b) {
+        if (!trim || keep_start[i] == -1) {
+            a = 1;
+            b = -1;
+            return;
         }
+        const int64_t slen = line_len[4 * i + 1];
+        a = std::max<int64_t>(keep_start[i], 1);
+        b = std::min<int64_t>(keep_end[i], slen);
+        if (a > b) {
+            a = 1;
+            b = 0;
+        }
+    };
+    const auto out_bytes = [&](int64_t i) -> int64_t {
         int64_t sl = line_len[4 * i + 1], ql = line_len[4 * i + 3];
-        if (trim && keep_start[i] != -1) {
-            const int64_t slen = sl;
-            int64_t a = std::max<int64_t>(keep_start[i], 1), b = std::min<int64_t>(keep_end[i], slen);
-            if (a > b) {
-                a = 1;
-                b = 0;
-            }
-            ta[i] = (int32_t)a;
-            tb[i] = (int32_t)b;
+        int64_t a, b;
+        trimmed(i, a, b);
+        if (b != -1) {
             sl = b - a + 1;
-            // the quality string is sliced with the same range; clamp to its own length
-            const int64_t qb = std::min<int64_t>(b, ql);
+            const int64_t qb = std::min<int64_t>(b, ql);  // the quality string is sliced with the same range, clamped to its own length
             ql = qb >= a ? qb - a + 1 : 0;
-        } else if (trim) {
-            ta[i] = 1;
-            tb[i] = -1;  // marker: untrimmed
         }
-        dst[i] = csize[c];
-        csize[c] += line_len[4 * i] + sl + line_len[4 * i + 2] + ql + 4;
-    }
-    std::vector<std::vector<uint8_t>> bufs((size_t)n_classes);
-    for (int c = 0; c < n_classes; ++c) bufs[c].resize((size_t)csize[c]);
-    // pass 2: parallel gather
+        return line_len[4 * i] + sl + line_len[4 * i + 2] + ql + 4;
+    };
+    // one run of the input ("h\ns\np\nq\n", nothing stripped)?
+    const auto contiguous = [&](int64_t i) -> bool {
+        const int64_t o0 = line_off[4 * i], o1 = line_off[4 * i + 1], o2 = line_off[4 * i + 2], o3 = line_off[4 * i + 3];
+        return o1 == o0 + line_len[4 * i] + 1 && o2 == o1 + line_len[4 * i + 1] + 1 && o3 == o2 + line_len[4 * i + 2] + 1 &&
+               o3 + line_len[4 * i + 3] < src->size && d[o3 + line_len[4 * i + 3]] == '\n';
+    };
+    // pass 1: bytes and records per class and thread; does every record of a class qualify for the iovec form?
+    std::vector<std::vector<int64_t>> tbytes((size_t)T, std::vector<int64_t>((size_t)n_classes, 0));
+    std::vector<std::vector<int64_t>> trecs((size_t)T, std::vector<int64_t>((size_t)n_classes, 0));
+    std::vector<std::vector<char>> tplain((size_t)T, std::vector<char>((size_t)n_classes, 1));
+    std::atomic<int> bad_class{0};
     {
-        const int T = std::max(1, std::min<int>(nthreads, (int)(nrec >> 13) + 1));
         std::vector<std::thread> th;
-        const int64_t per = (nrec + T - 1) / T;
         for (int t = 0; t < T; ++t)
             th.emplace_back([&, t]() {
                 const int64_t a0 = per * t, b0 = std::min(nrec, a0 + per);
+                auto &h = tbytes[(size_t)t];
+                auto &r = trecs[(size_t)t];
+                auto &pl = tplain[(size_t)t];
                 for (int64_t i = a0; i < b0; ++i) {
-                    uint8_t *o = bufs[cls[i]].data() + dst[i];
+                    const int32_t c = cls[i];
+                    if (c < 0 || c >= n_classes) {
+                        bad_class.store(1);
+                        return;
+                    }
+                    if (!mine(c)) continue;
+                    h[(size_t)c] += out_bytes(i);
+                    r[(size_t)c] += 1;
+                    if (pl[(size_t)c]) {
+                        int64_t a, b;
+                        trimmed(i, a, b);
+                        if (b != -1 || !contiguous(i)) pl[(size_t)c] = 0;
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    if (bad_class.load()) {
+        g_io_err = "class index out of range";
+        return -1;
+    }
+    tm1 = now();
+    std::vector<int64_t> csize((size_t)n_classes, 0), crecs((size_t)n_classes, 0);
+    std::vector<char> cplain((size_t)n_classes, 1);
+    for (int c = 0; c < n_classes; ++c)
+        for (int t = 0; t < T; ++t) {
+            const int64_t v = tbytes[(size_t)t][(size_t)c], r = trecs[(size_t)t][(size_t)c];
+            tbytes[(size_t)t][(size_t)c] = csize[(size_t)c];  // -> where thread t's records of class c start (bytes / records)
+            trecs[(size_t)t][(size_t)c] = crecs[(size_t)c];
+            csize[(size_t)c] += v;
+            crecs[(size_t)c] += r;
+            cplain[(size_t)c] = cplain[(size_t)c] && tplain[(size_t)t][(size_t)c];
+        }
+    std::vector<int> todo;
+    for (int c = 0; c < n_classes; ++c)
+        if (csize[(size_t)c] > 0) todo.push_back(c);
+    struct Dest {
+        uint8_t *base = nullptr;              // gather buffer (heap), or
+        std::unique_ptr<uint8_t[]> heap;
+        std::unique_ptr<struct iovec[]> iov;  // the records as iovecs into the input
+        bool gz = false;
+        int fail = 0;
+    };
+    std::vector<Dest> dest((size_t)n_classes);
+    const int64_t IOV_LIMIT = (int64_t)8 << 20;  // classes with more bytes than this in a batch are gathered
+    for (int c : todo) {
+        Dest &ds = dest[(size_t)c];
+        std::string low(class_paths[c]);
+        std::transform(low.begin(), low.end(), low.begin(), ::tolower);
+        ds.gz = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
+        if (!ds.gz && cplain[(size_t)c] && csize[(size_t)c] <= IOV_LIMIT) {
+            ds.iov.reset(new struct iovec[(size_t)crecs[(size_t)c]]);
+        } else {
+            ds.heap.reset(new uint8_t[(size_t)csize[(size_t)c]]);
+            ds.base = ds.heap.get();
+        }
+    }
+    const bool any_fail = false;
+    tm2 = now();
+    // pass 2: the gather (heap classes) / the iovecs (the others)
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const int64_t a0 = per * t, b0 = std::min(nrec, a0 + per);
+                auto &pos = tbytes[(size_t)t];
+                auto &rpos = trecs[(size_t)t];
+                for (int64_t i = a0; i < b0; ++i) {
+                    const int32_t c = cls[i];
+                    if (!mine(c)) continue;
+                    Dest &ds = dest[(size_t)c];
+                    if (ds.iov) {
+                        struct iovec &v = ds.iov[(size_t)rpos[(size_t)c]++];
+                        v.iov_base = (void *)(d + line_off[4 * i]);
+                        v.iov_len = (size_t)(line_off[4 * i + 3] + line_len[4 * i + 3] + 1 - line_off[4 * i]);
+                        continue;
+                    }
+                    uint8_t *o = ds.base + pos[(size_t)c];
                     const int64_t hl = line_len[4 * i], pl = line_len[4 * i + 2];
                     int64_t so = line_off[4 * i + 1], sl = line_len[4 * i + 1];
                     int64_t qo = line_off[4 * i + 3], ql = line_len[4 * i + 3];
-                    if (trim && tb[i] != -1) {
-                        const int64_t a = ta[i], b = tb[i];
+                    int64_t a, b;
+                    trimmed(i, a, b);
+                    if (b == -1 && contiguous(i)) {  // one run of the input: one copy
+                        const int64_t len = hl + sl + pl + ql + 4;
+                        memcpy(o, d + line_off[4 * i], (size_t)len);
+                        pos[(size_t)c] += len;
+                        continue;
+                    }
+                    if (b != -1) {
                         so += a - 1;
                         sl = b - a + 1;
                         const int64_t qb = std::min<int64_t>(b, ql);
@@ -520,45 +705,39 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
                     memcpy(o, d + qo, (size_t)ql);
                     o += ql;
                     *o++ = '\n';
+                    pos[(size_t)c] += hl + sl + pl + ql + 4;
                 }
             });
         for (auto &t : th) t.join();
     }
-    // pass 3: append each class buffer to its file.  gzip output: every 4 MiB piece of every class is
-    // deflated as a gzip member of its own by whichever thread is free (members concatenate to a valid
-    // .gz; one big class — `unknown` — would otherwise serialise the whole batch behind one zlib stream),
-    // then the members of a file are appended in order.
-    std::vector<int> todo;
-    for (int c = 0; c < n_classes; ++c)
-        if (csize[c] > 0) todo.push_back(c);
-    std::vector<int> fail((size_t)todo.size(), 0);
-    std::vector<char> is_gz(todo.size(), 0);
+    tm3 = now();
+    // pass 3: gzip output — every 4 MiB piece of every class is deflated as a gzip member of its own by whichever thread
+    // is free (members concatenate to a valid .gz; one big class — `unknown` — would otherwise serialise the whole batch
+    // behind one zlib stream), then the members of a file are appended in order.
     struct Member {
-        size_t k, off, len;
+        int c;
+        size_t off, len;
         std::vector<uint8_t> out;
         int bad = 0;
     };
     std::vector<Member> members;
-    for (size_t k = 0; k < todo.size(); ++k) {
-        std::string low(class_paths[todo[k]]);
-        std::transform(low.begin(), low.end(), low.begin(), ::tolower);
-        is_gz[k] = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
-        if (is_gz[k]) {
-            const size_t total = bufs[todo[k]].size(), piece = (size_t)1 << 22;
-            for (size_t off = 0; off < total; off += piece) {
-                Member mb;
-                mb.k = k;
-                mb.off = off;
-                mb.len = std::min(piece, total - off);
-                members.push_back(std::move(mb));
+    if (!any_fail)
+        for (int c : todo)
+            if (dest[(size_t)c].gz) {
+                const size_t total = (size_t)csize[(size_t)c], piece = (size_t)1 << 22;
+                for (size_t off = 0; off < total; off += piece) {
+                    Member mb;
+                    mb.c = c;
+                    mb.off = off;
+                    mb.len = std::min(piece, total - off);
+                    members.push_back(std::move(mb));
+                }
             }
-        }
-    }
     if (!members.empty()) {
         std::atomic<size_t> nextm{0};
-        const int T = std::max(1, std::min<int>(nthreads, (int)members.size()));
+        const int TM = std::max(1, std::min<int>(nthreads, (int)members.size()));
         std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < TM; ++t)
             th.emplace_back([&]() {
                 for (;;) {
                     const size_t i = nextm.fetch_add(1);
@@ -581,7 +760,7 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
                     hd.extra_len = 8;
                     deflateSetHeader(&zs, &hd);
                     mb.out.resize(deflateBound(&zs, (uLong)mb.len) + 64);
-                    zs.next_in = (Bytef *)(bufs[todo[mb.k]].data() + mb.off);
+                    zs.next_in = (Bytef *)(dest[(size_t)mb.c].base + mb.off);
                     zs.avail_in = (uInt)mb.len;
                     zs.next_out = mb.out.data();
                     zs.avail_out = (uInt)mb.out.size();
@@ -599,36 +778,83 @@ int32_t bdx_fq_demux_write(const bdx_fq_file *src, const int64_t *line_off, cons
             });
         for (auto &t : th) t.join();
     }
+    // finish: the plain files (largest first: the unmatched reads' buffer is one long write) and the members of the
+    // gzip files (consecutive in `members`), each file appended by one thread
     {
-        // members of one file are consecutive in `members`
-        std::vector<size_t> first(todo.size() + 1, members.size());
-        for (size_t i = members.size(); i-- > 0;) first[members[i].k] = i;
-        const int T = std::max(1, std::min<int>(nthreads, (int)todo.size()));
+        std::vector<int> order(todo);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return csize[(size_t)x] > csize[(size_t)y]; });
+        std::atomic<size_t> nextc{0};
+        const int TW = std::max(1, std::min<int>(nthreads, (int)order.size()));
         std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
-                for (size_t k = (size_t)t; k < todo.size(); k += (size_t)T) {
-                    const int c = todo[k];
-                    FILE *fp = fopen(class_paths[c], "ab");
-                    if (!fp) {
-                        fail[k] = 1;
+        for (int t = 0; t < TW; ++t)
+            th.emplace_back([&]() {
+                for (;;) {
+                    const size_t k = nextc.fetch_add(1);
+                    if (k >= order.size()) break;
+                    const int c = order[k];
+                    Dest &ds = dest[(size_t)c];
+                    if (ds.gz) {
+                        FILE *fp = fopen(class_paths[c], "ab");
+                        if (!fp) {
+                            ds.fail = 1;
+                            continue;
+                        }
+                        for (const Member &mb : members)
+                            if (mb.c == c && (mb.bad || fwrite(mb.out.data(), 1, mb.out.size(), fp) != mb.out.size())) ds.fail = 1;
+                        if (fclose(fp) != 0) ds.fail = 1;
                         continue;
                     }
-                    if (is_gz[k]) {
-                        for (size_t i = first[k]; i < members.size() && members[i].k == k; ++i)
-                            if (members[i].bad || fwrite(members[i].out.data(), 1, members[i].out.size(), fp) != members[i].out.size())
-                                fail[k] = 1;
-                    } else if (fwrite(bufs[c].data(), 1, bufs[c].size(), fp) != bufs[c].size()) {
-                        fail[k] = 1;
+                    const int fd = open(class_paths[c], O_WRONLY | O_APPEND | O_CREAT, 0644);
+                    if (fd < 0) {
+                        ds.fail = 1;
+                        continue;
                     }
-                    if (fclose(fp) != 0) fail[k] = 1;
+                    if (ds.iov) {
+                        struct iovec *v = ds.iov.get();
+                        int64_t left = crecs[(size_t)c];
+                        while (left > 0 && !ds.fail) {
+                            const int n = (int)std::min<int64_t>(left, 1024);  // IOV_MAX
+                            ssize_t w = writev(fd, v, n);
+                            if (w < 0) {
+                                ds.fail = 1;
+                                break;
+                            }
+                            int done = 0;  // (a short write: skip what went out, retry the rest)
+                            while (done < n && w >= (ssize_t)v[done].iov_len) {
+                                w -= (ssize_t)v[done].iov_len;
+                                ++done;
+                            }
+                            if (done < n && w > 0) {
+                                v[done].iov_base = (char *)v[done].iov_base + w;
+                                v[done].iov_len -= (size_t)w;
+                            }
+                            v += done;
+                            left -= done;
+                        }
+                    } else {
+                        const uint8_t *p = ds.base;
+                        int64_t left = csize[(size_t)c];
+                        while (left > 0) {
+                            const ssize_t w = write(fd, p, (size_t)left);
+                            if (w <= 0) {
+                                ds.fail = 1;
+                                break;
+                            }
+                            p += w;
+                            left -= w;
+                        }
+                    }
+                    if (close(fd) != 0) ds.fail = 1;
                 }
             });
         for (auto &t : th) t.join();
     }
-    for (size_t k = 0; k < todo.size(); ++k)
-        if (fail[k]) {
-            g_io_err = std::string("cannot write ") + class_paths[todo[k]];
+    if (timing)
+        fprintf(stderr, "[bdx_io] writer: sizes %.1f ms, buffers %.1f ms, gather / iovecs %.1f ms, deflate + files %.1f ms (%lld records)\n",
+                (tm1 - tm0) * 1e3, (tm2 - tm1) * 1e3, (tm3 - tm2) * 1e3, (now() - tm3) * 1e3, (long long)nrec);
+    for (int c : todo)
+        if (dest[(size_t)c].fail) {
+            g_io_err = std::string("cannot write ") + class_paths[c];
             return -1;
         }
     return 0;

@@ -59,6 +59,9 @@ def _load():
         L.bdx_fq_demux_write.restype = C.c_int32
         L.bdx_fq_demux_write.argtypes = [vp, vp, vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_char_p), vp, vp,
                                          C.c_int32, C.c_int32, C.c_int32]
+        L.bdx_fq_demux_write_range.restype = C.c_int32
+        L.bdx_fq_demux_write_range.argtypes = [vp, vp, vp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_char_p), vp, vp,
+                                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         _lib = L
     return _lib
 
@@ -99,10 +102,13 @@ class FastqFile:
         """Records below byte `upto` are written out: a streamed .gz input gives their pages back."""
         self.L.bdx_fq_release(self.h, int(upto))
 
-    def next_batch(self, max_reads: int, nthreads: int):
-        """-> (n_records, line_off int64[4n], line_len int32[4n]) from the cursor on."""
-        off = np.empty(4 * max_reads, dtype=np.int64)
-        ln = np.empty(4 * max_reads, dtype=np.int32)
+    def next_batch(self, max_reads: int, nthreads: int, off=None, ln=None):
+        """-> (n_records, line_off int64[4n], line_len int32[4n]) from the cursor on.  ``off`` / ``ln``: arrays to reuse
+        (a fresh 48 MB pair per 2^20-read batch is page-faulted in by the indexer)."""
+        if off is None or len(off) < 4 * max_reads:
+            off = np.empty(4 * max_reads, dtype=np.int64)
+        if ln is None or len(ln) < 4 * max_reads:
+            ln = np.empty(4 * max_reads, dtype=np.int32)
         nxt = C.c_int64(0)
         n = int(self.L.bdx_fq_index(self.h, self.cursor, max_reads, off.ctypes.data, ln.ctypes.data, C.byref(nxt),
                                     nthreads))
@@ -111,12 +117,14 @@ class FastqFile:
         self.cursor = int(nxt.value)
         return n, off, ln
 
-    def pack(self, off, ln, n: int, nthreads: int):
+    def pack(self, off, ln, n: int, nthreads: int, seq=None, so=None):
         total = int(self.L.bdx_fq_seq_bytes(ln.ctypes.data, n))
-        seq = np.empty(max(total, 1), dtype=np.uint8)
-        so = np.empty(n + 1, dtype=np.int64)
+        if seq is None or len(seq) < max(total, 1):
+            seq = np.empty(max(total, 1) + (max(total, 1) >> 4), dtype=np.uint8)
+        if so is None or len(so) < n + 1:
+            so = np.empty(n + 1, dtype=np.int64)
         self.L.bdx_fq_pack(self.h, off.ctypes.data, ln.ctypes.data, n, seq.ctypes.data, so.ctypes.data, nthreads)
-        return seq[:total] if total else np.zeros(0, dtype=np.uint8), so
+        return (seq[:total] if total else np.zeros(0, dtype=np.uint8)), so[:n + 1]
 
     def close(self):
         if self.h:
@@ -125,14 +133,17 @@ class FastqFile:
 
 
 def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: str, prefix1: str, prefix2: str,
-                 classifier, batch_reads: int, on_batch=None) -> None:
+                 classifier, batch_reads: int, on_batch=None, timings: Optional[dict] = None) -> None:
     """Native counterpart of core._demux: index -> pack -> ONE C-ABI classify call -> in-order write,
     as a three-stage pipeline (reader thread | classify on the calling thread | writer thread; the
     native calls release the GIL).  Batches flow through bounded FIFO queues, so per-file order is
     input order exactly as with the reference's single writer task (core.jl:139-148)."""
     import queue
     import threading
+    import time
 
+    busy = {"index_s": 0.0, "pack_s": 0.0, "classify_s": 0.0, "write_s": 0.0, "batches": 0}
+    t_wall = time.perf_counter()
     L = _load()
     T = _threads()
     f1 = FastqFile(fastq1)
@@ -141,25 +152,41 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
     n_classes = 2 + len(config.bc_seqs) * stride
     do_trim = config.trim_side is not None or config.trim_side2 is not None
     gz = int(bool(config.gzip_output))
-    q_in: "queue.Queue" = queue.Queue(maxsize=2)
-    q_out: "queue.Queue" = queue.Queue(maxsize=2)
+    q_in: "queue.Queue" = queue.Queue(maxsize=1)
     errors = []
+    # Batch buffers travel reader -> classify -> writer and come back through `free`: line tables, the packed chunk and
+    # the verdict vectors are allocated a handful of times per run, not once per batch (fresh arrays of this size are
+    # page-faulted in by whoever writes them first: ~15 % of the reader's time)
+    free: "queue.Queue" = queue.Queue()
+    for _ in range(5):  # one per stage (reader, classify, writer) + one waiting in front of each of the two consumers
+        free.put({})
 
     def reader():
         try:
             while True:
-                n1, off1, ln1 = f1.next_batch(batch_reads, T)
+                buf = free.get()
+                t0 = time.perf_counter()
+                n1, off1, ln1 = f1.next_batch(batch_reads, T, buf.get("off1"), buf.get("ln1"))
+                buf["off1"], buf["ln1"] = off1, ln1
                 off2 = ln2 = None
                 if f2 is not None:
-                    n2, off2, ln2 = f2.next_batch(batch_reads, T)
+                    n2, off2, ln2 = f2.next_batch(batch_reads, T, buf.get("off2"), buf.get("ln2"))
+                    buf["off2"], buf["ln2"] = off2, ln2
                     n = min(n1, n2)  # lock-step pairs: stop at the shorter file (core.jl:48)
                     last = n1 != n2
                 else:
                     n, last = n1, False
                 if n == 0:
                     break
-                seq, so = f1.pack(off1, ln1, n, T)
-                q_in.put((n, off1, ln1, off2, ln2, seq, so, f1.cursor, f2.cursor if f2 is not None else 0))
+                t1 = time.perf_counter()
+                seq, so = f1.pack(off1, ln1, n, T, buf.get("seq"), buf.get("so"))
+                if seq.base is not None:
+                    buf["seq"] = seq.base
+                if so.base is not None:
+                    buf["so"] = so.base
+                busy["index_s"] += t1 - t0
+                busy["pack_s"] += time.perf_counter() - t1
+                q_in.put((n, off1, ln1, off2, ln2, seq, so, f1.cursor, f2.cursor if f2 is not None else 0, buf))
                 if last:
                     break
         except BaseException as e:  # noqa: BLE001 - forwarded to the caller
@@ -181,40 +208,59 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
             arr[c] = os.path.join(output_directory, prefix + "." + filename_for(config, b1, b2)).encode()
         return arr
 
-    def writer():
+    # The writer gathers every batch straight into the (mapped) output files with all its threads working on all files
+    # (csrc/bdx_io.cpp): one writer thread, one class range.  (bdx_fq_demux_write_range lets several writer threads
+    # share a batch by class range — each file then still belongs to exactly one of them, in batch order: per-file order
+    # = input order, core.jl:139-148 — which pays on file systems without shared writable mappings.)
+    ranges = [(0, n_classes)]
+    q_outs = [queue.Queue(maxsize=1) for _ in ranges]
+    done_lock = threading.Lock()
+
+    def writer(wi):
+        lo, hi = ranges[wi]
+        qw = q_outs[wi]
+        tshare = T
         try:
             while True:
-                item = q_out.get()
+                item = qw.get()
                 if item is None:
                     break
-                n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2 = item
-                used = np.unique(cls)
+                n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2, buf, pending, used = item
+                tw0 = time.perf_counter()
 
                 def write(f, off, ln, prefix, trim):
-                    rc = L.bdx_fq_demux_write(f.h, off.ctypes.data, ln.ctypes.data, n, cls.ctypes.data, n_classes,
-                                              paths(prefix, used), ks.ctypes.data, ke.ctypes.data, int(trim), gz, T)
+                    rc = L.bdx_fq_demux_write_range(f.h, off.ctypes.data, ln.ctypes.data, n, cls.ctypes.data, n_classes,
+                                                    paths(prefix, used), ks.ctypes.data, ke.ctypes.data, int(trim), gz, tshare, lo, hi)
                     if rc != 0:
                         raise OSError(L.bdx_io_last_error().decode())
 
-                if config.classify_both and f2 is not None:  # core.jl:175-185
-                    write(f1, off1, ln1, prefix1, do_trim)
-                    write(f2, off2, ln2, prefix2, False)
-                elif f2 is not None:  # core.jl:186-190
-                    write(f2, off2, ln2, prefix2, False)
-                else:  # core.jl:191-196
-                    write(f1, off1, ln1, prefix1, do_trim)
-                f1.release(cur1)  # this batch and everything before it is on disk
-                if f2 is not None:
-                    f2.release(cur2)
+                if used[(used >= lo) & (used < hi)].size:
+                    if config.classify_both and f2 is not None:  # core.jl:175-185
+                        write(f1, off1, ln1, prefix1, do_trim)
+                        write(f2, off2, ln2, prefix2, False)
+                    elif f2 is not None:  # core.jl:186-190
+                        write(f2, off2, ln2, prefix2, False)
+                    else:  # core.jl:191-196
+                        write(f1, off1, ln1, prefix1, do_trim)
+                with done_lock:
+                    pending[0] -= 1
+                    last = pending[0] == 0
+                    busy["write_s"] += time.perf_counter() - tw0
+                if last:
+                    f1.release(cur1)  # this batch and everything before it is on disk
+                    if f2 is not None:
+                        f2.release(cur2)
+                    free.put(buf)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
-            while q_out.get() is not None:  # keep draining so the producer never blocks
+            while qw.get() is not None:  # keep draining so the producer never blocks
                 pass
 
     tr = threading.Thread(target=reader, name="bdx-reader")
-    tw = threading.Thread(target=writer, name="bdx-writer")
+    tws = [threading.Thread(target=writer, args=(wi,), name=f"bdx-writer-{wi}") for wi in range(len(ranges))]
     tr.start()
-    tw.start()
+    for tw in tws:
+        tw.start()
     try:
         while True:
             item = q_in.get()
@@ -222,26 +268,58 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 break
             if errors:
                 continue
-            n, off1, ln1, off2, ln2, seq, so, cur1, cur2 = item
-            out = classifier.classify(seq, so)  # <- the hot path: one C-ABI call per batch
+            n, off1, ln1, off2, ln2, seq, so, cur1, cur2, buf = item
+            tc0 = time.perf_counter()
+            res = buf.get("out")
+            reuse = (res is not None and len(res["bc1"]) >= n and getattr(classifier, "want_pass", False) is False
+                     and hasattr(classifier, "lib"))  # (the HIP wrapper takes result arrays to reuse; test doubles may not)
+            if reuse:
+                out = classifier.classify(seq, so, out={k: v[:n] for k, v in res.items()})  # <- the hot path: one C-ABI call per batch
+            else:
+                out = classifier.classify(seq, so)
+                if set(out) == {"bc1", "bc2", "keep_start", "keep_end"}:
+                    buf["out"] = out
+            busy["classify_s"] += time.perf_counter() - tc0
+            busy["batches"] += 1
             if on_batch is not None:
                 on_batch(out)
             bc1, bc2 = out["bc1"], out["bc2"]
-            cls = np.where(bc1 > 0, 2 + (bc1 - 1) * stride + np.maximum(bc2 - 1, 0), np.where(bc1 == 0, 0, 1))
-            cls = np.ascontiguousarray(cls, dtype=np.int32)
+            cls = buf.get("cls")
+            if cls is None or len(cls) < n:
+                cls = buf["cls"] = np.empty(max(n, batch_reads), dtype=np.int32)
+            cls = cls[:n]
+            # class of a read: 0 unknown, 1 ambiguous, 2 + (bc1 - 1) * stride + (bc2 - 1) matched
+            np.subtract(bc1, 1, out=cls)
+            if stride != 1:
+                np.multiply(cls, stride, out=cls)
+                cls += np.maximum(bc2, 1)
+                cls += 1
+            else:
+                cls += 2
+            cls[bc1 == 0] = 0
+            cls[bc1 < 0] = 1
             ks = np.ascontiguousarray(out["keep_start"], dtype=np.int32)
             ke = np.ascontiguousarray(out["keep_end"], dtype=np.int32)
-            q_out.put((n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2))
+            used = np.flatnonzero(np.bincount(cls, minlength=n_classes))
+            pending = [len(ranges)]
+            for qw in q_outs:
+                qw.put((n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2, buf, pending, used))
     except BaseException as e:  # noqa: BLE001
         errors.append(e)
         while q_in.get() is not None:
             pass
     finally:
-        q_out.put(None)
+        for qw in q_outs:
+            qw.put(None)
         tr.join()
-        tw.join()
+        for tw in tws:
+            tw.join()
         f1.close()
         if f2 is not None:
             f2.close()
+    if timings is not None:  # busy seconds of the three overlapped stages (reader = index + pack | classify | writer)
+        busy["wall_s"] = time.perf_counter() - t_wall
+        busy["threads"] = T
+        timings.update(busy)
     if errors:
         raise errors[0]
