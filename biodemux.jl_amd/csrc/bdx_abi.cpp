@@ -129,7 +129,7 @@ int plan_generic(bdx_ctx *ctx) {
         p.threads = t;
         // Read staging: aim for two resident workgroups per CU (<= 80 KiB each) when that
         // still leaves room for ~192 B per read; otherwise take what is left of the CU.
-        const size_t share = p.clean ? (LDS_MAX / 3) & ~(size_t)1279 : 80 * 1024;  // clean class: three workgroups per CU (<= 168 VGPRs)
+        const size_t share = 80 * 1024;  // two workgroups per CU (the exact kernels are compiled for two waves per SIMD)
         size_t budget = need < share ? share - need : 0;
         if (budget < (size_t)t * 192) budget = LDS_MAX - need;
         size_t stage = budget > 64 * 1024 ? 64 * 1024 : budget;

@@ -23,6 +23,11 @@
 // accept/tighten/ambiguity decisions are IEEE doubles exactly as written in the reference.
 #include "bdx_core.h"
 
+#ifndef BDX_CLEAN_WAVES
+#define BDX_CLEAN_WAVES 2  // waves per SIMD the clean-class exact kernel is compiled for: 2 = 208 VGPRs and NO scratch; 3 (<= 168 VGPRs)
+                           // spills 176-432 B per lane (1.8 GB each way per 10 M reads of C4) for the same speed within 2 %
+#endif
+
 namespace {
 
 struct GenericArgs {
@@ -90,7 +95,7 @@ __device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p,
 // CLEAN: the clean-class register DP (sg_core_clean) — no predicated rows, <= 168 VGPRs, three workgroups per CU;
 // UM: every barcode has exactly REGM rows.
 template <int BS, int REGM, bool CLEAN = false, bool UM = false>
-__global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? 3 : 2) : 1)) void bdx_generic_kernel(const GenericArgs a) {
+__global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? BDX_CLEAN_WAVES : 2) : 1)) void bdx_generic_kernel(const GenericArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const BdxDevCfg &cfg = a.cfg;
