@@ -588,56 +588,74 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp = BdxWavePlan{};
     const BdxBitparPlan &bp = F.bplan;
     const BdxSeedPlan &sp = F.splan;
-    if (ctx->tune.no_wave || !bp.enabled || !sp.enabled || sp.diag || bp.word_bytes != 4 || c.is_dual || !bp.known_ok[0] ||
-        sp.n_always[0] != 0 || sp.q < 6 || sp.q > 8 || c.algorithm != BDX_ALG_SEMIGLOBAL)
+    const int npass = c.is_dual ? 2 : 1;
+    if (ctx->tune.no_wave || !bp.enabled || !sp.enabled || sp.diag || bp.word_bytes != 4 || sp.n_always[0] != 0 || sp.n_always[1] != 0 ||
+        sp.q < 6 || sp.q > 8 || c.algorithm != BDX_ALG_SEMIGLOBAL || c.has_nindel)
         return BDX_OK;
-    const bdx_pass_t &p = c.pass[0];
+    // known-score configs: the kernel replays the reducer itself (single pass); everything else in the filters' domain:
+    // "split" — it only filters, candidate masks and column windows go to the exact kernel (either pass count)
+    bool split = false;
+    for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
+    if (!split && c.is_dual) return BDX_OK;
+    int cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
+    if (cmin < 1 || c.match < 0) return BDX_OK;
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
-    if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
-    const int B = p.n_barcodes;
-    if (B < 1 || B > 1024) return BDX_OK;
-    for (uint32_t i = 0; i < p.bc_off[B]; ++i) {
-        const uint8_t ch = p.bc_bytes[i];
-        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return BDX_OK;
+    int Btot = 0, cwt = 0;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        if (p.n_barcodes < 1) return BDX_OK;
+        for (uint32_t i = 0; i < p.bc_off[p.n_barcodes]; ++i) {
+            const uint8_t ch = p.bc_bytes[i];
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return BDX_OK;
+        }
+        Btot += p.n_barcodes;
+        cwt += (p.n_barcodes + 31) / 32;
     }
+    if (Btot > 1024 || (split && cwt > 4)) return BDX_OK;  // (split mode keeps four candidate words per read in LDS)
     const int q = sp.q;
-    struct Piece { int b, start; };
+    struct Piece { int g, start; const uint8_t *bc; };
     std::vector<Piece> pieces;
-    std::vector<uint32_t> meta((size_t)B, 0u), peq8((size_t)B * 9, 0u);  // (stride 9: bank spread, see the kernel)
-    int track = 1 << 20;
-    for (int b = 0; b < B; ++b) {
-        const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
-        if (m < 1 || m > 32) return BDX_OK;
-        const uint8_t *bc = p.bc_bytes + p.bc_off[b];
-        const int shift = 32 - m;
-        const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
-        const uint32_t pad = ~rows;  // virtual rows below the barcode: match everything, D stays 0
-        for (int code = 0; code < 8; ++code) {
-            uint32_t mask = pad;
-            if (code < 4)
-                for (int i = 0; i < m; ++i)
-                    if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
-            peq8[(size_t)b * 9 + code] = mask;
+    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u);  // (stride 9: bank spread, see the kernel)
+    int track = 1 << 20, g = 0;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        for (int b = 0; b < p.n_barcodes; ++b, ++g) {
+            const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+            if (m < 1 || m > 32) return BDX_OK;
+            const uint8_t *bc = p.bc_bytes + p.bc_off[b];
+            const int shift = 32 - m;
+            const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
+            const uint32_t pad = ~rows;  // virtual rows below the barcode: match everything, D stays 0
+            for (int code = 0; code < 8; ++code) {
+                uint32_t mask = pad;
+                if (code < 4)
+                    for (int i = 0; i < m; ++i)
+                        if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
+                peq8[(size_t)g * 9 + code] = mask;
+            }
+            const long long ae = (long long)std::floor(c.max_error_rate * (double)m);  // (SimpleScoring: normalisation = m)
+            if (ae < 0) {  // can never be recorded: neither seeded nor swept (budget field 255)
+                meta[(size_t)g] = (uint32_t)m | (255u << 8);
+                continue;
+            }
+            long long kb = ae / cmin;
+            if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
+            if (kb > 15) return BDX_OK;  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
+            const long long L = m / (kb + 1);
+            if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
+            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8);
+            if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
+            for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{g, (int)(t * L), bc});
         }
-        const long long ae = (long long)std::floor(c.max_error_rate * (double)m);  // (known-score class: SimpleScoring, cmin = 1)
-        if (ae < 0) {  // can never be recorded: neither seeded nor swept
-            meta[b] = (uint32_t)m;
-            continue;
-        }
-        long long kb = ae;
-        if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
-        if (kb > 15) return BDX_OK;  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
-        const long long L = m / (kb + 1);
-        if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
-        meta[b] = (uint32_t)m | ((uint32_t)kb << 8);
-        if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
-        for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{b, (int)(t * L)});
     }
     if (pieces.empty() || pieces.size() > 8192) return BDX_OK;
-    // the per-read record table holds four seeded barcodes: the planted one plus the chance pairs must nearly always fit
+    // the per-read record table holds eight (barcode, diagonal cluster) records: the planted one(s) plus the chance pairs must nearly always fit
     if (150.0 * (double)pieces.size() / std::pow(4.0, (double)q) > 1.2) return BDX_OK;
     wp.q = q;
-    wp.n_barcodes = B;
+    wp.n_barcodes = Btot;
+    wp.b0 = c.pass[0].n_barcodes;
+    wp.split = split ? 1 : 0;
     wp.bm_bytes = (1 << (2 * q)) / 8;
     wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
     wp.hash_log2 = 8;
@@ -647,9 +665,9 @@ int build_wave_tables(bdx_ctx *ctx) {
     const uint32_t hmask = (1u << wp.hash_log2) - 1;
     for (const Piece &pc : pieces) {
         uint32_t key = 0;
-        for (int i = 0; i < q; ++i) key |= (uint32_t)((p.bc_bytes[p.bc_off[pc.b] + pc.start + i] >> 1) & 3) << (2 * i);
+        for (int i = 0; i < q; ++i) key |= (uint32_t)((pc.bc[pc.start + i] >> 1) & 3) << (2 * i);
         bitmap[key >> 3] |= (uint8_t)(1u << (key & 7));
-        const uint32_t entry = (key << 16) | (uint32_t)(pc.b + 1);
+        const uint32_t entry = (key << 16) | (uint32_t)(pc.g + 1);
         uint32_t slot = (key * 0x9E3779B1u) >> (32 - wp.hash_log2);
         bool dup = false;  // one entry per (key, barcode, piece start): two pieces of one barcode may share a key
         while (hash[slot] != 0) {
@@ -1844,6 +1862,24 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 wave0 = size_bitpar(ctx, batch_len, n_reads, true);
             if (!tiered && !wave0) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
         }
+        // split configs (trimming, summary, weighted costs): the wave kernel as the FILTER of a dense launch — candidate
+        // masks and column windows in the formats of the general kernel's split mode, every verdict from the exact
+        // kernel as before.  Tiered: tier 1 (all reads); plain: the only filter launch.
+        bool wsplit1 = false, wsplit0 = false;
+        BdxWaveSplit wsp{};
+        if (split && windows && !ctx->dev.vlen) {
+            for (int k = 0; k < 2; ++k) {
+                wsp.cw[k] = k < npass ? ctx->dev.pass[k].cand_words : 0;
+                wsp.cand_out[k] = k ? c1 : c0;
+                wsp.wins_out[k] = k ? w1 : w0;
+                wsp.wcnt_out[k] = k ? n1 : n0;
+                wsp.short_lb[k] = short_lb[k];
+            }
+            if (tiered)
+                wsplit1 = ctx->fs[1].wplan.split && size_wave(ctx, 1, batch_len, n_reads);
+            else
+                wsplit0 = ctx->fs[0].wplan.split && !dense_w && size_wave(ctx, 0, batch_len, n_reads);
+        }
         if (wave0) {
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -1861,7 +1897,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.dense_w = 0;
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
-            if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
+            if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
+                HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                             nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
+                ctx->wave_launches += 1;
+            } else if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                              ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
                 ctx->wave_launches += 1;
@@ -1883,6 +1923,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
         ctx->F().bplan.dbg = ctx->tune.debug;
+        if (wsplit0) {
+            HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                         nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
+            ctx->wave_launches += 1;
+        } else
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
                                        n1, split ? 1 : 0, exc_list, exc_count, (tiered || wave0) ? &t0 : nullptr));
@@ -1911,7 +1956,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
 #endif
         ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
-        if (tiered) ctx->path = (wave1 ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (wsplit0) ctx->path = "wave+verify";
+        if (tiered) ctx->path = ((wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = "wave > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {

@@ -173,7 +173,9 @@ struct BdxWavePlan {
     int enabled;           // config-level eligibility of this filter set
     int q;                 // seed length (6..8)
     int hash_log2;
-    int n_barcodes;
+    int n_barcodes;        // of all passes together (the barcodes of pass 1 are numbered behind those of pass 0)
+    int b0;                // barcodes of pass 0
+    int split;             // the set's config is outside the known-score class: the kernel only filters (candidate masks + column windows for the exact kernel)
     int bm_bytes;          // direct bitmap over the 4^q keys
     int track_from;        // columns [0, track_from) of a sweep cannot end an alignment within any barcode's budget
     const uint8_t *d_bitmap;
@@ -211,12 +213,21 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
 hipError_t bdx_launch_maxlen(const long long *d_off, long long n_reads, int *d_out, hipStream_t stream);
 hipError_t bdx_launch_copy(void *d_dst, const void *src_mapped, size_t bytes, hipStream_t stream, void *d_zero = nullptr, int zero_bytes = 0);
 
+// split-mode outputs of the wave kernel (same buffers and formats as bdx_bitpar.hip's split mode)
+struct BdxWaveSplit {
+    int cw[2];
+    uint32_t *cand_out[2];
+    uint32_t *wins_out[2];
+    uint8_t *wcnt_out[2];
+    int short_lb[2];
+};
+
 // Implemented in bdx_wave.hip.
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
 size_t bdx_wave_area_bytes(int rw, int span_cap);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0);
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);
 
 // Implemented in bdx_device.hip.
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,

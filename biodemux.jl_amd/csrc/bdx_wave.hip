@@ -58,6 +58,14 @@ struct WaveArgs {
     double tier_slo;
     uint32_t *list;          // reads this kernel does not answer ...
     unsigned int *list_count;  // ... and how many
+    // split mode (trimming / summary / weighted costs: the exact kernel gives every verdict; this kernel only filters):
+    // candidate masks and column windows per pass, as bdx_bitpar.hip's split mode writes them
+    int B0;                  // barcodes of pass 0 (barcode numbers of pass 1 follow them: g = B0 + b)
+    int cw[2];               // candidate words per pass
+    uint32_t *cand_out[2];   // [n_reads][cw]
+    uint32_t *wins_out[2];   // [n_reads][BDX_WCAP][3] = {barcode, first column of the restricted run, last column}
+    uint8_t *wcnt_out[2];    // [n_reads] entries valid (255: none -> whole window)
+    int short_lb[2];         // lookback m + kb instead of 2 (m + kb) + 1
     int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a skip bit
               // is set: 1 skip verdicts, 2 skip sweeps, 4 skip resolve + emit, 8 skip seed scan, 32 skip transcode, 64 skip loads
 };
@@ -155,9 +163,12 @@ __device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
                  : "memory");
 }
 
-template <int TF>
+// TRACKW: also note which columns have a score within the budget (split mode): bit 31 - j of `inm` for column j of the
+// block (kk1 = budget + 1: the sign bit of score - kk1 is shifted in).
+template <int TF, bool TRACKW>
 __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3,
-                                            const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best) {
+                                            const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best, const int kk1,
+                                            uint32_t &inm) {
     const uint32_t A[4] = {A0, A1, A2, A3};
     uint32_t Eq[2][8];
     const auto issue = [&](const int h) __attribute__((always_inline)) {
@@ -167,6 +178,7 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
         lds_read8(Eq[h & 1], addr);
     };
     issue(0);
+    inm = 0u;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {  // the Eq words of the next eight columns fly while these eight are worked on
         lds_wait8(Eq[h & 1]);
@@ -179,6 +191,7 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
             } else {
                 if (j == TF && TF > 0) score = __builtin_popcount(Pv) - __builtin_popcount(Mv);
                 sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
+                if (TRACKW) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
             }
         }
     }
@@ -186,7 +199,7 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
 // on); Q: seed length
-template <int RW, int TF, int NV, int Q>
+template <int RW, int TF, int NV, int Q, bool SPLIT>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
     constexpr int HQ = 6 * RW;    // seed hits per tile
@@ -222,7 +235,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int O_SLOTS = O_RMK + RW * RCAP * 4;           // u32[RW * 4]: survivors: barcode << 8 | d
     constexpr int O_SCNT = O_SLOTS + RW * 16;                // int[RW]
     constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
-    constexpr int O_RECQ = O_FLAG + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
+    constexpr int O_WCL1 = O_FLAG + RW * 4;                  // int[RW]: split mode: window entries written for pass 1 (pass 0: scnt)
+    constexpr int O_RECQ = O_WCL1 + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
     constexpr int O_LBUF = O_RECQ + SQ * 4;                  // u32[64]: reads for the list, flushed in batches
     constexpr int O_IMG2 = O_LBUF + 64 * 4;                  // u32[nvec_cap + 2]: 2-bit image
     const int nvec_cap = a.span_cap >> 4;
@@ -234,6 +248,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS int *scnt = (LDS int *)(wbase + O_SCNT);
     LDS int *flag = (LDS int *)(wbase + O_FLAG);
     LDS uint32_t *recq = (LDS uint32_t *)(wbase + O_RECQ);
+    LDS int *wcl1 = (LDS int *)(wbase + O_WCL1);
+    LDS uint32_t *cand = slots;  // split mode: candidate masks [RW][4 words: pass 0 then pass 1] (no replay, no slots)
     LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
     LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
@@ -337,6 +353,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         if (lane < RW) {
             scnt[lane] = 0;
             flag[lane] = 0;
+            if (SPLIT) {
+                wcl1[lane] = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) cand[lane * 4 + w] = 0u;
+            }
         }
 
         // ---- bytes (requested one tile ago): registers -> 2-bit / 4-bit images ----
@@ -531,30 +552,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         WAVE_SYNC();
 
         // ---- sweeps: lane = one record = one (read, barcode, window) ----
-        for (int s0 = 0; s0 < ns; s0 += 64) {
-            const int k = s0 + lane;
-            bool valid = k < ns;
-            const uint32_t rslot = valid ? recq[k] : 0u;
-            const uint32_t id = valid ? rid[rslot] : 0u;
-            const uint32_t dmk = valid ? rmk[rslot] : 0u;
-            if (valid) {  // the record is consumed
-                rid[rslot] = 0u;
-                rmk[rslot] = 0u;
-            }
-            valid = valid && id != 0u && dmk != 0u;
-            const int t = (int)(rslot / RCAP), b = valid ? (int)(id & 0xFFFFu) - 1 : 0;
+        // (a lambda: split mode runs it a second time for the reads whose tables overflowed, below)
+        const auto sweep_lane = [&](bool valid, const int t, const int b, const int lo, const int hi) __attribute__((always_inline)) {
             const uint32_t mt = meta[b];
             const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
-            int lo = 0, hi = 0;  // [lo, hi): 0-based columns of the sweep
-            if (valid) {
-                const int d0 = (int)(id >> 16) - 64;
-                const int dmin = d0 + __builtin_ctz(dmk) - kk, dmax = d0 + (31 - __builtin_clz(dmk)) - kk;
-                const int n = fb[t + 1] - fb[t];
-                lo = dmin - kk - 1;
-                hi = dmax + mm + kk + 1;
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > n ? n : hi;
-            }
             valid = valid && hi > lo && !BDX_DBG(2);
             const int ncol = valid ? hi - lo : 0;
             uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             int score = mm, best = 0x7FFFFFFF;
             const uint32_t pbase = peq_base + (uint32_t)b * 36u;
             const int sb0 = fb[t] + lo;  // flat index of the window's first base
+            int e_lo = 0, e_hi = -1;     // split mode: first / last column (of the sweep) with a distance within the budget
             for (int blk = 0;; ++blk) {
                 const int rem = ncol - 32 * blk;
                 if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
@@ -580,17 +582,119 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
                     A[u] |= junk;
                 }
+                uint32_t inm = 0u;
                 if (blk == 0)
-                    sweep_block<TF>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
+                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm);
                 else
-                    sweep_block<0>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best);
+                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm);
+                if (SPLIT) {
+                    // first / last column of the window whose unit distance is within the budget; the
+                    // junk columns behind the window are not columns
+                    inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
+                    if (inm) {
+                        if (e_hi < 0) e_lo = 32 * blk + (int)__builtin_clz(inm);
+                        e_hi = 32 * blk + 31 - (int)__builtin_ctz(inm);
+                    }
+                }
             }
             if (valid && best <= kk) {
-                const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
+                if (SPLIT) {
+                    // candidate bit + one window entry for the exact kernel, exactly as bdx_bitpar.hip's tracked sweeps
+                    // hand them over: {barcode, first column of the restricted run, last column}, 1-based columns
+                    const int pass = b >= a.B0 ? 1 : 0;
+                    const int bl = b - (pass ? a.B0 : 0);
+                    __hip_atomic_fetch_or(&cand[t * 4 + (pass ? a.cw[0] : 0) + (bl >> 5)], 1u << (bl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int kx = __hip_atomic_fetch_add(pass ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (kx < BDX_WCAP && e_hi >= 0) {
+                        const int jf_abs = lo + 1;  // 1-based column of sweep column 0
+                        const int lb = a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1;
+                        uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + ((size_t)(r0 + t) * BDX_WCAP + kx) * 3;
+                        dst[0] = (uint32_t)bl;
+                        dst[1] = (uint32_t)(jf_abs + e_lo - lb);
+                        dst[2] = (uint32_t)(jf_abs + e_hi);
+                    }
+                } else {
+                    const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
+                }
             }
+        };
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int k = s0 + lane;
+            bool valid = k < ns;
+            const uint32_t rslot = valid ? recq[k] : 0u;
+            const uint32_t id = valid ? rid[rslot] : 0u;
+            const uint32_t dmk = valid ? rmk[rslot] : 0u;
+            if (valid) {  // the record is consumed
+                rid[rslot] = 0u;
+                rmk[rslot] = 0u;
+            }
+            valid = valid && id != 0u && dmk != 0u;
+            const int t = (int)(rslot / RCAP), b = valid ? (int)(id & 0xFFFFu) - 1 : 0;
+            int lo = 0, hi = 0;  // [lo, hi): 0-based columns of the sweep
+            if (valid) {
+                const uint32_t mt = meta[b];
+                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
+                const int d0 = (int)(id >> 16) - 64;
+                const int dmin = d0 + __builtin_ctz(dmk) - kk, dmax = d0 + (31 - __builtin_clz(dmk)) - kk;
+                const int n = fb[t + 1] - fb[t];
+                lo = dmin - kk - 1;
+                hi = dmax + mm + kk + 1;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > n ? n : hi;
+            }
+            sweep_lane(valid, t, b, lo, hi);
         }
         WAVE_SYNC();
+        if (SPLIT) {
+            // Reads whose tables overflowed (more records than a read or the tile holds, a hit queue that ran over: low
+            // complexity): every barcode is swept over the whole read here, lane = barcode — the exact kernel then still
+            // gets a true candidate mask.  (Handing such a read on with "every barcode, no windows" would make ONE lane
+            // of the exact kernel run B whole-window DPs one after the other: two such reads in 2 M cost 11 ms.)
+            unsigned long long fm = tile_ok ? __builtin_amdgcn_ballot_w64(lane < nr && (flag[lane] != 0 || !hq_ok)) : 0ull;
+            while (fm) {
+                const int t = (int)__builtin_ctzll(fm);
+                fm &= fm - 1ull;
+                if (lane == 0) {
+                    scnt[t] = 0;
+                    wcl1[t] = 0;
+                    flag[t] = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) cand[t * 4 + w] = 0u;
+                }
+                WAVE_SYNC();
+                const int n = fb[t + 1] - fb[t];
+                for (int b0 = 0; b0 < B; b0 += 64) {
+                    const int b = b0 + lane < B ? b0 + lane : 0;
+                    const bool valid = b0 + lane < B && ((meta[b] >> 8) & 255u) != 255u;  // (255: the barcode can never be recorded)
+                    sweep_lane(valid, t, b, 0, n);
+                }
+                WAVE_SYNC();
+            }
+        }
+
+        if (SPLIT) {
+            // ---- split mode: hand the candidate masks and the window counts to the exact kernel (lane = read) ----
+            if (lane < nr && !BDX_DBG(1)) {
+                const long long rid_g = r0 + lane;
+                const bool usable = tile_ok && !flag[lane];  // (overflows were swept above) else — a tile that does not fit the images: every barcode over its whole window
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    if (pass == 1 && a.cw[1] == 0) break;
+                    const int cwp = a.cw[pass];
+                    uint32_t *dst = a.cand_out[pass] + rid_g * cwp;
+                    for (int w = 0; w < cwp; ++w) dst[w] = usable ? cand[lane * 4 + (pass ? a.cw[0] : 0) + w] : 0xFFFFFFFFu;
+                    const int c = pass ? wcl1[lane] : scnt[lane];
+                    a.wcnt_out[pass][rid_g] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
+                }
+            }
+            WAVE_SYNC();  // the next tile reuses the per-read tables
+            tile = tile_next;
+            geo = geo_next;
+            ov = ov_next;
+            ov_next = ov_after;
+            continue;
+        }
 
         // ---- verdicts: lane = read; reducer replay on the survivors' unit distances ----
         const bool active = lane < nr;
@@ -697,17 +801,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q>
+template <int RW, int TF, int NV, int Q, bool SPLIT>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -722,14 +826,14 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
 
 size_t bdx_wave_area_bytes(int rw, int span_cap) {
     const size_t nvec = (size_t)span_cap >> 4;
-    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 2 * (size_t)rw * 4 + (size_t)3 * rw * 4 + 256;
+    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 3 * (size_t)rw * 4 + (size_t)3 * rw * 4 + 256;
     const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
     return (o + 31) & ~(size_t)31;
 }
 
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg) {
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
     if (n_reads <= 0) return hipSuccess;
     (void)d_tile_counter;  // (tiles are dealt round robin: no queue)
     WaveArgs a;
@@ -758,6 +862,15 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.list = list;
     a.list_count = list_count;
     a.dbg = dbg;
+    a.B0 = wp.b0;
+    for (int k = 0; k < 2; ++k) {
+        a.cw[k] = sp ? sp->cw[k] : 0;
+        a.cand_out[k] = sp ? sp->cand_out[k] : nullptr;
+        a.wins_out[k] = sp ? sp->wins_out[k] : nullptr;
+        a.wcnt_out[k] = sp ? sp->wcnt_out[k] : nullptr;
+        a.short_lb[k] = sp ? sp->short_lb[k] : 0;
+    }
+    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
     long long blocks = (long long)wp.blocks;
@@ -766,9 +879,9 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     if (blocks < 1) blocks = 1;
     const int tf = wp.track_from;
     // instantiated: seeds of 8 bases with every score-tracking start, 7 and 6 bases with the plain ones
-#define BDX_WAVE_NV(RWV, TFV, QV)                                                                   \
-    (wp.span_cap <= 5 * 1024 ? launch_wave<RWV, TFV, 5, QV>(a, lds, wp.waves, blocks, stream)           \
-                             : launch_wave<RWV, TFV, 10, QV>(a, lds, wp.waves, blocks, stream))
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV)                                                              \
+    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false>(a, lds, wp.waves, blocks, stream))
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
            : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
@@ -785,5 +898,6 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
 #undef BDX_WAVE_TF
 }

@@ -237,3 +237,65 @@ def test_wave_full_size_equals_the_general_kernel(monkeypatch):
     soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
     exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
     assert np.array_equal(res[True][0][idx], exp["bc1"])
+
+
+# ---- split mode: the wave kernel as the filter in front of the exact kernel (trimming, summary, weighted costs, dual) ----
+@pytest.mark.parametrize("kw", [
+    dict(trim_side=3), dict(trim_side=5), dict(max_error_rate=0.1, summary=True), dict(trim_side=3, min_delta=0.05),
+    dict(max_error_rate=0.2, trim_side=5), dict(max_error_rate=0.2, trim_side=3, summary=True),   # tiered: tier 1's filter
+    dict(max_error_rate=0.17, mismatch=2, indel=3, trim_side=5),                                  # weighted costs: budget floor(ae / cmin)
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_wave_split_mode(kw, monkeypatch):
+    """Candidate masks and column windows written by the wave kernel, verdicts and trim coordinates from the exact
+    kernel (diagonal band where it applies): identical to the general filter and to the oracle, statistics included."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 40000, 150, seed=31, repeat=dict(frac=0.1))
+    cfg = _cfg(bcs, **kw)
+    exp = _both_kernels(cfg, seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+    if cfg.summary:
+        tabs = {}
+        for wave in (True, False):
+            if not wave:
+                monkeypatch.setenv("BDX_NO_WAVE", "1")
+            with H.bdx.HipClassifier(cfg) as hc:
+                monkeypatch.delenv("BDX_NO_WAVE", raising=False)
+                hc.classify(seq, off)
+                tabs[wave] = hc.stats_tables()
+        for p_ in tabs[True]:
+            for name in tabs[True][p_]:
+                assert np.array_equal(tabs[True][p_][name][0], tabs[False][p_][name][0]), (kw, name)
+
+
+@pytest.mark.parametrize("t1,t2,rate", [(5, 3, 0.2), (5, 3, 0.1), (3, 5, 0.1), (5, None, 0.1), (None, 3, 0.2)])
+def test_wave_split_mode_dual(t1, t2, rate, monkeypatch):
+    """Dual barcodes (C4's shape): both passes' pieces share the wave kernel's hash table, the barcodes of pass 2 are
+    numbered behind those of pass 1; masks, windows and counts go out per pass."""
+    b1 = synth.make_barcodes(24, 24, seed=1)
+    b2 = synth.make_barcodes(16, 24, seed=2)
+    seq, off, _ = synth.make_reads(b1, 40000, 150, seed=41, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                            bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=rate, trim_side=t1, trim_side2=t2)
+    exp = _both_kernels(cfg, seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
+def test_wave_split_low_complexity_and_ragged(monkeypatch):
+    """Overflowing queues in split mode: the affected reads go to the exact kernel with every barcode as a candidate and
+    no windows."""
+    rng = np.random.Generator(np.random.PCG64(12))
+    bcs = ["A" * 24, "AC" * 12, "ACG" * 8, "ACGT" * 6, "T" * 24] + synth.make_barcodes(27, 24, seed=12)
+    motifs = ["A", "AC", "ACG", "ACGT", "T", "TTTTAAAA"]
+    reads = []
+    for i in range(3000):
+        if i % 3 == 0:
+            reads.append("".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(0, 200)))))
+            continue
+        mo = motifs[int(rng.integers(0, len(motifs)))]
+        s = list((mo * 200)[int(rng.integers(0, 8)):][:int(rng.integers(30, 180))])
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, len(s)))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s))
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(trim_side=3), dict(trim_side=5, summary=True)):
+        _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, expect_wave=False)
