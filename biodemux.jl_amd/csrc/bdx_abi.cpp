@@ -590,15 +590,18 @@ int build_wave_tables(bdx_ctx *ctx) {
     const BdxSeedPlan &sp = F.splan;
     const int npass = c.is_dual ? 2 : 1;
     if (ctx->tune.no_wave || !bp.enabled || !sp.enabled || sp.diag || bp.word_bytes != 4 || sp.n_always[0] != 0 || sp.n_always[1] != 0 ||
-        sp.q < 6 || sp.q > 8 || c.algorithm != BDX_ALG_SEMIGLOBAL || c.has_nindel)
+        sp.q < 6 || sp.q > 8 || (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel))
         return BDX_OK;
     // known-score configs: the kernel replays the reducer itself (single pass); everything else in the filters' domain:
     // "split" — it only filters, candidate masks and column windows go to the exact kernel (either pass count)
     bool split = false;
     for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
     if (!split && c.is_dual) return BDX_OK;
-    int cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
-    if (cmin < 1 || c.match < 0) return BDX_OK;
+    // :hamming / :exact (always split: their scans run in the exact kernel, restricted to the hand-over windows): the
+    // budget is floor(rate * m) substitutions / 0, one operation costs 1
+    const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
+    int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
+    if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     int Btot = 0, cwt = 0;
     for (int k = 0; k < npass; ++k) {
@@ -616,7 +619,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     const int q = sp.q;
     struct Piece { int g, start; const uint8_t *bc; };
     std::vector<Piece> pieces;
-    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u);  // (stride 9: bank spread, see the kernel)
+    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);  // (stride 9: bank spread, see the kernel)
     int track = 1 << 20, g = 0;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
@@ -634,9 +637,9 @@ int build_wave_tables(bdx_ctx *ctx) {
                         if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
                 peq8[(size_t)g * 9 + code] = mask;
             }
-            const long long ae = (long long)std::floor(c.max_error_rate * (double)m);  // (SimpleScoring: normalisation = m)
+            const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);  // (normalisation = m)
             if (ae < 0) {  // can never be recorded: neither seeded nor swept (budget field 255)
-                meta[(size_t)g] = (uint32_t)m | (255u << 8);
+                meta[(size_t)g] = (uint32_t)m | (255u << 8) | (255u << 16);
                 continue;
             }
             long long kb = ae / cmin;
@@ -644,7 +647,23 @@ int build_wave_tables(bdx_ctx *ctx) {
             if (kb > 15) return BDX_OK;  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
             const long long L = m / (kb + 1);
             if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
-            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8);
+            // lone-survivor tables of the replay (bdx_wave.hip): the reference accepts a survivor with distance d iff
+            // d <= floor(max_error_rate * m) (:254) and score = d / m <= max_error_rate (:658 / :696) — both Float64, both
+            // evaluated here exactly as the device would; tier 1 settles it iff score < slo (and, with_delta, the bound
+            // slo - score >= min_delta proves "not ambiguous")
+            int dmax = 255;
+            uint32_t sbits = 0;
+            for (long long d = 0; d <= kb && d <= 15; ++d) {
+                const double score = (double)d / (double)m;
+                if (d <= ae && score <= c.max_error_rate) dmax = (int)d;
+                const double slo = bp.tier_slo[k];
+                if (score < slo) {
+                    sbits |= 1u << d;
+                    if ((slo - score) >= c.min_delta) sbits |= 1u << (16 + d);
+                }
+            }
+            settle[(size_t)g] = sbits;
+            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8) | ((uint32_t)dmax << 16);
             if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
             for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{g, (int)(t * L), bc});
         }
@@ -683,13 +702,14 @@ int build_wave_tables(bdx_ctx *ctx) {
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_bm = 0, o_hash = al(bitmap.size()), o_ps = o_hash + al(hash.size() * 4), o_peq = o_ps + al(hash_ps.size()),
-                 o_meta = o_peq + al(peq8.size() * 4), bytes = o_meta + al(meta.size() * 4);
+                 o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4), bytes = o_settle + al(settle.size() * 4);
     std::vector<uint8_t> blob(bytes, 0);
     memcpy(blob.data() + o_bm, bitmap.data(), bitmap.size());
     memcpy(blob.data() + o_hash, hash.data(), hash.size() * 4);
     memcpy(blob.data() + o_ps, hash_ps.data(), hash_ps.size());
     memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
     memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
+    memcpy(blob.data() + o_settle, settle.data(), settle.size() * 4);
     HIP_TRY(ctx, F.wave_tables.ensure(bytes));
     HIP_TRY(ctx, hipMemcpy(F.wave_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)F.wave_tables.p;
@@ -698,6 +718,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.d_hash_ps = base + o_ps;
     wp.d_peq8 = (const uint32_t *)(base + o_peq);
     wp.d_meta = (const uint32_t *)(base + o_meta);
+    wp.d_settle = (const uint32_t *)(base + o_settle);
     wp.enabled = 1;
     return BDX_OK;
 }

@@ -182,7 +182,8 @@ struct BdxWavePlan {
     const uint32_t *d_hash;      // key << 16 | barcode + 1
     const uint8_t *d_hash_ps;
     const uint32_t *d_peq8;      // [B][9] (stride 9 dwords): rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
-    const uint32_t *d_meta;      // [B]: m | kb << 8
+    const uint32_t *d_meta;      // [B]: m | kb << 8 | lone-survivor accept threshold << 16
+    const uint32_t *d_settle;    // [B]: tier 1 settle bits of a lone survivor per distance (no_delta | with_delta << 16)
     // per batch (size_wave)
     int rw;                // reads per wave tile (32 / 16 / 8)
     int waves;             // waves per workgroup

@@ -49,7 +49,8 @@ struct WaveArgs {
     const uint8_t *hash_ps;  // piece start (bases) of every entry
     int hash_log2;
     const uint32_t *peq8;    // [B][9]: sweep word of barcode b for symbol code c (4..7: "other"; the ninth word pads the stride)
-    const uint32_t *meta;    // [B]: m | kb << 8
+    const uint32_t *meta;    // [B]: m | kb << 8 | (largest distance the reducer accepts for a lone survivor, 255: none) << 16
+    const uint32_t *settle;  // [B]: tier 1, lone survivor: bit d = a read whose only survivor has distance d is settled (no_delta: low half, with_delta: high half)
     int B;
     int q;
     int span_cap;            // bytes of one tile's span the images hold
@@ -66,6 +67,7 @@ struct WaveArgs {
     uint32_t *wins_out[2];   // [n_reads][BDX_WCAP][3] = {barcode, first column of the restricted run, last column}
     uint8_t *wcnt_out[2];    // [n_reads] entries valid (255: none -> whole window)
     int short_lb[2];         // lookback m + kb instead of 2 (m + kb) + 1
+    int sg;                  // :semiglobal (else :hamming / :exact: a window entry's first field is the first START position)
     int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a skip bit
               // is set: 1 skip verdicts, 2 skip sweeps, 4 skip resolve + emit, 8 skip seed scan, 32 skip transcode, 64 skip loads
 };
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS unsigned char *hps = take((size_t)1 << a.hash_log2);
     LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 36);  // 9 dwords per barcode: (9 b + code) mod 32 spreads over every bank
     LDS uint32_t *meta = (LDS uint32_t *)take((size_t)B * 4);
+    LDS uint32_t *settle = (LDS uint32_t *)take((size_t)B * 4);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
     // per-wave work area: the arrays whose size only depends on RW come first, at compile-time offsets from the area's
     // base (one base register + immediate offsets in the DS instructions), the two images after them
@@ -261,7 +264,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         hps[i] = a.hash_ps[i];
     }
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
-    for (int i = tid; i < B; i += blockDim.x) meta[i] = a.meta[i];
+    for (int i = tid; i < B; i += blockDim.x) {
+        meta[i] = a.meta[i];
+        settle[i] = a.settle[i];
+    }
     for (int i = tid; i < a.hist_entries; i += blockDim.x) hist[i] = 0;
     __syncthreads();
 
@@ -607,7 +613,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     const int kx = __hip_atomic_fetch_add(pass ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (kx < BDX_WCAP && e_hi >= 0) {
                         const int jf_abs = lo + 1;  // 1-based column of sweep column 0
-                        const int lb = a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1;
+                        // :semiglobal: first column of the restricted run; :hamming / :exact: first start position
+                        const int lb = !a.sg ? mm - 1 : (a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1);
                         uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + ((size_t)(r0 + t) * BDX_WCAP + kx) * 3;
                         dst[0] = (uint32_t)bl;
                         dst[1] = (uint32_t)(jf_abs + e_lo - lb);
@@ -707,7 +714,28 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             const int cnt = scnt[lane];
             // known-score class per read: this kernel only runs for configs whose ranges resolve to
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
-            if (!flag[lane] && cnt <= 4 && n >= 1) {
+            const bool simple = a.out.pass_start == nullptr && a.out.pass_end == nullptr && a.out.pass_raw == nullptr && a.out.pass_bc == nullptr &&
+                                a.out.pass_score == nullptr && a.out.pass_delta == nullptr;  // (kernel-uniform: only the verdict vectors are wanted)
+            if (simple && !flag[lane] && cnt <= 1 && n >= 1) {
+                // No or one survivor and nobody asked for scores: the reducers' answer for a lone survivor with distance d is a
+                // per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
+                // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
+                // IEEE operations (build_wave_tables); likewise tier 1's settle rule.  No Float64 here.
+                done = true;
+                if (cnt == 1) {
+                    const uint32_t e = slots[lane * 4];
+                    const int bb = (int)(e >> 8), d = (int)(e & 255u);
+                    const int dmax = (int)((meta[bb] >> 16) & 255u);
+                    vd.bc1 = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
+                    if (a.tier) done = vd.bc1 > 0 && ((settle[bb] >> (d + (a.min_delta == 0.0 ? 0 : 16))) & 1u) != 0u;
+                } else {
+                    vd.bc1 = 0;
+                    if (a.tier) done = false;  // (nothing within the capped budgets: tier 0 decides)
+                }
+                vd.bc2 = 0;
+                vd.keep_start = vd.bc1 > 0 ? 1 : -1;  // :907-908 / :879-883 (ScoreOnly: the whole read, n >= 1)
+                vd.keep_end = vd.bc1 > 0 ? n : -1;
+            } else if (!flag[lane] && cnt <= 4 && n >= 1) {
                 const LDS uint32_t *e0 = slots + lane * 4;
                 const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
                 const KnownPass kn1{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
@@ -821,7 +849,7 @@ hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long block
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
     return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 36) +
-           al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
+           2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
 size_t bdx_wave_area_bytes(int rw, int span_cap) {
@@ -853,6 +881,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.hash_log2 = wp.hash_log2;
     a.peq8 = wp.d_peq8;
     a.meta = wp.d_meta;
+    a.settle = wp.d_settle;
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
@@ -870,6 +899,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
         a.wcnt_out[k] = sp ? sp->wcnt_out[k] : nullptr;
         a.short_lb[k] = sp ? sp->short_lb[k] : 0;
     }
+    a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
     if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;

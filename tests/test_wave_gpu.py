@@ -299,3 +299,17 @@ def test_wave_split_low_complexity_and_ragged(monkeypatch):
     seq, off = H.bdx.pack_reads(reads)
     for kw in (dict(trim_side=3), dict(trim_side=5, summary=True)):
         _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, expect_wave=False)
+
+
+@pytest.mark.parametrize("kw", [dict(matching_algorithm="hamming", max_error_rate=0.1), dict(matching_algorithm="hamming", max_error_rate=0.13, trim_side=3),
+                                dict(matching_algorithm="exact"), dict(matching_algorithm="exact", trim_side=5),
+                                dict(matching_algorithm="hamming", max_error_rate=0.2, min_delta=0.05)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_wave_split_mode_hamming_and_exact(kw, monkeypatch):
+    """:hamming / :exact (classification.jl:485-625): the wave kernel's sweeps bound the unit edit distance, which is at
+    most the Hamming distance of an occurrence; the window entries carry the first START position and the last end column
+    (classification.jl:490-491, :570-571), the scans themselves run in the exact kernel."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 40000, 150, seed=51, repeat=dict(frac=0.1))
+    exp = _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, expect_wave=kw.get("max_error_rate") != 0.2)
+    assert (exp["bc1"] > 0).mean() > 0.2
