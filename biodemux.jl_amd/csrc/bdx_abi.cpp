@@ -46,6 +46,7 @@ BdxTuning read_tuning() {
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_wave = getenv("BDX_NO_WAVE") != nullptr;
+    t.no_pairs = getenv("BDX_NO_PAIRS") != nullptr;
     t.poison = getenv("BDX_POISON") != nullptr;
     if (const char *e = getenv("BDX_WAVE_RW")) t.wave_rw = atoi(e);
     if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
@@ -760,6 +761,158 @@ bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
     }
     if (best_waves < 4) return false;
     wp.read_len_hint = read_len;
+    return true;
+}
+
+// ---- pairs mode of the wave kernel (bdx_pairs.hip): tables of the FULL-budget set --------------------------------
+// Between tier 1 and the general kernel of a tiered config: the reads tier 1 lists are gathered into slots and filtered
+// by the two-intact-pieces lemma on barcode masks (one table entry per (piece, 4-base key): the barcodes whose piece has
+// that key).  Eligible: the conditions of build_wave_tables on alphabet, lengths and ranges; every barcode's budget kb
+// at most 4 with 4 (kb + 2) <= m (kb + 2 disjoint 4-base pieces at offsets 0, 4, ..); at most 128 barcodes.
+int build_pair_tables(bdx_ctx *ctx) {
+    const bdx_config_t &c = ctx->cfg;
+    BdxFilterSet &F = ctx->F();
+    BdxWavePlan &wp = F.pplan;
+    wp = BdxWavePlan{};
+    const BdxBitparPlan &bp = F.bplan;
+    const int npass = c.is_dual ? 2 : 1;
+    if (ctx->tune.no_wave || ctx->tune.no_pairs || !bp.enabled || bp.word_bytes != 4 || bp.tier_capped || c.filter != BDX_FILTER_AUTO ||
+        (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel))
+        return BDX_OK;
+    bool split = false;
+    for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
+    if (!split && c.is_dual) return BDX_OK;
+    const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
+    const int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
+    if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
+    const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
+    int Btot = 0, cwt = 0;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        if (p.n_barcodes < 1) return BDX_OK;
+        for (uint32_t i = 0; i < p.bc_off[p.n_barcodes]; ++i) {
+            const uint8_t ch = p.bc_bytes[i];
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return BDX_OK;
+        }
+        Btot += p.n_barcodes;
+        cwt += (p.n_barcodes + 31) / 32;
+    }
+    if (Btot > 128 || (split && cwt > 4)) return BDX_OK;
+    const int nw = (Btot + 31) / 32;
+    const int estride = nw <= 2 ? 8 : 16;
+    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);
+    int kmax = 0, track = 1 << 20, mmin = 1 << 20, g = 0;
+    struct Bc { int g, m, kb; const uint8_t *bc; };
+    std::vector<Bc> bcs;
+    for (int k = 0; k < npass; ++k) {
+        const bdx_pass_t &p = c.pass[k];
+        for (int b = 0; b < p.n_barcodes; ++b, ++g) {
+            const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+            if (m < 1 || m > 32) return BDX_OK;
+            const uint8_t *bc = p.bc_bytes + p.bc_off[b];
+            const int shift = 32 - m;
+            const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
+            const uint32_t pad = ~rows;
+            for (int code = 0; code < 8; ++code) {
+                uint32_t mask = pad;
+                if (code < 4)
+                    for (int i = 0; i < m; ++i)
+                        if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
+                peq8[(size_t)g * 9 + code] = mask;
+            }
+            const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);
+            if (ae < 0) {  // can never be recorded: in no table entry, never swept
+                meta[(size_t)g] = (uint32_t)m | (255u << 8) | (255u << 16);
+                continue;
+            }
+            const long long kb = ae / cmin;
+            if (kb > 4 || 4 * (kb + 2) > m) return BDX_OK;
+            int dmax = 255;
+            for (long long d = 0; d <= kb; ++d)  // lone-survivor accept threshold of the replay, as in build_wave_tables
+                if (d <= ae && (double)d / (double)m <= c.max_error_rate) dmax = (int)d;
+            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8) | ((uint32_t)dmax << 16);
+            if ((int)kb > kmax) kmax = (int)kb;
+            if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
+            if (m < mmin) mmin = m;
+            bcs.push_back(Bc{g, m, (int)kb, bc});
+        }
+    }
+    if (bcs.empty() || track < 12) return BDX_OK;
+    const int KB = kmax <= 3 ? 3 : 4, P = KB + 2;
+    std::vector<uint32_t> tab((size_t)P * 256 * (size_t)(estride / 4), 0u);
+    for (const Bc &x : bcs)
+        for (int t = 0; t < x.kb + 2; ++t) {
+            uint32_t key = 0;
+            for (int i = 0; i < 4; ++i) key |= (uint32_t)((x.bc[4 * t + i] >> 1) & 3) << (2 * i);
+            tab[((size_t)t * 256 + key) * (size_t)(estride / 4) + (size_t)(x.g >> 5)] |= 1u << (x.g & 31);
+        }
+    wp.q = 4;
+    wp.n_barcodes = Btot;
+    wp.b0 = c.pass[0].n_barcodes;
+    wp.split = split ? 1 : 0;
+    wp.bm_bytes = (int)(tab.size() * 4);
+    wp.hash_log2 = 0;
+    wp.track_from = track > 28 ? 28 : track;
+    wp.pairs_kb = KB;
+    wp.nw = nw;
+    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_tab = 0, o_peq = al(tab.size() * 4), o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4),
+                 bytes = o_settle + al(settle.size() * 4);
+    std::vector<uint8_t> blob(bytes, 0);
+    memcpy(blob.data() + o_tab, tab.data(), tab.size() * 4);
+    memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
+    memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
+    memcpy(blob.data() + o_settle, settle.data(), settle.size() * 4);
+    HIP_TRY(ctx, F.pair_tables.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy(F.pair_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
+    const uint8_t *base = (const uint8_t *)F.pair_tables.p;
+    wp.d_bitmap = base + o_tab;
+    wp.d_hash = (const uint32_t *)base;  // (never read)
+    wp.d_hash_ps = base;
+    wp.d_peq8 = (const uint32_t *)(base + o_peq);
+    wp.d_meta = (const uint32_t *)(base + o_meta);
+    wp.d_settle = (const uint32_t *)(base + o_settle);
+    ctx->pair_mmin = mmin;
+    wp.enabled = 1;
+    return BDX_OK;
+}
+
+// Geometry of the pairs mode for a batch: 16-read tiles of slots of `read_len` rounded up to 16 bytes.
+bool size_pairs(bdx_ctx *ctx, int read_len) {
+    BdxWavePlan &wp = ctx->fs[0].pplan;
+    if (!wp.enabled || ctx->dev.vlen) return false;
+    if (read_len < 1) read_len = 1;
+    const int slot = (read_len + 15) & ~15;
+    const int rw = 16;
+    const int span = rw * slot + 16;
+    if (span > 6 * 1024) return false;  // (instantiated: three and six 16-byte vectors per lane)
+    int cpr = ((read_len - ctx->pair_mmin + wp.pairs_kb + 8) >> 4) + 1;
+    if (read_len < ctx->pair_mmin) cpr = 1;
+    if (cpr > slot / 16) cpr = slot / 16;
+    if (cpr < 1) cpr = 1;
+    const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
+    const size_t area = bdx_wave_area_bytes(rw, span, true);
+    int best = 0;
+    const int shapes[3] = {16, 8, 4};
+    for (int w : shapes) {
+        if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
+        const size_t lds = tables + (size_t)w * area;
+        if (lds > LDS_MAX) continue;
+        int per_cu = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));
+        if (per_cu * w > 16) per_cu = 16 / w;
+        if (per_cu * w > best) {
+            best = per_cu * w;
+            wp.waves = w;
+            wp.blocks = per_cu * ctx->n_cu;
+        }
+    }
+    if (best < 4) return false;
+    wp.rw = rw;
+    wp.span_cap = span;
+    wp.slot = slot;
+    wp.cpr = cpr;
     return true;
 }
 
@@ -1519,6 +1672,8 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     }
     rc = build_wave_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
+    rc = build_pair_tables(ctx);
+    if (rc != BDX_OK) return bail(rc);
     // tier 1 (capped budgets, strict single seeds) beside a full-budget set that is NOT already strict single seeds
     {
         const BdxFilterSet &full = ctx->fs[0];
@@ -1654,6 +1809,8 @@ void bdx_destroy(bdx_ctx *ctx) {
         f.wave_tables.release();
     }
     ctx->d_wlist.release();
+    ctx->d_gseq.release();
+    ctx->d_glen.release();
     ctx->d_tier.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
@@ -1888,14 +2045,15 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // kernel as before.  Tiered: tier 1 (all reads); plain: the only filter launch.
         bool wsplit1 = false, wsplit0 = false;
         BdxWaveSplit wsp{};
+        for (int k = 0; k < 2; ++k) {
+            wsp.cw[k] = k < npass ? ctx->dev.pass[k].cand_words : 0;
+            wsp.cand_out[k] = k ? c1 : c0;
+            wsp.wins_out[k] = k ? w1 : w0;
+            wsp.wcnt_out[k] = k ? n1 : n0;
+            wsp.short_lb[k] = short_lb[k];
+        }
+        const BdxWaveSplit &wsp_all = wsp;
         if (split && windows && !ctx->dev.vlen) {
-            for (int k = 0; k < 2; ++k) {
-                wsp.cw[k] = k < npass ? ctx->dev.pass[k].cand_words : 0;
-                wsp.cand_out[k] = k ? c1 : c0;
-                wsp.wins_out[k] = k ? w1 : w0;
-                wsp.wcnt_out[k] = k ? n1 : n0;
-                wsp.short_lb[k] = short_lb[k];
-            }
             if (tiered)
                 wsplit1 = ctx->fs[1].wplan.split && size_wave(ctx, 1, batch_len, n_reads);
             else
@@ -1940,11 +2098,42 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
         if (tiered || wave0) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false));
+        // Pairs mode of the wave kernel between tier 1 and the general kernel: the listed reads are gathered into slots and
+        // filtered at the full budgets by the two-intact-pieces lemma.  Known-score configs: it answers them (what it cannot
+        // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the
+        // listed reads for the exact kernel).
+        bool pairs = false;
+        if (tiered && (!split || windows) && !dense_w && size_pairs(ctx, tier_len)) {
+            const BdxWavePlan &pp = ctx->fs[0].pplan;
+            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
+            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
+            if (!split) HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            if (ctx->tune.poison) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
+                if (!split) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
+            }
+            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, t0.in_list, t0.in_count, n_reads, (uint8_t *)ctx->d_gseq.p,
+                                           (int *)ctx->d_glen.p, pp.slot, tier_len, ctx->n_cu, ctx->stream));
+            uint32_t *list2 = split ? nullptr : (uint32_t *)ctx->d_wlist.p;
+            unsigned int *count2 = split ? nullptr : (unsigned int *)(scratch + 320);
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, t0.in_list,
+                                          t0.in_count, o, split ? nullptr : ctx->counts, list2, count2, ctx->stream, ctx->tune.debug, split ? &wsp_all : nullptr));
+            ctx->pair_launches += 1;
+            pairs = true;
+            if (!split) {  // the general kernel (list mode) evaluates what is left
+                t0.in_list = list2;
+                t0.in_count = count2;
+                HIP_TRY(ctx, poison_check(list2, count2, true, false));
+            }
+        }
         ctx->F().bplan.d_tile_counter = (int *)(scratch + 64);
         ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
         ctx->F().bplan.dbg = ctx->tune.debug;
-        if (wsplit0) {
+        if (pairs && split) {
+            // (tier 0's filter already ran: the pairs mode wrote the listed reads' masks and windows)
+        } else if (wsplit0) {
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                          nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
             ctx->wave_launches += 1;
@@ -1978,6 +2167,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         if (wsplit0) ctx->path = "wave+verify";
+        if (pairs) ctx->path = split ? "pairs+verify" : "pairs > " + ctx->path;
         if (tiered) ctx->path = ((wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = "wave > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
@@ -2168,6 +2358,7 @@ int64_t bdx_window_uploads(const bdx_ctx *ctx) { return ctx ? ctx->window_upload
 int64_t bdx_band_launches(const bdx_ctx *ctx) { return ctx ? ctx->band_launches : 0; }
 
 int64_t bdx_wave_launches(const bdx_ctx *ctx) { return ctx ? ctx->wave_launches : 0; }
+int64_t bdx_pair_launches(const bdx_ctx *ctx) { return ctx ? ctx->pair_launches : 0; }
 
 int64_t bdx_pipelined_calls(const bdx_ctx *ctx) { return ctx ? ctx->pipelined_calls : 0; }
 

@@ -48,6 +48,7 @@ struct BdxTuning {
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
     int poison = 0;       // BDX_POISON: every hand-over buffer is filled with 0xA5 before each classify call (tests: a consumer that reads what no producer wrote gets garbage on every run, not only when the allocator happens to hand back dirty memory)
+    int no_pairs = 0;     // BDX_NO_PAIRS: never the pairs-mode kernel (bdx_pairs.hip) between tier 1 and the general kernel
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;
@@ -70,6 +71,8 @@ struct BdxFilterSet {
     DevBuf bp_tables, seed_tables, seed_tables_alt;
     BdxWavePlan wplan{};   // wave-autonomous kernel (bdx_wave.hip) for this set, when the config qualifies
     DevBuf wave_tables;
+    BdxWavePlan pplan{};   // the same kernel in pairs mode (bdx_pairs.hip) at this set's full budgets, over listed reads
+    DevBuf pair_tables;
 };
 
 struct bdx_ctx {
@@ -89,6 +92,9 @@ struct bdx_ctx {
     int device = 0;
     int n_cu = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount, read in bdx_create)
     int64_t wave_launches = 0;  // launches of the wave-autonomous kernel
+    int64_t pair_launches = 0;  // launches of its pairs mode
+    int pair_mmin = 0;          // shortest barcode of the pairs plan
+    DevBuf d_gseq, d_glen;      // the listed reads gathered into slots + their lengths (input of the pairs mode)
     DevBuf d_dbg;            // [0] hand-over windows the exact kernel refused (not a window: defence in depth; must stay 0)
     DevBuf d_wlist;          // reads the wave kernel hands to the general kernel (plain configs; tiered ones use d_tier)
     hipStream_t own_stream = nullptr;

@@ -190,6 +190,12 @@ struct BdxWavePlan {
     int blocks;            // persistent grid
     int span_cap;          // bytes of a tile's span the images hold
     int read_len_hint;     // the read length the geometry was planned for
+    // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
+    // tables [kb + 2][256] of barcode masks, there is no hash
+    int pairs_kb;          // 0: single seeds; else the largest budget (3 / 4)
+    int nw;                // words of a barcode mask
+    int slot;              // bytes per gathered read
+    int cpr;               // 16-diagonal chunks scanned per read
 };
 
 // Tiered budgets: tier 1 (tier1 = 1) appends the reads it cannot settle to out_list / *out_count; tier 0 then
@@ -225,7 +231,14 @@ struct BdxWaveSplit {
 
 // Implemented in bdx_wave.hip.
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
-size_t bdx_wave_area_bytes(int rw, int span_cap);
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs = false);
+// Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
+hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
+                            const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,
+                            uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);
+// Gathers the reads of a list into slots of `slot` bytes (padded with 'N') + their lengths (bdx_device.hip).
+hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const uint32_t *d_list, const unsigned int *d_count,
+                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
                            double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);

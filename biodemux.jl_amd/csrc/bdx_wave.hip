@@ -68,6 +68,14 @@ struct WaveArgs {
     uint8_t *wcnt_out[2];    // [n_reads] entries valid (255: none -> whole window)
     int short_lb[2];         // lookback m + kb instead of 2 (m + kb) + 1
     int sg;                  // :semiglobal (else :hamming / :exact: a window entry's first field is the first START position)
+    // pairs mode (KB > 0; two-intact-pieces filter over the reads an earlier tier listed): the reads were gathered into
+    // slots of `slot` bytes (16-byte multiple, padded with 'N'); read k of the gathered buffer is read idmap[k] of the batch
+    int slot;                // bytes per slot
+    int cpr;                 // 16-diagonal chunks scanned per read
+    int cpr_inv;             // ceil(2^16 / cpr)
+    const int *lens;         // [count] read lengths
+    const uint32_t *idmap;   // [count] batch read numbers (= the list the reads were gathered from)
+    const unsigned int *n_dev;  // the number of gathered reads lives on the device
     int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a skip bit
               // is set: 1 skip verdicts, 2 skip sweeps, 4 skip resolve + emit, 8 skip seed scan, 32 skip transcode, 64 skip loads
 };
@@ -80,6 +88,7 @@ struct WaveArgs {
 #endif
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 #define WAVE_SYNC()                                          \
     do {                                                     \
@@ -200,12 +209,17 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 }
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
-// on); Q: seed length
-template <int RW, int TF, int NV, int Q, bool SPLIT>
+// on); Q: seed length.
+// KB > 0: PAIRS mode — the filter is the two-intact-pieces lemma instead of single seeds (budgets up to KB, see the
+// scan below), the input is a gathered slot buffer, every flagged (barcode, diagonal run) is one sweep (no record
+// tables); NW: words of a barcode mask (table entries of 8 bytes for NW <= 2, else 16).
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
+    constexpr bool PAIRS = KB > 0;
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
-    constexpr int HQ = 6 * RW;    // seed hits per tile
-    constexpr int SQ = 3 * RW;    // sweeps (= records) per tile
+    constexpr int HQ = PAIRS ? 56 * RW : 6 * RW;  // seed hits per tile (pairs mode: flagged (barcode, diagonal run)s = sweeps)
+    constexpr int SQ = PAIRS ? 0 : 3 * RW;        // sweeps (= records) per tile
+    constexpr int NREC = PAIRS ? 0 : RW * RCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
     const int tid = threadIdx.x;
@@ -213,6 +227,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: tile numbers and their geometry live in scalar registers)
     const int B = a.B;
     constexpr int q = Q;  // seed length
+    // (pairs mode: the number of gathered reads is only known on the device)
+    const long long n_reads = PAIRS ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
     size_t o = 0;
@@ -234,14 +250,16 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int O_FB = 0;                                  // int[RW + 1]: flat index of every read's first base
     constexpr int O_HQ = O_FB + ((RW + 1) * 4 + 15) / 16 * 16;  // u32[HQ]: seed hits: flat position << 16 | key
     constexpr int O_RID = O_HQ + HQ * 4;                     // u32[RW * RCAP]: sweep records: barcode + 1 | (first diagonal + 64) << 16
-    constexpr int O_RMK = O_RID + RW * RCAP * 4;             // u32[RW * RCAP]: diagonals seen, as bits: diagonal - first + kb
-    constexpr int O_SLOTS = O_RMK + RW * RCAP * 4;           // u32[RW * 4]: survivors: barcode << 8 | d
+    constexpr int O_RMK = O_RID + NREC * 4;                  // u32[RW * RCAP]: diagonals seen, as bits: diagonal - first + kb
+    constexpr int O_SLOTS = O_RMK + NREC * 4;                // u32[RW * 4]: survivors: barcode << 8 | d
     constexpr int O_SCNT = O_SLOTS + RW * 16;                // int[RW]
     constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
     constexpr int O_WCL1 = O_FLAG + RW * 4;                  // int[RW]: split mode: window entries written for pass 1 (pass 0: scnt)
     constexpr int O_RECQ = O_WCL1 + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
     constexpr int O_LBUF = O_RECQ + SQ * 4;                  // u32[64]: reads for the list, flushed in batches
-    constexpr int O_IMG2 = O_LBUF + 64 * 4;                  // u32[nvec_cap + 2]: 2-bit image
+    constexpr int O_RL = O_LBUF + 64 * 4;                    // int[RW]: pairs mode: read lengths (the slots are longer)
+    constexpr int O_GID = O_RL + (PAIRS ? RW * 4 : 0);       // u32[RW]: pairs mode: batch read numbers of the gathered reads
+    constexpr int O_IMG2 = O_GID + (PAIRS ? RW * 4 + 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (pairs mode: four guard words in front)
     const int nvec_cap = a.span_cap >> 4;
     LDS int *fb = (LDS int *)(wbase + O_FB);
     LDS uint32_t *hq = (LDS uint32_t *)(wbase + O_HQ);
@@ -254,15 +272,19 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS int *wcl1 = (LDS int *)(wbase + O_WCL1);
     LDS uint32_t *cand = slots;  // split mode: candidate masks [RW][4 words: pass 0 then pass 1] (no replay, no slots)
     LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
+    LDS int *rl = (LDS int *)(wbase + O_RL);
+    LDS uint32_t *gid = (LDS uint32_t *)(wbase + O_GID);
     LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
-    for (int i = tid; i < (1 << a.hash_log2); i += blockDim.x) {
-        hsh[i] = a.hash[i];
-        hps[i] = a.hash_ps[i];
-    }
+    if (!PAIRS)  // (pairs mode: `bm` holds the piece tables, there is no hash)
+        for (int i = tid; i < (1 << a.hash_log2); i += blockDim.x) {
+            hsh[i] = a.hash[i];
+            hps[i] = a.hash_ps[i];
+        }
+    if (PAIRS && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
     for (int i = tid; i < B; i += blockDim.x) {
         meta[i] = a.meta[i];
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     __syncthreads();
 
     const uint32_t peq_base = (uint32_t)(uintptr_t)peq;
-    const int ntiles = (int)((a.n_reads + RW - 1) / RW);  // (< 2^29: a batch holds fewer than 2^32 reads)
+    const int ntiles = (int)((n_reads + RW - 1) / RW);  // (< 2^29: a batch holds fewer than 2^32 reads)
     const uint32_t hmask = (1u << a.hash_log2) - 1u;
 
     // Tiles are dealt round robin over all waves of the grid (tile = wave + k x waves): no queue, no atomics.  The
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     const auto geometry = [&](const int t, const long long ov) -> Geo {
         Geo g;
         const long long r0 = (long long)t * RW;
-        g.nr = (int)(a.n_reads - r0 < RW ? a.n_reads - r0 : RW);
+        g.nr = (int)(n_reads - r0 < RW ? n_reads - r0 : RW);
         const uint32_t ov_lo = (uint32_t)ov, ov_hi = (uint32_t)(ov >> 32);
         g.span0 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, 0) << 32) | __builtin_amdgcn_readlane(ov_lo, 0));
         const long long span1 = (long long)(((unsigned long long)__builtin_amdgcn_readlane(ov_hi, g.nr) << 32) | __builtin_amdgcn_readlane(ov_lo, g.nr));
@@ -305,14 +327,25 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     };
     const auto load_offsets = [&](const int t) -> long long {  // (t < 2^30 also when it runs past the last tile)
         const long long r0 = (long long)t * RW;
-        const long long left = a.n_reads - r0;
+        const long long left = n_reads - r0;
         const int cnt = t < ntiles ? (int)(left < RW ? left : RW) : -1;  // lanes 0 .. cnt load
+        if (PAIRS) return lane <= cnt ? (r0 + lane) * (long long)a.slot : 0;  // slots: no offsets to load
         // wave-uniform base in scalar registers + a 32-bit lane offset
         const uintptr_t bp = (uintptr_t)(a.off + r0);
         const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bp), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
         const long long *base = (const long long *)(((uintptr_t)bhi << 32) | blo);
         return lane <= cnt ? base[lane] : 0;
     };
+    // pairs mode: length and batch read number of the tile's reads (lanes 0 .. cnt - 1), requested with the offsets
+    const auto load_len = [&](const int t) -> int {
+        const long long r0 = (long long)t * RW;
+        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? a.lens[r0 + lane] : 0;
+    };
+    const auto load_gid = [&](const int t) -> uint32_t {
+        const long long r0 = (long long)t * RW;
+        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? a.idmap[r0 + lane] : 0u;
+    };
+    const auto rlen = [&](const int t) -> int { return PAIRS ? rl[t] : fb[t + 1] - fb[t]; };
     u32x4 v[NV];
     LDS uint32_t *const img2_lane = img2 + lane;      // (one base register each: the unrolled stores differ by immediates)
     LDS uint32_t *const img4_lane = img4 + 2 * lane;
@@ -347,6 +380,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         load_bytes(geo);
     }
     long long ov_next = load_offsets(tile + nwaves);
+    int lv = load_len(tile), lv_next = load_len(tile + nwaves);
+    uint32_t iv = load_gid(tile), iv_next = load_gid(tile + nwaves);
 
     while (tile < ntiles) {
         const long long r0 = (long long)tile * RW;
@@ -359,6 +394,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         if (lane < RW) {
             scnt[lane] = 0;
             flag[lane] = 0;
+            if (PAIRS) {
+                rl[lane] = lv;
+                gid[lane] = iv;
+            }
             if (SPLIT) {
                 wcl1[lane] = 0;
 #pragma unroll
@@ -390,6 +429,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             load_bytes(geo_next);
         }
         const long long ov_after = load_offsets(tile_next + nwaves);
+        const int lv_after = load_len(tile_next + nwaves);
+        const uint32_t iv_after = load_gid(tile_next + nwaves);
         WAVE_SYNC();
 
         // uniform read length of the tile (0: mixed) for the hit -> read mapping
@@ -404,7 +445,113 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         // The bitmap is read as 32-bit words (word = key >> 5 at LDS address 0 + 4 word, bit = key & 31): the shift
         // that brings the key to bit 0 also is the shift amount of the bit test (the hardware takes its low five bits).
         int nhq = 0;  // seed hits of the tile so far (wave-uniform)
-        {
+        if constexpr (PAIRS) {
+            // ---- pairs scan: lane = 16 consecutive diagonals of one read ----
+            // Two-intact-pieces lemma: an alignment of barcode b with at most kb <= KB unit operations leaves at least two
+            // of the kb + 2 disjoint 4-base pieces at barcode offsets 0, 4, 8, .. untouched; they occur in the read on
+            // diagonals (read position - barcode offset) at most kb apart, and the alignment lies within the columns
+            // [d - kb, d + m + kb) of the larger diagonal d.  Per diagonal, the table entry of (piece t, key of the read's
+            // four bases at d + 4 t) is the set of barcodes whose piece t has that key, as a bit mask over the barcodes:
+            // `twice` = barcodes with two pieces on this diagonal, `once & near` = one here and one on the KB diagonals
+            // before.  Flagged barcodes are swept over that window; every other pair has a distance beyond its budget.
+            // Keys of positions outside the read are whatever the image holds there: they can only add sweeps.
+            constexpr int P = KB + 2;
+            constexpr int ESTRIDE = NW <= 2 ? 8 : 16;   // bytes per table entry
+            constexpr int TSTRIDE = 256 * ESTRIDE;      // bytes per piece table (the tables start at LDS address 0)
+            constexpr int XLO = -8 - KB;                // first position, relative to the chunk, whose key is needed
+            constexpr int NX = 16 + KB + 4 * (P - 1);   // positions
+            uint32_t amask = 0xFFu * ESTRIDE;
+            asm volatile("" : "+v"(amask));
+            const int s16 = a.slot >> 4;
+            const int items = BDX_DBG(8) ? 0 : nr * a.cpr;
+            for (int i0 = 0; i0 < items; i0 += 64) {
+                const int i = i0 + lane;
+                const bool on = i < items;
+                const int t = on ? (int)(((uint32_t)i * (uint32_t)a.cpr_inv) >> 16) : 0;
+                const int c = on ? i - t * a.cpr : 0;
+                uint32_t Fl[NW], dmw[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
+                if (on) {
+                    // chunk c holds the diagonals d = 16 c - 8 + j, j = 0 .. 15; position of piece t on diagonal d: d + 4 t
+                    const int g = t * s16 + c;
+                    const uint32_t wm1 = img2[g - 1], w0 = img2[g], w1 = img2[g + 1];
+                    uint32_t ad[NX];  // LDS byte offset of the key's entry within a piece table
+#pragma unroll
+                    for (int xi = 0; xi < NX; ++xi) {
+                        const int bit = 2 * (XLO + xi + 16) - (ESTRIDE == 16 ? 4 : 3);  // the key lands at bit 4 (3): times 16 (8)
+                        const int wi = bit >> 5, sh = bit & 31;
+                        const uint32_t lo = wi == 0 ? wm1 : (wi == 1 ? w0 : w1);
+                        const uint32_t hi = wi == 0 ? w0 : (wi == 1 ? w1 : 0u);
+                        ad[xi] = __builtin_amdgcn_alignbit(hi, lo, sh) & amask;
+                    }
+                    uint32_t Ah[KB][NW];  // barcodes with any piece on each of the previous KB diagonals
+#pragma unroll
+                    for (int j = -KB; j < 16; ++j) {
+                        uint32_t H[P][NW];
+#pragma unroll
+                        for (int tt = 0; tt < P; ++tt) {
+                            const uint32_t ea = ad[j - 8 + 4 * tt - XLO] + (uint32_t)(tt * TSTRIDE);
+                            if constexpr (NW == 1) {
+                                H[tt][0] = *(const LDS uint32_t *)(bm + ea);
+                            } else if constexpr (NW == 2) {
+                                const u32x2 x = *(const LDS u32x2 *)(bm + ea);
+                                H[tt][0] = x[0];
+                                H[tt][1] = x[1];
+                            } else if constexpr (NW == 3) {
+                                const u32x3 x = *(const LDS u32x3 *)(bm + ea);
+                                H[tt][0] = x[0];
+                                H[tt][1] = x[1];
+                                H[tt][2] = x[2];
+                            } else {
+                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);
+                                H[tt][0] = x[0];
+                                H[tt][1] = x[1];
+                                H[tt][2] = x[2];
+                                H[tt][3] = x[3];
+                            }
+                        }
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            uint32_t once = H[0][w] | H[1][w];
+                            uint32_t twice = H[0][w] & H[1][w];
+#pragma unroll
+                            for (int tt = 2; tt < P; ++tt) {
+                                if (j >= 0) twice |= once & H[tt][w];
+                                once |= H[tt][w];
+                            }
+                            if (j >= 0) {
+                                uint32_t near = Ah[0][w];
+#pragma unroll
+                                for (int u = 1; u < KB; ++u) near |= Ah[u][w];
+                                const uint32_t F = twice | (once & near);
+                                Fl[w] |= F;
+                                dmw[w] = (dmw[w] << 1) | (F != 0u ? 1u : 0u);  // bit 15 - j
+                            }
+                            Ah[(j + KB) % KB][w] = once;  // (replaces the oldest)
+                        }
+                    }
+                }
+                // one queue entry per flagged barcode: barcode | read << 7 | (last - first flagged diagonal) << 12 | (first + 64) << 16
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t bits = Fl[w];
+                    const int jlo = 15 - (31 - (int)__builtin_clz(dmw[w] | 1u)), jhi = 15 - (int)__builtin_ctz(dmw[w] | 0x10000u);
+                    const uint32_t common = ((uint32_t)t << 7) | ((uint32_t)(jhi - jlo) << 12) | ((uint32_t)(16 * c - 8 + jlo + 64) << 16);
+                    unsigned long long mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                    while (mk) {
+                        const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        if (bits) {
+                            const int bi = __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            if (k < HQ) hq[k] = common | (uint32_t)(32 * w + bi);
+                        }
+                        nhq += (int)__builtin_popcountll(mk);
+                        mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                    }
+                }
+            }
+        } else {
             constexpr uint32_t AMASK = ((1u << (2 * Q - 5)) - 1u) << 2;
             constexpr uint32_t KMASK = (1u << (2 * Q)) - 1u;
             uint32_t amask = AMASK;
@@ -458,7 +605,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         // the replay takes the smallest of a barcode's entries (bdx_core.h run_pass_known).  The lane that opens a
         // record appends its slot number to the tile's record list: the records ARE the sweeps.
         int ns = 0;  // records of the tile so far (wave-uniform)
-        {
+        if constexpr (!PAIRS) {
             const int fb0 = fb[0];
             const float rinv = ulen > 0 ? 1.0f / (float)ulen : 0.0f;
             const float ginv = total > 0 ? (float)nr / (float)total : 0.0f;
@@ -615,7 +762,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         const int jf_abs = lo + 1;  // 1-based column of sweep column 0
                         // :semiglobal: first column of the restricted run; :hamming / :exact: first start position
                         const int lb = !a.sg ? mm - 1 : (a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1);
-                        uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + ((size_t)(r0 + t) * BDX_WCAP + kx) * 3;
+                        const size_t rg = PAIRS ? (size_t)gid[t] : (size_t)(r0 + t);
+                        uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + (rg * BDX_WCAP + kx) * 3;
                         dst[0] = (uint32_t)bl;
                         dst[1] = (uint32_t)(jf_abs + e_lo - lb);
                         dst[2] = (uint32_t)(jf_abs + e_hi);
@@ -626,6 +774,23 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 }
             }
         };
+        if constexpr (PAIRS) {
+            // pairs mode: every queue entry is a sweep over the columns [first - kb, last + m + kb) of its diagonals
+            for (int s0 = 0; s0 < nh; s0 += 64) {
+                const int k = s0 + lane;
+                bool valid = k < nh;
+                const uint32_t h = valid ? hq[k] : 0u;
+                const int b = (int)(h & 127u), t = (int)((h >> 7) & 31u), wd = (int)((h >> 12) & 15u), dlo = (int)(h >> 16) - 64;
+                const uint32_t mt = meta[b];
+                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
+                valid = valid && kk != 255;
+                const int n = rl[t];
+                int lo = dlo - kk, hi = dlo + wd + mm + kk;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > n ? n : hi;
+                sweep_lane(valid, t, b, lo, hi);
+            }
+        } else
         for (int s0 = 0; s0 < ns; s0 += 64) {
             const int k = s0 + lane;
             bool valid = k < ns;
@@ -644,7 +809,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
                 const int d0 = (int)(id >> 16) - 64;
                 const int dmin = d0 + __builtin_ctz(dmk) - kk, dmax = d0 + (31 - __builtin_clz(dmk)) - kk;
-                const int n = fb[t + 1] - fb[t];
+                const int n = rlen(t);
                 lo = dmin - kk - 1;
                 hi = dmax + mm + kk + 1;
                 lo = lo < 0 ? 0 : lo;
@@ -670,7 +835,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     for (int w = 0; w < 4; ++w) cand[t * 4 + w] = 0u;
                 }
                 WAVE_SYNC();
-                const int n = fb[t + 1] - fb[t];
+                const int n = rlen(t);
                 for (int b0 = 0; b0 < B; b0 += 64) {
                     const int b = b0 + lane < B ? b0 + lane : 0;
                     const bool valid = b0 + lane < B && ((meta[b] >> 8) & 255u) != 255u;  // (255: the barcode can never be recorded)
@@ -683,7 +848,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         if (SPLIT) {
             // ---- split mode: hand the candidate masks and the window counts to the exact kernel (lane = read) ----
             if (lane < nr && !BDX_DBG(1)) {
-                const long long rid_g = r0 + lane;
+                const long long rid_g = PAIRS ? (long long)gid[lane] : r0 + lane;
                 const bool usable = tile_ok && !flag[lane];  // (overflows were swept above) else — a tile that does not fit the images: every barcode over its whole window
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
@@ -700,17 +865,21 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             geo = geo_next;
             ov = ov_next;
             ov_next = ov_after;
+            lv = lv_next;
+            lv_next = lv_after;
+            iv = iv_next;
+            iv_next = iv_after;
             continue;
         }
 
         // ---- verdicts: lane = read; reducer replay on the survivors' unit distances ----
         const bool active = lane < nr;
-        const long long ridx = r0 + lane;
+        const long long ridx = PAIRS ? (long long)gid[lane < RW ? lane : 0] : r0 + lane;
         Verdict vd{0, 0, -1, -1};
         PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
         bool done = false;
         if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
-            const int n = fb[lane + 1] - fb[lane];
+            const int n = rlen(lane);
             const int cnt = scnt[lane];
             // known-score class per read: this kernel only runs for configs whose ranges resolve to
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
@@ -817,6 +986,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         geo = geo_next;
         ov = ov_next;
         ov_next = ov_after;
+        lv = lv_next;
+        lv_next = lv_after;
+        iv = iv_next;
+        iv_next = iv_after;
     }
 
     flush_list();
@@ -829,48 +1002,25 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
-}  // namespace
-
-// LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
-size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
-    auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
-    return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 36) +
-           2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
-}
-
-size_t bdx_wave_area_bytes(int rw, int span_cap) {
-    const size_t nvec = (size_t)span_cap >> 4;
-    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + (size_t)6 * rw * 4 + 2 * (size_t)rw * 8 * 4 + (size_t)rw * 16 + 3 * (size_t)rw * 4 + (size_t)3 * rw * 4 + 256;
-    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
-    return (o + 31) & ~(size_t)31;
-}
-
-hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
-                           long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
-    if (n_reads <= 0) return hipSuccess;
-    (void)d_tile_counter;  // (tiles are dealt round robin: no queue)
-    WaveArgs a;
+void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const BdxDevOut &out, unsigned long long *d_counts,
+               uint32_t *list, unsigned int *list_count, int dbg, const BdxWaveSplit *sp) {
     a.max_error_rate = cfg.max_error_rate;
     a.min_delta = cfg.min_delta;
     a.counts_stride2 = cfg.counts_stride2;
-    a.seq = d_seq;
-    a.off = d_off;
-    a.n_reads = n_reads;
     a.out = out;
     a.counts = d_counts;
     a.hist_entries = hist_entries;
@@ -885,9 +1035,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap);
-    a.tier = tier1;
-    a.tier_slo = tier_slo;
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0);
     a.list = list;
     a.list_count = list_count;
     a.dbg = dbg;
@@ -900,6 +1048,47 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
         a.short_lb[k] = sp ? sp->short_lb[k] : 0;
     }
     a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
+    a.slot = 0;
+    a.cpr = 1;
+    a.cpr_inv = 65536;
+    a.lens = nullptr;
+    a.idmap = nullptr;
+    a.n_dev = nullptr;
+}
+
+}  // namespace
+
+#ifndef BDX_WAVE_TU_PAIRS
+// LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
+size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
+    auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
+    return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 36) +
+           2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
+}
+
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs) {
+    const size_t nvec = (size_t)span_cap >> 4;
+    const size_t hq = pairs ? (size_t)56 * rw * 4 : (size_t)6 * rw * 4;
+    const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4 + (size_t)3 * rw * 4;  // record tables + the record list
+    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + hq + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
+                         (pairs ? 2 * (size_t)rw * 4 + 16 : 0);
+    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
+    return (o + 31) & ~(size_t)31;
+}
+
+hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                           long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
+    if (n_reads <= 0) return hipSuccess;
+    (void)d_tile_counter;  // (tiles are dealt round robin: no queue)
+    WaveArgs a;
+    fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, sp);
+    a.seq = d_seq;
+    a.off = d_off;
+    a.n_reads = n_reads;
+    a.tier = tier1;
+    a.tier_slo = tier_slo;
+    if (wp.pairs_kb > 0) return hipErrorInvalidValue;
     if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
@@ -910,7 +1099,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     const int tf = wp.track_from;
     // instantiated: seeds of 8 bases with every score-tracking start, 7 and 6 bases with the plain ones
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV)                                                              \
-    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false>(a, lds, wp.waves, blocks, stream))
+    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0>(a, lds, wp.waves, blocks, stream))
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -929,5 +1118,49 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
 #undef BDX_WAVE_SP
-#undef BDX_WAVE_TF
 }
+
+#else  // BDX_WAVE_TU_PAIRS: the pairs-mode instantiations live in a translation unit of their own (bdx_pairs.hip)
+
+// Pairs mode over the reads of a list (gathered into slots by bdx_launch_gather): final verdicts at the full budgets for
+// the known-score class (what it cannot answer goes to `list`), candidate masks + windows in split mode.
+hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
+                            const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,
+                            uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
+    if (wp.pairs_kb <= 0 || !d_slots || !d_lens || !d_idmap || !d_count) return hipErrorInvalidValue;
+    WaveArgs a;
+    fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, sp);
+    a.seq = d_slots;
+    a.off = nullptr;
+    a.n_reads = 0;
+    a.tier = 0;
+    a.tier_slo = 0.0;
+    a.slot = wp.slot;
+    a.cpr = wp.cpr;
+    a.cpr_inv = (65536 + wp.cpr - 1) / wp.cpr;
+    a.lens = d_lens;
+    a.idmap = d_idmap;
+    a.n_dev = d_count;
+    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
+    if (wp.rw * wp.cpr > 32 * 40 || (wp.slot & 15) || wp.rw * wp.slot + 16 > wp.span_cap) return hipErrorInvalidValue;
+    const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
+    const long long blocks = wp.blocks < 1 ? 1 : wp.blocks;
+    const int tf = wp.track_from;
+#define BDX_PAIRS_SP(RWV, TFV, NVV, KBV, NWV)                                                                                  \
+    (wp.split ? launch_wave<RWV, TFV, NVV, 4, true, KBV, NWV>(a, lds, wp.waves, blocks, stream)                                \
+              : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
+#define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
+#define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
+#define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
+    // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
+    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12) return hipErrorInvalidValue;
+    if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
+    if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
+    return hipErrorInvalidValue;
+#undef BDX_PAIRS_TF
+#undef BDX_PAIRS_KB
+#undef BDX_PAIRS_NW
+#undef BDX_PAIRS_SP
+}
+
+#endif

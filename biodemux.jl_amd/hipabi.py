@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
-    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pipelined_calls", "bdx_rejected_windows",
+    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pair_launches", "bdx_pipelined_calls", "bdx_rejected_windows",
     "bdx_debug_rejected_windows_total",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
@@ -486,6 +486,11 @@ class HipClassifier:
     def wave_launches(self) -> int:
         """Launches of the wave-autonomous kernel (bdx_wave.hip) this context made."""
         return int(self.lib.bdx_wave_launches(self.h))
+
+    @property
+    def pair_launches(self) -> int:
+        """Launches of the wave kernel's pairs mode (bdx_pairs.hip) this context made."""
+        return int(self.lib.bdx_pair_launches(self.h))
 
     @property
     def window_uploads(self) -> int:

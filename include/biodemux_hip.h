@@ -277,6 +277,12 @@ int64_t bdx_band_launches(const bdx_ctx *ctx);
  * tests can tell which kernel ran. */
 int64_t bdx_wave_launches(const bdx_ctx *ctx);
 
+/* How many launches of the same kernel's PAIRS mode this context made (bdx_pairs.hip): tiered configs (budgets too large
+ * for selective single seeds, e.g. the reference's default max_error_rate 0.2 on 24-nt barcodes) gather the reads tier 1
+ * could not settle and filter them at the full budgets by the two-intact-pieces lemma, ahead of the general kernel.
+ * Results are identical either way (env BDX_NO_PAIRS switches it off); a test-visibility counter like the one above. */
+int64_t bdx_pair_launches(const bdx_ctx *ctx);
+
 /* How many bdx_classify_host calls uploaded their batch in chunks on a copy stream beside the previous chunk's kernels
  * (large batches of configs with heavier kernels; env BDX_NO_PIPELINE switches it off).  Results are identical. */
 int64_t bdx_pipelined_calls(const bdx_ctx *ctx);

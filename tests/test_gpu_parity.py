@@ -371,8 +371,8 @@ def _all_filters_agree(cfg, seq, off, expect_path=None, hint=None):
             fuzz.assert_same(got, exp, f"filter {flt} [{hc.kernel_path}]")
             assert np.array_equal(hc.counts, oc.counts)
     if expect_path:  # (known-score configs run tier 1 in front: "tier1:qgram+bitpar > <full-budget path>"; split configs that
-        # qualify for the wave kernel as their filter report "wave+verify")
-        assert paths["auto"].endswith(expect_path) or paths["auto"].endswith("wave+verify"), paths
+        # qualify for the wave kernel as their filter report "wave+verify" / (tier 0 of tiered ones) "pairs+verify")
+        assert paths["auto"].endswith(expect_path) or paths["auto"].endswith("wave+verify") or paths["auto"].endswith("pairs+verify"), paths
     return exp
 
 

@@ -17,6 +17,15 @@ from biodemux_jl_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    # (torch's bundled HIP runtime has to come up before the library's first bdx_create in a process that uses both:
+    # the other order leaves torch without a device — INTEGRATION.md)
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+
+
 def _cfg(bcs, **kw):
     base = dict(bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"bc{i + 1}" for i in range(len(bcs))],
                 max_error_rate=0.1)
