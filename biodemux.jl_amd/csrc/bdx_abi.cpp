@@ -2118,7 +2118,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             uint32_t *list2 = split ? nullptr : (uint32_t *)ctx->d_wlist.p;
             unsigned int *count2 = split ? nullptr : (unsigned int *)(scratch + 320);
             HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, t0.in_list,
-                                          t0.in_count, o, split ? nullptr : ctx->counts, list2, count2, ctx->stream, ctx->tune.debug, split ? &wsp_all : nullptr));
+                                          t0.in_count, o, split ? nullptr : ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, split ? &wsp_all : nullptr));
             ctx->pair_launches += 1;
             pairs = true;
             if (!split) {  // the general kernel (list mode) evaluates what is left

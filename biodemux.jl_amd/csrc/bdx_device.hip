@@ -383,7 +383,7 @@ __global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list
 
 // ---- gather: the reads of a list -> slots (input of the wave kernel's pairs mode, bdx_pairs.hip) ----
 // Read list[k] of the batch is copied to slots[k * slot .. ) and padded with 'N' up to the slot size; lens[k] is its
-// length, or -1 when it is longer than the planned length (the consumer hands such a read on).  One wave per read, one lane per dword:
+// length, or -1 when it is longer than the planned length (the consumer hands such a read on).  Sixteen lanes per read, one lane per dword:
 // the source is unaligned, so every dword is funnelled out of the two aligned dwords it straddles (the second one is
 // only touched when bytes of the read lie in it).
 namespace {
@@ -391,18 +391,19 @@ __global__ __launch_bounds__(256) void bdx_gather_kernel(const uint8_t *seq, con
                                                          long long n_cap, uint8_t *slots, int *lens, const int slot, const int max_len) {
     long long n = (long long)*count;
     if (n > n_cap) n = n_cap;
-    const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    // sixteen lanes per read (four reads per wave side by side: the list -> offsets -> bytes chain is latency-bound)
+    const int sub = threadIdx.x & 15;
+    const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
     const int dw = slot >> 2;
-    for (long long k = wave; k < n; k += nwaves) {
+    for (long long k = grp; k < n; k += ngrp) {
         const uint32_t id = list[k];
         const long long o0 = off[id];
         long long len = off[id + 1] - o0;
         const bool fits = len >= 0 && len <= (long long)max_len;  // (the scan was planned for reads up to max_len <= slot)
         if (!fits) len = 0;
-        if (lane == 0) lens[k] = fits ? (int)len : -1;
+        if (sub == 0) lens[k] = fits ? (int)len : -1;
         uint32_t *dst = (uint32_t *)(slots + (size_t)k * (size_t)slot);
-        for (int w = lane; w < dw; w += 64) {
+        for (int w = sub; w < dw; w += 16) {
             const int b0 = 4 * w;
             uint32_t v = 0x4E4E4E4Eu;
             if (b0 < len) {
@@ -428,7 +429,7 @@ hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const
                              long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream) {
     if (!d_seq || !d_off || !d_list || !d_count || !d_slots || !d_lens || slot < 16 || (slot & 15) || max_len > slot) return hipErrorInvalidValue;
     long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * 8;
-    const long long useful = (n_cap + 3) / 4;
+    const long long useful = (n_cap + 15) / 16;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bdx_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq, d_off, d_list, d_count, n_cap, d_slots, d_lens, slot, max_len);

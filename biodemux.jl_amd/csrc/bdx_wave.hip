@@ -179,7 +179,7 @@ __device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
 template <int TF, bool TRACKW>
 __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3,
                                             const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best, const int kk1,
-                                            uint32_t &inm) {
+                                            uint32_t &inm, const int ngr) {
     const uint32_t A[4] = {A0, A1, A2, A3};
     uint32_t Eq[2][8];
     const auto issue = [&](const int h) __attribute__((always_inline)) {
@@ -192,8 +192,9 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
     inm = 0u;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {  // the Eq words of the next eight columns fly while these eight are worked on
+        if (h >= ngr) break;       // (wave-uniform: no lane has a column in the remaining groups of eight)
         lds_wait8(Eq[h & 1]);
-        if (h < 3) issue(h + 1);
+        if (h < 3 && h + 1 < ngr) issue(h + 1);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = 8 * h + jj;
@@ -206,6 +207,7 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
             }
         }
     }
+    if (TRACKW && ngr < 4) inm <<= 32 - 8 * ngr;  // (bit 31 - j stands for column j also when the block stopped early)
 }
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
@@ -736,10 +738,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     A[u] |= junk;
                 }
                 uint32_t inm = 0u;
+                // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
+                const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
                 if (blk == 0)
-                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm);
+                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
                 else
-                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm);
+                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
                 if (SPLIT) {
                     // first / last column of the window whose unit distance is within the budget; the
                     // junk columns behind the window are not columns
