@@ -853,7 +853,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // ---- split mode: hand the candidate masks and the window counts to the exact kernel (lane = read) ----
             if (lane < nr && !BDX_DBG(1)) {
                 const long long rid_g = PAIRS ? (long long)gid[lane] : r0 + lane;
-                const bool usable = tile_ok && !flag[lane];  // (overflows were swept above) else — a tile that does not fit the images: every barcode over its whole window
+                const bool usable = tile_ok && !flag[lane] && (!PAIRS || rl[lane] >= 0);  // (overflows were swept above) else — a tile that does not fit the images, a read longer than its slot: every barcode over its whole window
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
                     if (pass == 1 && a.cw[1] == 0) break;
