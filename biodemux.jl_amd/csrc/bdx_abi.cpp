@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <new>
 #include <string>
@@ -678,36 +679,61 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.split = split ? 1 : 0;
     wp.bm_bytes = (1 << (2 * q)) / 8;
     wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
-    wp.hash_log2 = 8;
-    while ((1u << wp.hash_log2) < pieces.size() * 2) wp.hash_log2++;
-    std::vector<uint8_t> bitmap((size_t)wp.bm_bytes, 0), hash_ps((size_t)1 << wp.hash_log2, 0);
-    std::vector<uint32_t> hash((size_t)1 << wp.hash_log2, 0);
-    const uint32_t hmask = (1u << wp.hash_log2) - 1;
+    // seed table: the bitmap is exact (one bit per key of the 4^q key space), so a hit's entry is found by the RANK of its
+    // key among the keys present (prefix count per bitmap word + a popcount); pieces that share a key are chained
+    std::vector<uint8_t> bitmap((size_t)wp.bm_bytes, 0);
+    struct Ent { uint32_t key; int g, start; };
+    std::vector<Ent> ents;
     for (const Piece &pc : pieces) {
         uint32_t key = 0;
         for (int i = 0; i < q; ++i) key |= (uint32_t)((pc.bc[pc.start + i] >> 1) & 3) << (2 * i);
+        bool dup = false;  // one entry per (key, barcode, piece start)
+        for (const Ent &e : ents) dup |= e.key == key && e.g == pc.g && e.start == pc.start;
+        if (dup) continue;
         bitmap[key >> 3] |= (uint8_t)(1u << (key & 7));
-        const uint32_t entry = (key << 16) | (uint32_t)(pc.g + 1);
-        uint32_t slot = (key * 0x9E3779B1u) >> (32 - wp.hash_log2);
-        bool dup = false;  // one entry per (key, barcode, piece start): two pieces of one barcode may share a key
-        while (hash[slot] != 0) {
-            if (hash[slot] == entry && hash_ps[slot] == (uint8_t)pc.start) { dup = true; break; }
-            slot = (slot + 1) & hmask;
-        }
-        if (!dup) {
-            hash[slot] = entry;
-            hash_ps[slot] = (uint8_t)pc.start;
+        ents.push_back(Ent{key, pc.g, pc.start});
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.key < y.key; });
+    std::vector<uint32_t> ent;  // heads (one per key, in key order) first, chained entries behind them
+    std::vector<uint32_t> chain;
+    {
+        std::vector<size_t> head_of;  // index into ents of every head
+        for (size_t i = 0; i < ents.size(); ++i)
+            if (i == 0 || ents[i].key != ents[i - 1].key) head_of.push_back(i);
+        const size_t D = head_of.size();
+        if (ents.size() >= 65536) return BDX_OK;
+        ent.assign(ents.size(), 0u);
+        size_t next_free = D;
+        for (size_t h = 0; h < D; ++h) {
+            const size_t first = head_of[h], last = h + 1 < D ? head_of[h + 1] : ents.size();
+            size_t at = h;
+            for (size_t i = first; i < last; ++i) {
+                const size_t nxt = i + 1 < last ? next_free++ : 0;
+                ent[at] = (uint32_t)(ents[i].g + 1) | ((uint32_t)ents[i].start << 11) | ((uint32_t)nxt << 16);
+                at = nxt;
+            }
         }
     }
+    std::vector<uint16_t> rank((size_t)wp.bm_bytes / 4, 0);
+    {
+        uint32_t run = 0;
+        for (size_t w = 0; w < rank.size(); ++w) {
+            rank[w] = (uint16_t)run;
+            uint32_t word;
+            memcpy(&word, bitmap.data() + 4 * w, 4);
+            run += (uint32_t)__builtin_popcount(word);
+        }
+    }
+    wp.n_ent = (int)ent.size();
     // the tables must leave room for at least eight waves' work areas at the smallest tile
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
-    const size_t o_bm = 0, o_hash = al(bitmap.size()), o_ps = o_hash + al(hash.size() * 4), o_peq = o_ps + al(hash_ps.size()),
+    const size_t o_bm = 0, o_rank = al(bitmap.size()), o_ent = o_rank + al(rank.size() * 2), o_peq = o_ent + al(ent.size() * 4),
                  o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4), bytes = o_settle + al(settle.size() * 4);
     std::vector<uint8_t> blob(bytes, 0);
     memcpy(blob.data() + o_bm, bitmap.data(), bitmap.size());
-    memcpy(blob.data() + o_hash, hash.data(), hash.size() * 4);
-    memcpy(blob.data() + o_ps, hash_ps.data(), hash_ps.size());
+    memcpy(blob.data() + o_rank, rank.data(), rank.size() * 2);
+    memcpy(blob.data() + o_ent, ent.data(), ent.size() * 4);
     memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
     memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
     memcpy(blob.data() + o_settle, settle.data(), settle.size() * 4);
@@ -715,8 +741,8 @@ int build_wave_tables(bdx_ctx *ctx) {
     HIP_TRY(ctx, hipMemcpy(F.wave_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)F.wave_tables.p;
     wp.d_bitmap = base + o_bm;
-    wp.d_hash = (const uint32_t *)(base + o_hash);
-    wp.d_hash_ps = base + o_ps;
+    wp.d_rank = (const uint16_t *)(base + o_rank);
+    wp.d_ent = (const uint32_t *)(base + o_ent);
     wp.d_peq8 = (const uint32_t *)(base + o_peq);
     wp.d_meta = (const uint32_t *)(base + o_meta);
     wp.d_settle = (const uint32_t *)(base + o_settle);
@@ -852,7 +878,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.b0 = c.pass[0].n_barcodes;
     wp.split = split ? 1 : 0;
     wp.bm_bytes = (int)(tab.size() * 4);
-    wp.hash_log2 = 0;
+    wp.n_ent = 0;
     wp.track_from = track > 28 ? 28 : track;
     wp.pairs_kb = KB;
     wp.nw = nw;
@@ -869,8 +895,8 @@ int build_pair_tables(bdx_ctx *ctx) {
     HIP_TRY(ctx, hipMemcpy(F.pair_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)F.pair_tables.p;
     wp.d_bitmap = base + o_tab;
-    wp.d_hash = (const uint32_t *)base;  // (never read)
-    wp.d_hash_ps = base;
+    wp.d_rank = (const uint16_t *)base;  // (never read)
+    wp.d_ent = (const uint32_t *)base;
     wp.d_peq8 = (const uint32_t *)(base + o_peq);
     wp.d_meta = (const uint32_t *)(base + o_meta);
     wp.d_settle = (const uint32_t *)(base + o_settle);

@@ -172,15 +172,15 @@ struct BdxSeedPlan {
 struct BdxWavePlan {
     int enabled;           // config-level eligibility of this filter set
     int q;                 // seed length (6..8)
-    int hash_log2;
+    int n_ent;             // seed table entries (one per (key, barcode, piece start))
     int n_barcodes;        // of all passes together (the barcodes of pass 1 are numbered behind those of pass 0)
     int b0;                // barcodes of pass 0
     int split;             // the set's config is outside the known-score class: the kernel only filters (candidate masks + column windows for the exact kernel)
     int bm_bytes;          // direct bitmap over the 4^q keys
     int track_from;        // columns [0, track_from) of a sweep cannot end an alignment within any barcode's budget
     const uint8_t *d_bitmap;
-    const uint32_t *d_hash;      // key << 16 | barcode + 1
-    const uint8_t *d_hash_ps;
+    const uint16_t *d_rank;      // [bm_bytes / 4]: keys present below each 32-bit word of the bitmap
+    const uint32_t *d_ent;       // barcode + 1 | piece start << 11 | next entry of the same key << 16
     const uint32_t *d_peq8;      // [B][9] (stride 9 dwords): rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
     const uint32_t *d_meta;      // [B]: m | kb << 8 | lone-survivor accept threshold << 16
     const uint32_t *d_settle;    // [B]: tier 1 settle bits of a lone survivor per distance (no_delta | with_delta << 16)

@@ -45,9 +45,9 @@ struct WaveArgs {
     int hist_entries;
     const uint8_t *bitmap;   // direct bitmap over the 4^q keys
     int bm_bytes;
-    const uint32_t *hash;    // key << 16 | barcode + 1 (0: empty), open addressing
-    const uint8_t *hash_ps;  // piece start (bases) of every entry
-    int hash_log2;
+    const uint16_t *rank;    // [bm_bytes / 4]: keys present below each 32-bit word of the bitmap
+    const uint32_t *ent;     // [n_ent]: barcode + 1 | piece start << 11 | next entry with the same key << 16 (0: none); entry i < keys present belongs to the i-th key
+    int n_ent;
     const uint32_t *peq8;    // [B][9]: sweep word of barcode b for symbol code c (4..7: "other"; the ninth word pads the stride)
     const uint32_t *meta;    // [B]: m | kb << 8 | (largest distance the reducer accepts for a lone survivor, 255: none) << 16
     const uint32_t *settle;  // [B]: tier 1, lone survivor: bit d = a read whose only survivor has distance d is settled (no_delta: low half, with_delta: high half)
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         return p;
     };
     LDS unsigned char *bm = take((size_t)a.bm_bytes);  // LDS address 0: a probe's address is its byte index
-    LDS uint32_t *hsh = (LDS uint32_t *)take((size_t)4 << a.hash_log2);
-    LDS unsigned char *hps = take((size_t)1 << a.hash_log2);
+    LDS uint16_t *rnk = (LDS uint16_t *)take(PAIRS ? 0 : (size_t)a.bm_bytes / 2);
+    LDS uint32_t *ent = (LDS uint32_t *)take((size_t)a.n_ent * 4);
     LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 36);  // 9 dwords per barcode: (9 b + code) mod 32 spreads over every bank
     LDS uint32_t *meta = (LDS uint32_t *)take((size_t)B * 4);
     LDS uint32_t *settle = (LDS uint32_t *)take((size_t)B * 4);
@@ -281,11 +281,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
-    if (!PAIRS)  // (pairs mode: `bm` holds the piece tables, there is no hash)
-        for (int i = tid; i < (1 << a.hash_log2); i += blockDim.x) {
-            hsh[i] = a.hash[i];
-            hps[i] = a.hash_ps[i];
-        }
+    if (!PAIRS) {  // (pairs mode: `bm` holds the piece tables)
+        for (int i = tid; i < a.bm_bytes / 8; i += blockDim.x) ((LDS uint32_t *)rnk)[i] = ((const uint32_t *)a.rank)[i];
+        for (int i = tid; i < a.n_ent; i += blockDim.x) ent[i] = a.ent[i];
+    }
     if (PAIRS && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
     for (int i = tid; i < B; i += blockDim.x) {
@@ -297,7 +296,6 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
 
     const uint32_t peq_base = (uint32_t)(uintptr_t)peq;
     const int ntiles = (int)((n_reads + RW - 1) / RW);  // (< 2^29: a batch holds fewer than 2^32 reads)
-    const uint32_t hmask = (1u << a.hash_log2) - 1u;
 
     // Tiles are dealt round robin over all waves of the grid (tile = wave + k x waves): no queue, no atomics.  The
     // bytes of tile k + 1 are requested while tile k is worked on, its offsets one tile earlier still, so the HBM
@@ -637,14 +635,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     const int p = pos - f0, n = f1 - f0;
                     // a seed lies inside its read (final_search_range = 1:n for this kernel's configs, classification.jl:795-800)
                     if (ok && p >= 0 && p + q <= n) {
-                        uint32_t slot = (key * 0x9E3779B1u) >> (32 - a.hash_log2);
-                        for (;;) {
-                            const uint32_t e = hsh[slot];
-                            if (e == 0u) break;
-                            if ((e >> 16) == key) {
-                                const uint32_t pb = e & 0xFFFFu;  // barcode + 1
+                        // the key is in the bitmap (the bitmap is exact): its entry is the one with the key's rank among the
+                        // keys present; further pieces with the same key (rare) hang off it
+                        const uint32_t wi = key >> 5;
+                        uint32_t idx = (uint32_t)rnk[wi] + (uint32_t)__builtin_popcount(((const LDS uint32_t *)bm)[wi] & ((1u << (key & 31u)) - 1u));
+                        do {
+                            const uint32_t e = ent[idx];
+                            idx = e >> 16;
+                            {
+                                const uint32_t pb = e & 2047u;  // barcode + 1
                                 const int kk = (int)((meta[pb - 1u] >> 8) & 255u);
-                                const int diag = p - (int)hps[slot];
+                                const int diag = p - (int)((e >> 11) & 31u);
                                 const uint32_t mine = pb | ((uint32_t)(diag + 64) << 16);
                                 int rs = (int)((pb + (uint32_t)(diag >> 3)) & (RCAP - 1));
                                 bool placed = false;
@@ -678,8 +679,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                                 }
                                 if (!placed) flag[t] = 1;  // more than RCAP records in this read
                             }
-                            slot = (slot + 1) & hmask;
-                        }
+                        } while (idx != 0u);
                     }
                 }
                 // the slots opened in this round -> the record list (at most two layers)
@@ -1030,9 +1030,9 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.hist_entries = hist_entries;
     a.bitmap = wp.d_bitmap;
     a.bm_bytes = wp.bm_bytes;
-    a.hash = wp.d_hash;
-    a.hash_ps = wp.d_hash_ps;
-    a.hash_log2 = wp.hash_log2;
+    a.rank = wp.d_rank;
+    a.ent = wp.d_ent;
+    a.n_ent = wp.n_ent;
     a.peq8 = wp.d_peq8;
     a.meta = wp.d_meta;
     a.settle = wp.d_settle;
@@ -1066,7 +1066,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
-    return al((size_t)wp.bm_bytes) + al((size_t)4 << wp.hash_log2) + al((size_t)1 << wp.hash_log2) + al((size_t)wp.n_barcodes * 36) +
+    return al((size_t)wp.bm_bytes) + al(wp.pairs_kb > 0 ? 0 : (size_t)wp.bm_bytes / 2) + al((size_t)wp.n_ent * 4) + al((size_t)wp.n_barcodes * 36) +
            2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
