@@ -825,7 +825,8 @@ int build_pair_tables(bdx_ctx *ctx) {
         cwt += (p.n_barcodes + 31) / 32;
     }
     if (Btot > 128 || (split && cwt > 4)) return BDX_OK;
-    const int nw = (Btot + 31) / 32;
+    int nw = (Btot + 31) / 32;
+    if (const char *e = getenv("BDX_PAIRS_NW")) nw = atoi(e) > nw ? atoi(e) : nw;  // (tuning experiment)
     const int estride = nw <= 2 ? 8 : 16;
     std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);
     int kmax = 0, track = 1 << 20, mmin = 1 << 20, g = 0;
