@@ -469,10 +469,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const bool on = i < items;
                 const int t = on ? (int)(((uint32_t)i * (uint32_t)a.cpr_inv) >> 16) : 0;
                 const int c = on ? i - t * a.cpr : 0;
-                const uint32_t onmask = on ? 0xFFFFFFFFu : 0u;  // (lanes past the tile's last chunk walk chunk 0 of read 0 and flag nothing: the queue appends below are wave-wide)
-                // one queue entry per flagged (barcode, diagonal): barcode | read << 7 | (diagonal + 64) << 16
-                const uint32_t common = ((uint32_t)t << 7) | ((uint32_t)(16 * c - 8 + 64) << 16);
-                {
+                uint32_t Fl[NW], dmw[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
+                if (on) {
                     // chunk c holds the diagonals d = 16 c - 8 + j, j = 0 .. 15; position of piece t on diagonal d: d + 4 t
                     const int g = t * s16 + c;
                     const uint32_t wm1 = img2[g - 1], w0 = img2[g], w1 = img2[g + 1];
@@ -498,15 +498,19 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                                 const u32x2 x = *(const LDS u32x2 *)(bm + ea);
                                 H[tt][0] = x[0];
                                 H[tt][1] = x[1];
-                            } else {
-                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);  // (NW = 3: a 12-byte read is slower than reading the padding along: measured)
+                            } else if constexpr (NW == 3) {
+                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);  // (a 12-byte read is slower than reading the padding along: 2.94 -> 2.74 ms for C2d)
                                 H[tt][0] = x[0];
                                 H[tt][1] = x[1];
                                 H[tt][2] = x[2];
-                                if constexpr (NW == 4) H[tt][3] = x[3];
+                            } else {
+                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);
+                                H[tt][0] = x[0];
+                                H[tt][1] = x[1];
+                                H[tt][2] = x[2];
+                                H[tt][3] = x[3];
                             }
                         }
-                        uint32_t F[NW];
 #pragma unroll
                         for (int w = 0; w < NW; ++w) {
                             uint32_t once = H[0][w] | H[1][w];
@@ -516,46 +520,34 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                                 if (j >= 0) twice |= once & H[tt][w];
                                 once |= H[tt][w];
                             }
-                            F[w] = 0u;
                             if (j >= 0) {
                                 uint32_t near = Ah[0][w];
 #pragma unroll
                                 for (int u = 1; u < KB; ++u) near |= Ah[u][w];
-                                F[w] = (twice | (once & near)) & onmask;
+                                const uint32_t F = twice | (once & near);
+                                Fl[w] |= F;
+                                dmw[w] = (dmw[w] << 1) | (F != 0u ? 1u : 0u);  // bit 15 - j
                             }
                             Ah[(j + KB) % KB][w] = once;  // (replaces the oldest)
                         }
-                        if (j >= 0) {
-                            // append this diagonal's flags: one trip per "layer" (the lowest remaining flag of every lane that has one)
-                            uint32_t anyf = F[0];
+                    }
+                }
+                // one queue entry per flagged barcode: barcode | read << 7 | (last - first flagged diagonal) << 12 | (first + 64) << 16
 #pragma unroll
-                            for (int w = 1; w < NW; ++w) anyf |= F[w];
-                            unsigned long long mk = __builtin_amdgcn_ballot_w64(anyf != 0u);
-                            while (mk) {
-                                const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                if (anyf) {
-                                    uint32_t x = F[0];
-                                    int wsel = 0;
-#pragma unroll
-                                    for (int w = 1; w < NW; ++w)
-                                        if (x == 0u) {
-                                            x = F[w];
-                                            wsel = w;
-                                        }
-                                    const int bi = __builtin_ctz(x);
-                                    const uint32_t clr = ~(1u << bi);
-#pragma unroll
-                                    for (int w = 0; w < NW; ++w)
-                                        if (wsel == w) F[w] &= clr;
-                                    if (k < HQ) hq[k] = (common + ((uint32_t)j << 16)) | (uint32_t)(32 * wsel + bi);
-                                    anyf = F[0];
-#pragma unroll
-                                    for (int w = 1; w < NW; ++w) anyf |= F[w];
-                                }
-                                nhq += (int)__builtin_popcountll(mk);
-                                mk = __builtin_amdgcn_ballot_w64(anyf != 0u);
-                            }
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t bits = Fl[w];
+                    const int jlo = 15 - (31 - (int)__builtin_clz(dmw[w] | 1u)), jhi = 15 - (int)__builtin_ctz(dmw[w] | 0x10000u);
+                    const uint32_t common = ((uint32_t)t << 7) | ((uint32_t)(jhi - jlo) << 12) | ((uint32_t)(16 * c - 8 + jlo + 64) << 16);
+                    unsigned long long mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                    while (mk) {
+                        const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        if (bits) {
+                            const int bi = __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            if (k < HQ) hq[k] = common | (uint32_t)(32 * w + bi);
                         }
+                        nhq += (int)__builtin_popcountll(mk);
+                        mk = __builtin_amdgcn_ballot_w64(bits != 0u);
                     }
                 }
             }
@@ -787,17 +779,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
         };
         if constexpr (PAIRS) {
-            // pairs mode: every queue entry is a sweep over the columns [d - kb, d + m + kb) of its diagonal
+            // pairs mode: every queue entry is a sweep over the columns [first - kb, last + m + kb) of its diagonals
             for (int s0 = 0; s0 < nh; s0 += 64) {
                 const int k = s0 + lane;
                 bool valid = k < nh;
                 const uint32_t h = valid ? hq[k] : 0u;
-                const int b = (int)(h & 127u), t = (int)((h >> 7) & 31u), dlo = (int)(h >> 16) - 64;
+                const int b = (int)(h & 127u), t = (int)((h >> 7) & 31u), wd = (int)((h >> 12) & 15u), dlo = (int)(h >> 16) - 64;
                 const uint32_t mt = meta[b];
                 const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
                 valid = valid && kk != 255;
                 const int n = rl[t];
-                int lo = dlo - kk, hi = dlo + mm + kk;
+                int lo = dlo - kk, hi = dlo + wd + mm + kk;
                 lo = lo < 0 ? 0 : lo;
                 hi = hi > n ? n : hi;
                 sweep_lane(valid, t, b, lo, hi);
