@@ -190,8 +190,9 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         cand_words += (size_t)(p.n_barcodes + 31) / 32;
         for (int b = 0; b < p.n_barcodes; ++b) {
             const uint32_t m = p.bc_off[b + 1] - p.bc_off[b];
-            if (m > 64) return BDX_OK;  // one sweep word per barcode: 32 bits, or 64 for barcodes of 33..64 nt
-            if (m > 32) wb = 8;
+            if (m > 128) return BDX_OK;  // one sweep word per barcode: 32 bits, 64 for barcodes of 33..64 nt, 128 for 65..128 nt
+            if (m > 64) wb = 16;
+            else if (m > 32 && wb < 8) wb = 8;
             for (uint32_t i = 0; i < m; ++i) {
                 const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
                 if (code_of[ch] < 0) {
@@ -214,7 +215,7 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         bp.bpad[k] = 32;  // power of two >= B: peq row address = code << log2(4*bpad)
         while (bp.bpad[k] < B) bp.bpad[k] <<= 1;
         if ((size_t)bp.ncodes * bp.bpad[k] * wb > 96 * 1024) return BDX_OK;  // the table lives in LDS
-        bytes = (bytes + 7) & ~(size_t)7;
+        bytes = (bytes + 15) & ~(size_t)15;
         o_peq[k] = bytes;
         bytes += (size_t)bp.ncodes * bp.bpad[k] * wb;
         o_pv[k] = bytes;
@@ -231,25 +232,28 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         int32_t *kb = (int32_t *)(blob.data() + o_kb[k]);
         const int bits = (int)wb * 8;
         bp.kb_uniform[k] = -2;  // (unset)
-        const auto put = [&](uint8_t *dst, size_t idx, uint64_t v) {
-            if (wb == 8)
-                ((uint64_t *)dst)[idx] = v;
+        typedef unsigned __int128 u128;
+        const auto put = [&](uint8_t *dst, size_t idx, u128 v) {
+            if (wb == 16)
+                memcpy(dst + idx * 16, &v, 16);
+            else if (wb == 8)
+                ((uint64_t *)dst)[idx] = (uint64_t)v;
             else
                 ((uint32_t *)dst)[idx] = (uint32_t)v;
         };
         for (int b = 0; b < p.n_barcodes; ++b) {
             const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
             const int shift = bits - m;
-            const uint64_t all = bits == 64 ? ~0ULL : 0xFFFFFFFFULL;
-            const uint64_t rows = m == bits ? all : (((1ULL << m) - 1ULL) << shift);
-            const uint64_t pad = ~rows & all;  // virtual rows below the barcode: match everything, D stays 0
+            const u128 all = bits == 128 ? ~(u128)0 : (((u128)1 << bits) - 1);
+            const u128 rows = m == bits ? all : ((((u128)1 << m) - 1) << shift);
+            const u128 pad = ~rows & all;  // virtual rows below the barcode: match everything, D stays 0
             put(pv, (size_t)b, rows);
             for (int code = 0; code < bp.ncodes; ++code) {
-                uint64_t mask = pad;
+                u128 mask = pad;
                 for (int i = 0; i < m; ++i) {
                     const uint8_t ch = p.bc_bytes[p.bc_off[b] + i];
                     const bool wild = n_wild && ch == 'N';
-                    if (wild || (code < K && code_of[ch] == code)) mask |= 1ULL << (shift + i);
+                    if (wild || (code < K && code_of[ch] == code)) mask |= (u128)1 << (shift + i);
                 }
                 put(peq, (size_t)code * bp.bpad[k] + b, mask);
             }
@@ -470,7 +474,7 @@ int build_diag_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
     BdxSeedPlan &sp = ctx->F().splan;
     if (sp.enabled || !ctx->F().bplan.enabled || c.filter == BDX_FILTER_BITPAR || ctx->tune.no_seed || ctx->tune.no_diag ||
-        ctx->F().bplan.word_bytes == 8)  // (the diagonal variant has 32-bit sweep words)
+        ctx->F().bplan.word_bytes != 4)  // (the diagonal variant has 32-bit sweep words)
         return BDX_OK;
     const int npass = c.is_dual ? 2 : 1;
     int cmin = 1;
@@ -1023,6 +1027,7 @@ bool size_bitpar(bdx_ctx *ctx, int read_len, long long n_reads, bool force_slot 
         if (diag ? R > 32 : R < 16) continue;  // the diagonal variant indexes 8 reads at a time (40 KiB): small tiles
         if (forced && R != forced) continue;
         if (!forced && R > r_cap) continue;
+        if (bp.word_bytes == 16 && (R > 64 || R < 16)) continue;  // (128-bit sweep words: instantiated for tiles of 64 / 32 / 16 reads)
         if (!forced && !ctx->F().splan.enabled && R > 64 && read_len <= 1024) continue;  // sweep-all: 64-read tiles measured best
         size_t st = slot_mode ? (size_t)R * (size_t)slot : (size_t)R * (size_t)read_len + 64;
         st = (st + 15) & ~(size_t)15;

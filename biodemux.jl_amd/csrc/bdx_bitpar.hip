@@ -104,15 +104,23 @@ struct BitparArgs {
 // The kernel holds no DP state (the exact stage lives in bdx_generic_kernel), which keeps it at ~100
 // VGPRs and ~37 KiB of LDS for a 64-read tile: 4 workgroups = 16 waves per CU.  The phases of a tile
 // are short and barrier-separated, so throughput follows the number of resident waves closely.
-// W64: 64-bit sweep words (barcodes of 33..64 nt; every 64-bit operation is two VALU instructions) — the plain
-// sweep and the single-seed variant; the diagonal variant stays 32-bit.
-template <int BS, int R, bool SEED, bool DIAG, int NW = 5, bool W64 = false>
+// WL: log2 of the sweep word in 32-bit units — 1: 64-bit words (barcodes of 33..64 nt; every operation is two VALU
+// instructions), 2: 128-bit words (65..128 nt; four) — the plain sweep and the single-seed variant; the diagonal variant
+// stays 32-bit.
+template <int BS, int R, bool SEED, bool DIAG, int NW = 5, int WL = 0>
 __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     static_assert(!DIAG || SEED, "the diagonal variant is a seeded variant");
-    static_assert(!DIAG || !W64, "the diagonal variant has 32-bit sweep words");
-    using WT = typename std::conditional<W64, unsigned long long, uint32_t>::type;
-    constexpr int WB = W64 ? 8 : 4;  // bytes per sweep word
-    const auto popw = [](const WT x) __attribute__((always_inline)) { return W64 ? (int)__builtin_popcountll((unsigned long long)x) : (int)__builtin_popcount((uint32_t)x); };
+    static_assert(!DIAG || WL == 0, "the diagonal variant has 32-bit sweep words");
+    using WT = typename std::conditional<WL == 2, unsigned __int128, typename std::conditional<WL == 1, unsigned long long, uint32_t>::type>::type;
+    constexpr int WB = 4 << WL;  // bytes per sweep word
+    const auto popw = [](const WT x) __attribute__((always_inline)) {
+        if constexpr (WL == 2)
+            return (int)__builtin_popcountll((unsigned long long)x) + (int)__builtin_popcountll((unsigned long long)(x >> 64));
+        else if constexpr (WL == 1)
+            return (int)__builtin_popcountll((unsigned long long)x);
+        else
+            return (int)__builtin_popcount((uint32_t)x);
+    };
     constexpr bool HASH = SEED && !DIAG;  // single-piece seeds: bitmap + hash table + record tables
     // NW (DIAG): position words per 4-mer key: 5 for reads of <= 152 staged bases, 10 for <= 312
     constexpr int SBMAX = NW <= 5 ? BDX_DIAG_SB_NARROW : 4;  // index sub-batch: SBMAX x 5 KiB (NW = 5) or x 10 KiB
@@ -464,7 +472,12 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
         // << 1 as an add whose carry-out is the bit of the barcode's last row (the patterns are top-aligned):
         // v_add_co + v_addc instead of two shifts and a three-operand add (shifts and v_add3 issue at 2/3 rate)
         WT cp, cm;
-        if constexpr (W64) {
+        if constexpr (WL == 2) {
+            cp = Ph >> 127;
+            cm = Mh >> 127;
+            Ph = Ph + Ph;
+            Mh = Mh + Mh;
+        } else if constexpr (WL == 1) {
             Ph = __builtin_addcll(Ph, Ph, 0ull, &cp);
             Mh = __builtin_addcll(Mh, Mh, 0ull, &cm);
         } else {
@@ -1190,7 +1203,7 @@ __global__ __launch_bounds__(BS, 4) void bdx_bitpar_kernel(const BitparArgs a) {
     }
 }
 
-template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5, bool W64 = false>
+template <int BS, int R, bool SEED, bool DIAG = false, int NW = 5, int WL = 0>
 hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStream_t stream, long long grid_override, int n_cu) {
     // the attribute is per device: one flag per device of this process.  Contexts of several OS threads may
     // launch concurrently: setting the attribute twice is harmless, the flag itself must not be a data race.
@@ -1198,7 +1211,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, W64>,
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, WL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
@@ -1213,7 +1226,7 @@ hipError_t launch_one(const BitparArgs &a, size_t lds, long long n_reads, hipStr
     if (grid_override > 0) blocks = grid_override;
     if (blocks > tiles) blocks = tiles;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, W64>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
+    hipLaunchKernelGGL((bdx_bitpar_kernel<BS, R, SEED, DIAG, NW, WL>), dim3((unsigned)blocks), dim3(BS), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1227,7 +1240,7 @@ size_t bdx_bitpar_lds_bytes(const BdxDevCfg &cfg, const BdxBitparPlan &bp, const
     const int cw0 = cfg.pass[0].cand_words, cw1 = cfg.is_dual ? cfg.pass[1].cand_words : 0;
     size_t o = 0;
     o += al((size_t)gp.hist_entries * 4) + al(256);
-    const size_t wb = bp.word_bytes == 8 ? 8 : 4;
+    const size_t wb = bp.word_bytes >= 8 ? (size_t)bp.word_bytes : 4;
     o += al((size_t)bp.ncodes * bp.bpad[0] * wb) + al(cfg.is_dual ? (size_t)bp.ncodes * bp.bpad[1] * wb : 0);
     o += al((size_t)B0 * wb) + al((size_t)B1 * wb) + al((size_t)B0 * 4) + al((size_t)B1 * 4);
     o += al((size_t)R * (cw0 + cw1) * 4) + al((size_t)(R + 1) * 4) + 4 * al((size_t)R * 4) + al((size_t)R * 16);
@@ -1293,7 +1306,7 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
         a.kb[k] = bp.d_kb[k];
         a.bpad[k] = bp.bpad[k];
         a.bshift[k] = 2;  // log2 of a peq row in bytes: bpad (a power of two) sweep words
-        while ((1 << a.bshift[k]) < bp.bpad[k] * (bp.word_bytes == 8 ? 8 : 4)) a.bshift[k]++;
+        while ((1 << a.bshift[k]) < bp.bpad[k] * (bp.word_bytes >= 8 ? bp.word_bytes : 4)) a.bshift[k]++;
     }
     a.ncodes = bp.ncodes;
     a.dbg = bp.dbg;
@@ -1356,10 +1369,26 @@ hipError_t bdx_launch_bitpar(const BdxDevCfg &cfg, const BdxGenericPlan &gp, con
 #undef BDX_LAUNCH_D
     }
 #define BDX_LAUNCH_R(RR)                                                                                                  \
-    return bp.word_bytes == 8 ? (seed ? launch_one<256, RR, true, false, 5, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)    \
-                                      : launch_one<256, RR, false, false, 5, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)) \
+    return bp.word_bytes == 8 ? (seed ? launch_one<256, RR, true, false, 5, 1>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)    \
+                                      : launch_one<256, RR, false, false, 5, 1>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)) \
                               : (seed ? launch_one<256, RR, true>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)                    \
                                       : launch_one<256, RR, false>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu))
+#define BDX_LAUNCH_Q(RR)                                                                                                  \
+    return seed ? launch_one<256, RR, true, false, 5, 2>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)                \
+                : launch_one<256, RR, false, false, 5, 2>(a, lds, n_reads, stream, bp.grid_override, bp.n_cu)
+    if (bp.word_bytes == 16) {  // barcodes of 65..128 nt: tiles of 64 / 32 / 16 reads (size_bitpar)
+        switch (bp.reads_per_block) {
+            case 64:
+                BDX_LAUNCH_Q(64);
+            case 32:
+                BDX_LAUNCH_Q(32);
+            case 16:
+                BDX_LAUNCH_Q(16);
+            default:
+                return hipErrorInvalidValue;
+        }
+    }
+#undef BDX_LAUNCH_Q
     switch (bp.reads_per_block) {
         case 256:
             BDX_LAUNCH_R(256);

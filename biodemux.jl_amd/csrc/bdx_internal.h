@@ -137,7 +137,7 @@ struct BdxBitparPlan {
     int bpad[2];           // barcode stride of peq[code][barcode], multiple of 32
     int *d_tile_counter;           // device int, zeroed before each launch
     const uint8_t *d_lut;          // device, 256 bytes
-    int word_bytes;                // 4: 32-bit sweep words (barcodes <= 32 nt); 8: 64-bit (33..64 nt)
+    int word_bytes;                // 4: 32-bit sweep words (barcodes <= 32 nt); 8: 64-bit (33..64 nt); 16: 128-bit (65..128 nt)
     const void *d_peq[2];          // device, [ncodes][bpad] sweep words
     const void *d_pvinit[2];       // device, [B]: top-aligned mask of the barcode's rows
     const int32_t *d_kb[2];        // device, [B]: max unit edit operations of a recordable alignment

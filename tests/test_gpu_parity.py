@@ -844,14 +844,50 @@ def test_long_barcodes_use_the_filtered_path(lens, kw):
     assert (exp["bc1"] > 0).mean() > 0.25
 
 
-def test_barcodes_beyond_64_nt_still_classify_exactly():
-    """65 nt and more: outside the sweep's domain, the unfiltered exact kernel answers (slow, but exact)."""
-    bcs = synth.make_barcodes(6, 24, seed=124, lengths=[70, 66, 80, 65, 72, 90], min_hamming=10)
-    seq, off, _ = synth.make_ragged_reads(bcs, 1500, 100, 260, seed=125, sub=0.04)
+# ---- barcodes of 65..128 nt: 128-bit sweep words ----
+@pytest.mark.parametrize("lens,kw", [
+    ([80], dict(max_error_rate=0.1)),
+    ([128], dict(max_error_rate=0.15, min_delta=0.05)),
+    ([65, 66, 80, 100, 127, 128], dict(max_error_rate=0.12, trim_side=3)),
+    ([24, 40, 64, 65, 96], dict(max_error_rate=0.15, trim_side=5, min_delta=0.03)),      # mixed with short barcodes
+    ([72], dict(max_error_rate=0.1, matching_algorithm="hamming")),
+    ([70, 110], dict(max_error_rate=0.2, mismatch=1, indel=2, summary=True)),
+], ids=lambda v: ",".join(map(str, v)) if isinstance(v, list) else ",".join(f"{k}={x}" for k, x in v.items()))
+def test_barcodes_of_65_to_128_nt_use_the_filtered_path(lens, kw):
+    rng = np.random.Generator(np.random.PCG64(126))
+    ls = rng.choice(lens, size=40)
+    bcs = synth.make_barcodes(40, 24, seed=127, lengths=ls, min_hamming=10)
+    seq, off, _ = synth.make_ragged_reads(bcs, 8000, 100, 400, seed=128, sub=0.03, ins=0.008, dele=0.008, repeat=dict(frac=0.1))
+    cfg = _c2_config(bcs, **kw)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for flt in ("off", "bitpar", "auto"):
+        with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"long barcodes {lens} {kw} filter {flt} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts)
+            if flt != "off":
+                assert "bitpar" in hc.kernel_path, hc.kernel_path
+    assert (exp["bc1"] > 0).mean() > 0.25
+
+
+def test_barcodes_of_65_to_128_nt_dual(monkeypatch):
+    b1 = synth.make_barcodes(20, 24, seed=129, lengths=[90] * 20, min_hamming=12)
+    b2 = synth.make_barcodes(12, 24, seed=130, lengths=[30] * 12)
+    seq, off, _ = synth.make_reads(b1, 6000, 300, seed=131, plant_lo=0, plant_hi=100, second=(b2, 220, 270), sub=0.03, ins=0.005, dele=0.005)
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[90] * 20, ids=[f"x{i}" for i in range(20)], is_dual=True, bc_seqs2=b2,
+                            bc_lengths_no_N2=[30] * 12, ids2=[f"y{i}" for i in range(12)], max_error_rate=0.15, trim_side=5, trim_side2=3)
+    _all_filters_agree(cfg, seq, off)
+
+
+def test_barcodes_beyond_128_nt_still_classify_exactly():
+    """129 nt and more: outside the sweep's domain, the unfiltered exact kernel answers (slow, but exact)."""
+    bcs = synth.make_barcodes(6, 24, seed=124, lengths=[140, 130, 160, 129, 150, 200], min_hamming=10)
+    seq, off, _ = synth.make_ragged_reads(bcs, 1200, 200, 460, seed=125, sub=0.04)
     cfg = _c2_config(bcs, max_error_rate=0.15, trim_side=3)
     exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq, off)
     with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
-        fuzz.assert_same(hc.classify(seq, off), exp, "barcodes > 64 nt")
+        fuzz.assert_same(hc.classify(seq, off), exp, "barcodes > 128 nt")
         assert hc.kernel_path == "generic"
 
 
