@@ -676,7 +676,16 @@ int build_wave_tables(bdx_ctx *ctx) {
     }
     if (pieces.empty() || pieces.size() > 8192) return BDX_OK;
     // the per-read record table holds eight (barcode, diagonal cluster) records: the planted one(s) plus the chance pairs must nearly always fit
-    if (150.0 * (double)pieces.size() / std::pow(4.0, (double)q) > 1.2) return BDX_OK;
+    {
+        // chance seed hits per 150-base read: the hit queue and the sweep list of a tile are sized from it (size_wave)
+        // (measured, 24-nt barcodes, 2 M reads: B = 192 / 384 / 768 at rate 0.1 — chance 1.3 / 2.6 / 5.3 — 1.99 -> 4.85, 1.49 -> 3.52,
+        // 0.94 -> 1.62 G reads/s against the general kernel; as tier 1 of rate 0.2: 0.92 -> 1.22, 0.50 -> 0.64, 0.25 -> 0.17: whatever
+        // overflows there costs a full-budget evaluation)
+        double limit = ctx->cur == 1 ? 3.0 : 6.0;
+        if (const char *e = getenv("BDX_WAVE_CHANCE")) limit = atof(e);  // (tuning experiment)
+        wp.chance = 150.0 * (double)pieces.size() / std::pow(4.0, (double)q);
+        if (wp.chance > limit) return BDX_OK;
+    }
     wp.q = q;
     wp.n_barcodes = Btot;
     wp.b0 = c.pass[0].n_barcodes;
@@ -770,7 +779,10 @@ bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
         if (!ctx->tune.wave_rw && rw > 8 && n_reads / rw < (long long)ctx->n_cu * 16) continue;
         const long long span = (((long long)rw * read_len + 64 + 15) & ~15LL);
         if (span > 10 * 1024) continue;  // a tile's bytes wait in registers: at most ten 16-byte vectors per lane
-        const size_t area = bdx_wave_area_bytes(rw, (int)span);
+        // queues: the planted barcode's pieces (up to kb + 1 = 3 hits, one or two records) + the chance hits, with slack
+        const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * wp.chance));
+        const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * wp.chance));
+        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap);
         const int shapes[3] = {8, 16, 4};
         for (int w : shapes) {
             if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
@@ -785,6 +797,8 @@ bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
                 wp.waves = w;
                 wp.blocks = per_cu * ctx->n_cu;
                 wp.span_cap = (int)span;
+                wp.hq_cap = hq_cap;
+                wp.sq_cap = sq_cap;
             }
         }
         if (best_waves >= 12) break;  // a larger tile at (nearly) full residency beats a smaller one
@@ -924,7 +938,9 @@ bool size_pairs(bdx_ctx *ctx, int read_len) {
     if (cpr > slot / 16) cpr = slot / 16;
     if (cpr < 1) cpr = 1;
     const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
-    const size_t area = bdx_wave_area_bytes(rw, span, true);
+    wp.hq_cap = 56 * rw;  // (31 chance flags per read at 96 barcodes and kb = 4; a tile that runs over is handed on / swept whole)
+    wp.sq_cap = 0;
+    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0);
     int best = 0;
     const int shapes[3] = {16, 8, 4};
     for (int w : shapes) {

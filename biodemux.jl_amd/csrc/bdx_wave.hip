@@ -73,6 +73,7 @@ struct WaveArgs {
     int slot;                // bytes per slot
     int cpr;                 // 16-diagonal chunks scanned per read
     int cpr_inv;             // ceil(2^16 / cpr)
+    int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
     const int *lens;         // [count] read lengths
     const uint32_t *idmap;   // [count] batch read numbers (= the list the reads were gathered from)
     const unsigned int *n_dev;  // the number of gathered reads lives on the device
@@ -219,8 +220,9 @@ template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
-    constexpr int HQ = PAIRS ? 56 * RW : 6 * RW;  // seed hits per tile (pairs mode: flagged (barcode, diagonal run)s = sweeps)
-    constexpr int SQ = PAIRS ? 0 : 3 * RW;        // sweeps (= records) per tile
+    // seed hits per tile (pairs mode: flagged (barcode, run of diagonals)s = sweeps) / sweeps (= records) per tile: sized per
+    // config from the expected chance hits (size_wave) — the two queues sit behind the images, at run-time offsets
+    const int HQ = a.hq_cap, SQ = PAIRS ? 0 : a.sq_cap;
     constexpr int NREC = PAIRS ? 0 : RW * RCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LDS unsigned char *smem = (LDS unsigned char *)smem_raw;
@@ -250,27 +252,23 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     // base (one base register + immediate offsets in the DS instructions), the two images after them
     LDS unsigned char *wbase = smem + o + (size_t)wv * (size_t)a.per_wave;
     constexpr int O_FB = 0;                                  // int[RW + 1]: flat index of every read's first base
-    constexpr int O_HQ = O_FB + ((RW + 1) * 4 + 15) / 16 * 16;  // u32[HQ]: seed hits: flat position << 16 | key
-    constexpr int O_RID = O_HQ + HQ * 4;                     // u32[RW * RCAP]: sweep records: barcode + 1 | (first diagonal + 64) << 16
+    constexpr int O_RID = O_FB + ((RW + 1) * 4 + 15) / 16 * 16;  // u32[RW * RCAP]: sweep records: barcode + 1 | (first diagonal + 64) << 16
     constexpr int O_RMK = O_RID + NREC * 4;                  // u32[RW * RCAP]: diagonals seen, as bits: diagonal - first + kb
     constexpr int O_SLOTS = O_RMK + NREC * 4;                // u32[RW * 4]: survivors: barcode << 8 | d
     constexpr int O_SCNT = O_SLOTS + RW * 16;                // int[RW]
     constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
     constexpr int O_WCL1 = O_FLAG + RW * 4;                  // int[RW]: split mode: window entries written for pass 1 (pass 0: scnt)
-    constexpr int O_RECQ = O_WCL1 + RW * 4;                  // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
-    constexpr int O_LBUF = O_RECQ + SQ * 4;                  // u32[64]: reads for the list, flushed in batches
+    constexpr int O_LBUF = O_WCL1 + RW * 4;                  // u32[64]: reads for the list, flushed in batches
     constexpr int O_RL = O_LBUF + 64 * 4;                    // int[RW]: pairs mode: read lengths (the slots are longer)
     constexpr int O_GID = O_RL + (PAIRS ? RW * 4 : 0);       // u32[RW]: pairs mode: batch read numbers of the gathered reads
     constexpr int O_IMG2 = O_GID + (PAIRS ? RW * 4 + 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (pairs mode: four guard words in front)
     const int nvec_cap = a.span_cap >> 4;
     LDS int *fb = (LDS int *)(wbase + O_FB);
-    LDS uint32_t *hq = (LDS uint32_t *)(wbase + O_HQ);
     LDS uint32_t *rid = (LDS uint32_t *)(wbase + O_RID);
     LDS uint32_t *rmk = (LDS uint32_t *)(wbase + O_RMK);
     LDS uint32_t *slots = (LDS uint32_t *)(wbase + O_SLOTS);
     LDS int *scnt = (LDS int *)(wbase + O_SCNT);
     LDS int *flag = (LDS int *)(wbase + O_FLAG);
-    LDS uint32_t *recq = (LDS uint32_t *)(wbase + O_RECQ);
     LDS int *wcl1 = (LDS int *)(wbase + O_WCL1);
     LDS uint32_t *cand = slots;  // split mode: candidate masks [RW][4 words: pass 0 then pass 1] (no replay, no slots)
     LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
@@ -278,6 +276,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint32_t *gid = (LDS uint32_t *)(wbase + O_GID);
     LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
+    LDS uint32_t *hq = img4 + ((2 * nvec_cap + 6 + 3) & ~3);  // u32[HQ]: seed hits: flat position << 16 | key (pairs mode: sweep entries)
+    LDS uint32_t *recq = hq + HQ;                             // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
@@ -1039,7 +1039,9 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0);
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap);
+    a.hq_cap = wp.hq_cap;
+    a.sq_cap = wp.sq_cap;
     a.list = list;
     a.list_count = list_count;
     a.dbg = dbg;
@@ -1070,13 +1072,12 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
            2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
-size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs) {
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap) {
     const size_t nvec = (size_t)span_cap >> 4;
-    const size_t hq = pairs ? (size_t)56 * rw * 4 : (size_t)6 * rw * 4;
-    const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4 + (size_t)3 * rw * 4;  // record tables + the record list
-    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + hq + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
+    const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4;  // record tables
+    const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
                          (pairs ? 2 * (size_t)rw * 4 + 16 : 0);
-    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + (2 * nvec + 6) * 4;
+    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + ((2 * nvec + 6 + 3) & ~(size_t)3) * 4 + ((size_t)hq_cap + (pairs ? 0 : (size_t)sq_cap)) * 4;
     return (o + 31) & ~(size_t)31;
 }
 

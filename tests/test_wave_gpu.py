@@ -322,3 +322,17 @@ def test_wave_split_mode_hamming_and_exact(kw, monkeypatch):
     seq, off, _ = synth.make_reads(bcs, 40000, 150, seed=51, repeat=dict(frac=0.1))
     exp = _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, expect_wave=kw.get("max_error_rate") != 0.2)
     assert (exp["bc1"] > 0).mean() > 0.2
+
+
+# ---- many barcodes: the hit queue and the sweep list of a tile are sized from the expected chance hits per read ----
+@pytest.mark.parametrize("n_bc,kw,expect", [
+    (192, dict(), True), (384, dict(), True), (700, dict(), True),          # chance hits per read 1.3 / 2.6 / 4.8
+    (384, dict(min_delta=0.05), True), (128, dict(trim_side=3), True),      # replay with with_delta / split mode (four mask words at most)
+    (300, dict(max_error_rate=0.2), True),                                  # as tier 1 (chance 2.1)
+    (700, dict(max_error_rate=0.2), False),                                 # tier 1 beyond its limit of 3: the general kernel
+    (1000, dict(), False),                                                  # beyond the plain limit of 6
+], ids=lambda v: str(v) if not isinstance(v, dict) else ",".join(f"{k}={x}" for k, x in v.items()) or "plain")
+def test_wave_many_barcodes(n_bc, kw, expect, monkeypatch):
+    bcs = synth.make_barcodes(n_bc, 24, seed=91, min_hamming=6)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=92)
+    _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, want_pass=False, expect_wave=expect)
