@@ -842,9 +842,13 @@ int build_pair_tables(bdx_ctx *ctx) {
         Btot += p.n_barcodes;
         cwt += (p.n_barcodes + 31) / 32;
     }
-    if (Btot > 128 || (split && cwt > 4)) return BDX_OK;
-    int nw = (Btot + 31) / 32;
+    // more than 128 barcodes (known-score configs only: split mode keeps four mask words per read): groups of 128 barcodes,
+    // each with its own piece tables of four-word masks
+    if (Btot > 512 || (split && (cwt > 4 || Btot > 128))) return BDX_OK;
+    const int groups = (Btot + 127) / 128;
+    int nw = groups > 1 ? 4 : (Btot + 31) / 32;
     if (const char *e = getenv("BDX_PAIRS_NW")) nw = atoi(e) > nw ? atoi(e) : nw;  // (tuning experiment)
+    if (nw > 4) nw = 4;
     const int estride = nw <= 2 ? 8 : 16;
     std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);
     int kmax = 0, track = 1 << 20, mmin = 1 << 20, g = 0;
@@ -885,12 +889,13 @@ int build_pair_tables(bdx_ctx *ctx) {
     }
     if (bcs.empty() || track < 12) return BDX_OK;
     const int KB = kmax <= 3 ? 3 : 4, P = KB + 2;
-    std::vector<uint32_t> tab((size_t)P * 256 * (size_t)(estride / 4), 0u);
+    std::vector<uint32_t> tab((size_t)groups * P * 256 * (size_t)(estride / 4), 0u);
     for (const Bc &x : bcs)
         for (int t = 0; t < x.kb + 2; ++t) {
             uint32_t key = 0;
             for (int i = 0; i < 4; ++i) key |= (uint32_t)((x.bc[4 * t + i] >> 1) & 3) << (2 * i);
-            tab[((size_t)t * 256 + key) * (size_t)(estride / 4) + (size_t)(x.g >> 5)] |= 1u << (x.g & 31);
+            const int grp = x.g >> 7, gl = x.g & 127;
+            tab[(((size_t)grp * P + (size_t)t) * 256 + key) * (size_t)(estride / 4) + (size_t)(gl >> 5)] |= 1u << (gl & 31);
         }
     wp.q = 4;
     wp.n_barcodes = Btot;
@@ -901,7 +906,8 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.track_from = track > 28 ? 28 : track;
     wp.pairs_kb = KB;
     wp.nw = nw;
-    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
+    wp.groups = groups;
+    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 112 * 1024) return BDX_OK;  // (at least four waves' work areas must fit beside the tables)
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_tab = 0, o_peq = al(tab.size() * 4), o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4),
                  bytes = o_settle + al(settle.size() * 4);
@@ -938,7 +944,9 @@ bool size_pairs(bdx_ctx *ctx, int read_len) {
     if (cpr > slot / 16) cpr = slot / 16;
     if (cpr < 1) cpr = 1;
     const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
-    wp.hq_cap = 56 * rw;  // (31 chance flags per read at 96 barcodes and kb = 4; a tile that runs over is handed on / swept whole)
+    // (31 chance flags per read at 96 barcodes and kb = 4: the queue holds a 16-read tile's worth; with more barcodes it is
+    // drained several times per tile; a tile whose queue runs over between two drains is handed on / swept whole)
+    wp.hq_cap = wp.groups > 1 ? 1024 : 56 * rw;
     wp.sq_cap = 0;
     const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0);
     int best = 0;

@@ -196,6 +196,7 @@ struct BdxWavePlan {
     // tables [kb + 2][256] of barcode masks, there is no hash
     int pairs_kb;          // 0: single seeds; else the largest budget (3 / 4)
     int nw;                // words of a barcode mask
+    int groups;            // groups of 128 barcodes (more than 128 barcodes: one set of piece tables per group, nw = 4)
     int slot;              // bytes per gathered read
     int cpr;               // 16-diagonal chunks scanned per read
 };

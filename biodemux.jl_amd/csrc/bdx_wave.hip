@@ -74,6 +74,7 @@ struct WaveArgs {
     int cpr;                 // 16-diagonal chunks scanned per read
     int cpr_inv;             // ceil(2^16 / cpr)
     int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
+    int ngroups;             // pairs mode: groups of 128 barcodes (one set of piece tables each)
     const int *lens;         // [count] read lengths
     const uint32_t *idmap;   // [count] batch read numbers (= the list the reads were gathered from)
     const unsigned int *n_dev;  // the number of gathered reads lives on the device
@@ -216,7 +217,8 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // KB > 0: PAIRS mode — the filter is the two-intact-pieces lemma instead of single seeds (budgets up to KB, see the
 // scan below), the input is a gathered slot buffer, every flagged (barcode, diagonal run) is one sweep (no record
 // tables); NW: words of a barcode mask (table entries of 8 bytes for NW <= 2, else 16).
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW>
+// MG: pairs mode with more than 128 barcodes (groups of 128; the queue is drained inside the scan).
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
@@ -441,10 +443,107 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             ulen = (l0 > 0 && !__builtin_amdgcn_ballot_w64(lane < nr && my != l0)) ? l0 : 0;
         }
 
+        // ---- sweeps: lane = one record = one (read, barcode, window) ----
+        // (a lambda: split mode runs it a second time for the reads whose tables overflowed, below)
+        const auto sweep_lane = [&](bool valid, const int t, const int b, const int lo, const int hi) __attribute__((always_inline)) {
+            const uint32_t mt = meta[b];
+            const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
+            valid = valid && hi > lo && !BDX_DBG(2);
+            const int ncol = valid ? hi - lo : 0;
+            uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
+            uint32_t Mv = 0;
+            int score = mm, best = 0x7FFFFFFF;
+            const uint32_t pbase = peq_base + (uint32_t)b * 36u;
+            const int sb0 = fb[t] + lo;  // flat index of the window's first base
+            int e_lo = 0, e_hi = -1;     // split mode: first / last column (of the sweep) with a distance within the budget
+            for (int blk = 0;; ++blk) {
+                const int rem = ncol - 32 * blk;
+                if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
+                const int sb = sb0 + 32 * blk;
+                const int d0 = sb >> 3, shb = (sb & 7) * 4;
+                uint32_t W[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) W[u] = valid ? img4[d0 + u] : 0u;
+                uint32_t A[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
+                    // columns beyond the window become "other" symbols: they match no barcode row, and a column that
+                    // matches nothing never lowers the running minimum (D[i][j] >= D[i][j-1] for every row)
+                    const int nv = rem - 8 * u;
+                    const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
+                    A[u] |= junk;
+                }
+                uint32_t inm = 0u;
+                // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
+                const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
+                if (blk == 0)
+                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                else
+                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                if (SPLIT) {
+                    // first / last column of the window whose unit distance is within the budget (DESIGN.md §3.2); the
+                    // junk columns behind the window are not columns
+                    inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
+                    if (inm) {
+                        if (e_hi < 0) e_lo = 32 * blk + (int)__builtin_clz(inm);
+                        e_hi = 32 * blk + 31 - (int)__builtin_ctz(inm);
+                    }
+                }
+            }
+            if (valid && best <= kk) {
+                if (SPLIT) {
+                    // candidate bit + one window entry for the exact kernel, exactly as bdx_bitpar.hip's tracked sweeps
+                    // hand them over: {barcode, first column of the restricted run, last column}, 1-based columns
+                    const int pass = b >= a.B0 ? 1 : 0;
+                    const int bl = b - (pass ? a.B0 : 0);
+                    __hip_atomic_fetch_or(&cand[t * 4 + (pass ? a.cw[0] : 0) + (bl >> 5)], 1u << (bl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int kx = __hip_atomic_fetch_add(pass ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (kx < BDX_WCAP && e_hi >= 0) {
+                        const int jf_abs = lo + 1;  // 1-based column of sweep column 0
+                        // :semiglobal: first column of the restricted run (DESIGN.md §3.2); :hamming / :exact: first start position
+                        const int lb = !a.sg ? mm - 1 : (a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1);
+                        const size_t rg = PAIRS ? (size_t)gid[t] : (size_t)(r0 + t);
+                        uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + (rg * BDX_WCAP + kx) * 3;
+                        dst[0] = (uint32_t)bl;
+                        dst[1] = (uint32_t)(jf_abs + e_lo - lb);
+                        dst[2] = (uint32_t)(jf_abs + e_hi);
+                    }
+                } else {
+                    const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
+                }
+            }
+        };
+        int nhq = 0;  // seed hits of the tile so far (wave-uniform)
+        bool hq_over = false;  // pairs mode: the queue ran over at some point of the tile
+        // pairs mode: every queue entry is a sweep over the columns [first - kb, last + m + kb) of its diagonals; the queue is
+        // drained whenever it is nearly full (many barcodes: > 100 flagged pairs per read) and at the end of the scan
+        const auto drain = [&]() __attribute__((always_inline)) {
+            WAVE_SYNC();
+            hq_over = hq_over || nhq > HQ;
+            const int nh = BDX_DBG(4) ? 0 : (nhq < HQ ? nhq : HQ);
+            for (int s0 = 0; s0 < nh; s0 += 64) {
+                const int k = s0 + lane;
+                bool valid = k < nh;
+                const uint32_t h = valid ? hq[k] : 0u;
+                const int b = (int)(h & 511u), t = (int)((h >> 9) & 15u), wd = (int)((h >> 13) & 15u), dlo = (int)(h >> 17) - 64;
+                const uint32_t mt = meta[b];
+                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
+                valid = valid && kk != 255;
+                const int n = rl[t];
+                int lo = dlo - kk, hi = dlo + wd + mm + kk;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > n ? n : hi;
+                sweep_lane(valid, t, b, lo, hi);
+            }
+            nhq = 0;
+            WAVE_SYNC();
+        };
+
         // ---- seed scan: lane = 16 consecutive flat positions, one bitmap probe per position ----
         // The bitmap is read as 32-bit words (word = key >> 5 at LDS address 0 + 4 word, bit = key & 31): the shift
         // that brings the key to bit 0 also is the shift amount of the bit test (the hardware takes its low five bits).
-        int nhq = 0;  // seed hits of the tile so far (wave-uniform)
         if constexpr (PAIRS) {
             // ---- pairs scan: lane = 16 consecutive diagonals of one read ----
             // Two-intact-pieces lemma: an alignment of barcode b with at most kb <= KB unit operations leaves at least two
@@ -469,14 +568,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const bool on = i < items;
                 const int t = on ? (int)(((uint32_t)i * (uint32_t)a.cpr_inv) >> 16) : 0;
                 const int c = on ? i - t * a.cpr : 0;
+                uint32_t ad[NX];  // LDS byte offset of the key's entry within a piece table
                 uint32_t Fl[NW], dmw[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
-                if (on) {
+                const auto keys = [&]() __attribute__((always_inline)) {
                     // chunk c holds the diagonals d = 16 c - 8 + j, j = 0 .. 15; position of piece t on diagonal d: d + 4 t
                     const int g = t * s16 + c;
                     const uint32_t wm1 = img2[g - 1], w0 = img2[g], w1 = img2[g + 1];
-                    uint32_t ad[NX];  // LDS byte offset of the key's entry within a piece table
 #pragma unroll
                     for (int xi = 0; xi < NX; ++xi) {
                         const int bit = 2 * (XLO + xi + 16) - (ESTRIDE == 16 ? 4 : 3);  // the key lands at bit 4 (3): times 16 (8)
@@ -485,30 +582,27 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         const uint32_t hi = wi == 0 ? w0 : (wi == 1 ? w1 : 0u);
                         ad[xi] = __builtin_amdgcn_alignbit(hi, lo, sh) & amask;
                     }
+                };
+                const auto diagonals = [&](const uint32_t gbase) __attribute__((always_inline)) {
                     uint32_t Ah[KB][NW];  // barcodes with any piece on each of the previous KB diagonals
 #pragma unroll
                     for (int j = -KB; j < 16; ++j) {
                         uint32_t H[P][NW];
 #pragma unroll
                         for (int tt = 0; tt < P; ++tt) {
-                            const uint32_t ea = ad[j - 8 + 4 * tt - XLO] + (uint32_t)(tt * TSTRIDE);
+                            const uint32_t ea = ad[j - 8 + 4 * tt - XLO] + gbase + (uint32_t)(tt * TSTRIDE);
                             if constexpr (NW == 1) {
                                 H[tt][0] = *(const LDS uint32_t *)(bm + ea);
                             } else if constexpr (NW == 2) {
                                 const u32x2 x = *(const LDS u32x2 *)(bm + ea);
                                 H[tt][0] = x[0];
                                 H[tt][1] = x[1];
-                            } else if constexpr (NW == 3) {
-                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);  // (a 12-byte read is slower than reading the padding along: 2.94 -> 2.74 ms for C2d)
-                                H[tt][0] = x[0];
-                                H[tt][1] = x[1];
-                                H[tt][2] = x[2];
                             } else {
-                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);
+                                const u32x4 x = *(const LDS u32x4 *)(bm + ea);  // (NW = 3: a 12-byte read is slower than reading the padding along: 2.94 -> 2.74 ms for C2d)
                                 H[tt][0] = x[0];
                                 H[tt][1] = x[1];
                                 H[tt][2] = x[2];
-                                H[tt][3] = x[3];
+                                if constexpr (NW == 4) H[tt][3] = x[3];
                             }
                         }
 #pragma unroll
@@ -531,23 +625,45 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                             Ah[(j + KB) % KB][w] = once;  // (replaces the oldest)
                         }
                     }
-                }
-                // one queue entry per flagged barcode: barcode | read << 7 | (last - first flagged diagonal) << 12 | (first + 64) << 16
+                };
+                // one queue entry per flagged barcode: barcode | read << 9 | (last - first flagged diagonal) << 13 | (first + 64) << 17
+                const auto append = [&](const int grp) __attribute__((always_inline)) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    uint32_t bits = Fl[w];
-                    const int jlo = 15 - (31 - (int)__builtin_clz(dmw[w] | 1u)), jhi = 15 - (int)__builtin_ctz(dmw[w] | 0x10000u);
-                    const uint32_t common = ((uint32_t)t << 7) | ((uint32_t)(jhi - jlo) << 12) | ((uint32_t)(16 * c - 8 + jlo + 64) << 16);
-                    unsigned long long mk = __builtin_amdgcn_ballot_w64(bits != 0u);
-                    while (mk) {
-                        const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                        if (bits) {
-                            const int bi = __builtin_ctz(bits);
-                            bits &= bits - 1u;
-                            if (k < HQ) hq[k] = common | (uint32_t)(32 * w + bi);
+                    for (int w = 0; w < NW; ++w) {
+                        uint32_t bits = Fl[w];
+                        const int jlo = 15 - (31 - (int)__builtin_clz(dmw[w] | 1u)), jhi = 15 - (int)__builtin_ctz(dmw[w] | 0x10000u);
+                        const uint32_t common = ((uint32_t)t << 9) | ((uint32_t)(jhi - jlo) << 13) | ((uint32_t)(16 * c - 8 + jlo + 64) << 17) |
+                                                (uint32_t)(128 * grp + 32 * w);
+                        unsigned long long mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                        while (mk) {
+                            const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                            if (bits) {
+                                const int bi = __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                if (k < HQ) hq[k] = common | (uint32_t)bi;
+                            }
+                            nhq += (int)__builtin_popcountll(mk);
+                            mk = __builtin_amdgcn_ballot_w64(bits != 0u);
                         }
-                        nhq += (int)__builtin_popcountll(mk);
-                        mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                    }
+                };
+                if constexpr (!MG) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
+                    if (on) {
+                        keys();
+                        diagonals(0u);
+                    }
+                    append(0);
+                } else {
+                    // more than 128 barcodes: groups of 128, each with its own piece tables (the keys' addresses are shared)
+                    if (on) keys();
+                    for (int grp = 0; grp < a.ngroups; ++grp) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
+                        if (on) diagonals((uint32_t)grp * (uint32_t)(P * TSTRIDE));
+                        append(grp);
+                        if (nhq > HQ - 384) drain();  // (room for one more round of flags: ~5 per lane and group at 128 barcodes)
                     }
                 }
             }
@@ -593,9 +709,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 }
             }
         }
+        if constexpr (PAIRS) drain();
         WAVE_SYNC();
-        const bool hq_ok = nhq <= HQ;  // else: the whole tile goes to the list
-        const int nh = (hq_ok && !BDX_DBG(4)) ? nhq : 0;
+        const bool hq_ok = PAIRS ? !hq_over : nhq <= HQ;  // else: the whole tile goes to the list
+        const int nh = (hq_ok && !BDX_DBG(4) && !PAIRS) ? nhq : 0;
 
         // ---- resolve: one lane per hit -> (read, barcode, diagonal) -> the read's record table ----
         // A record is one (barcode, cluster of diagonals): hits of the barcode whose diagonal lies within kb of the
@@ -706,95 +823,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         ns = ns < SQ ? ns : SQ;
         WAVE_SYNC();
 
-        // ---- sweeps: lane = one record = one (read, barcode, window) ----
-        // (a lambda: split mode runs it a second time for the reads whose tables overflowed, below)
-        const auto sweep_lane = [&](bool valid, const int t, const int b, const int lo, const int hi) __attribute__((always_inline)) {
-            const uint32_t mt = meta[b];
-            const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
-            valid = valid && hi > lo && !BDX_DBG(2);
-            const int ncol = valid ? hi - lo : 0;
-            uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
-            uint32_t Mv = 0;
-            int score = mm, best = 0x7FFFFFFF;
-            const uint32_t pbase = peq_base + (uint32_t)b * 36u;
-            const int sb0 = fb[t] + lo;  // flat index of the window's first base
-            int e_lo = 0, e_hi = -1;     // split mode: first / last column (of the sweep) with a distance within the budget
-            for (int blk = 0;; ++blk) {
-                const int rem = ncol - 32 * blk;
-                if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
-                const int sb = sb0 + 32 * blk;
-                const int d0 = sb >> 3, shb = (sb & 7) * 4;
-                uint32_t W[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) W[u] = valid ? img4[d0 + u] : 0u;
-                uint32_t A[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
-                    // columns beyond the window become "other" symbols: they match no barcode row, and a column that
-                    // matches nothing never lowers the running minimum (D[i][j] >= D[i][j-1] for every row)
-                    const int nv = rem - 8 * u;
-                    const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
-                    A[u] |= junk;
-                }
-                uint32_t inm = 0u;
-                // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
-                const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
-                if (blk == 0)
-                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
-                else
-                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
-                if (SPLIT) {
-                    // first / last column of the window whose unit distance is within the budget (DESIGN.md §3.2); the
-                    // junk columns behind the window are not columns
-                    inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
-                    if (inm) {
-                        if (e_hi < 0) e_lo = 32 * blk + (int)__builtin_clz(inm);
-                        e_hi = 32 * blk + 31 - (int)__builtin_ctz(inm);
-                    }
-                }
-            }
-            if (valid && best <= kk) {
-                if (SPLIT) {
-                    // candidate bit + one window entry for the exact kernel, exactly as bdx_bitpar.hip's tracked sweeps
-                    // hand them over: {barcode, first column of the restricted run, last column}, 1-based columns
-                    const int pass = b >= a.B0 ? 1 : 0;
-                    const int bl = b - (pass ? a.B0 : 0);
-                    __hip_atomic_fetch_or(&cand[t * 4 + (pass ? a.cw[0] : 0) + (bl >> 5)], 1u << (bl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int kx = __hip_atomic_fetch_add(pass ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (kx < BDX_WCAP && e_hi >= 0) {
-                        const int jf_abs = lo + 1;  // 1-based column of sweep column 0
-                        // :semiglobal: first column of the restricted run (DESIGN.md §3.2); :hamming / :exact: first start position
-                        const int lb = !a.sg ? mm - 1 : (a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1);
-                        const size_t rg = PAIRS ? (size_t)gid[t] : (size_t)(r0 + t);
-                        uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + (rg * BDX_WCAP + kx) * 3;
-                        dst[0] = (uint32_t)bl;
-                        dst[1] = (uint32_t)(jf_abs + e_lo - lb);
-                        dst[2] = (uint32_t)(jf_abs + e_hi);
-                    }
-                } else {
-                    const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
-                }
-            }
-        };
-        if constexpr (PAIRS) {
-            // pairs mode: every queue entry is a sweep over the columns [first - kb, last + m + kb) of its diagonals
-            for (int s0 = 0; s0 < nh; s0 += 64) {
-                const int k = s0 + lane;
-                bool valid = k < nh;
-                const uint32_t h = valid ? hq[k] : 0u;
-                const int b = (int)(h & 127u), t = (int)((h >> 7) & 31u), wd = (int)((h >> 12) & 15u), dlo = (int)(h >> 16) - 64;
-                const uint32_t mt = meta[b];
-                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
-                valid = valid && kk != 255;
-                const int n = rl[t];
-                int lo = dlo - kk, hi = dlo + wd + mm + kk;
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > n ? n : hi;
-                sweep_lane(valid, t, b, lo, hi);
-            }
-        } else
+        if constexpr (!PAIRS)
         for (int s0 = 0; s0 < ns; s0 += 64) {
             const int k = s0 + lane;
             bool valid = k < ns;
@@ -1006,17 +1035,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1054,6 +1083,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
         a.short_lb[k] = sp ? sp->short_lb[k] : 0;
     }
     a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
+    a.ngroups = wp.groups > 0 ? wp.groups : 1;
     a.slot = 0;
     a.cpr = 1;
     a.cpr_inv = 65536;
@@ -1154,11 +1184,11 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 #define BDX_PAIRS_SP(RWV, TFV, NVV, KBV, NWV)                                                                                  \
     (wp.split ? launch_wave<RWV, TFV, NVV, 4, true, KBV, NWV>(a, lds, wp.waves, blocks, stream)                                \
               : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
-#define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
+#define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.groups > 1 ? launch_wave<RWV, TFV, NVV, 4, false, KBV, 4, true>(a, lds, wp.waves, blocks, stream) : wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
 #define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
 #define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
-    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12) return hipErrorInvalidValue;
+    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split))) return hipErrorInvalidValue;
     if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
     if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
     return hipErrorInvalidValue;

@@ -85,10 +85,43 @@ def test_pairs_mask_words(n_bc, monkeypatch):
     _with_and_without(_cfg(bcs, trim_side=5), seq, off, monkeypatch, want_pass=False, expect_pairs=None if n_bc < 32 else True)
 
 
-def test_pairs_not_for_more_than_128_barcodes(monkeypatch):
+@pytest.mark.parametrize("n_bc", [129, 200, 256, 257, 384])
+def test_pairs_groups_of_128_barcodes(n_bc, monkeypatch):
+    """More than 128 barcodes (known-score configs): one set of piece tables per group of 128, the flag queue of a tile is
+    drained inside the scan."""
+    bcs = synth.make_barcodes(n_bc, 24, seed=65, min_hamming=6)
+    seq, off, _ = synth.make_reads(bcs, 12000, 150, seed=66, sub=0.05, ins=0.01, dele=0.01)
+    _with_and_without(_cfg(bcs), seq, off, monkeypatch)
+    _with_and_without(_cfg(bcs, min_delta=0.05), seq, off, monkeypatch, want_pass=False)
+
+
+def test_pairs_groups_low_complexity(monkeypatch):
+    """Low-complexity reads flag nearly every barcode on nearly every diagonal: the queue runs over between two drains and
+    the tile is handed on."""
+    rng = np.random.Generator(np.random.PCG64(86))
+    bcs = ["A" * 24, "AC" * 12, "ACG" * 8, "ACGT" * 6, "T" * 24] + synth.make_barcodes(195, 24, seed=86, min_hamming=6)
+    motifs = ["A", "AC", "ACG", "ACGT", "T"]
+    reads = []
+    for i in range(3000):
+        if i % 2 == 0:
+            b = bcs[5 + int(rng.integers(0, 195))]
+            body = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=126))
+            reads.append(body[:50] + synth.mutate_copy(rng, b, int(rng.integers(2, 5))).decode() + body[50:])
+            continue
+        mo = motifs[int(rng.integers(0, len(motifs)))]
+        s = list((mo * 200)[int(rng.integers(0, 8)):][:150])
+        for _ in range(int(rng.integers(3, 6))):
+            s[int(rng.integers(0, 150))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s))
+    seq, off = H.bdx.pack_reads(reads)
+    _with_and_without(_cfg(bcs), seq, off, monkeypatch, want_pass=False)
+
+
+def test_pairs_not_for_more_than_128_barcodes_in_split_mode(monkeypatch):
+    """Split mode keeps four mask words per read: the general kernel stays tier 0."""
     bcs = synth.make_barcodes(130, 24, seed=65)
     seq, off, _ = synth.make_reads(bcs, 6000, 150, seed=66)
-    _with_and_without(_cfg(bcs), seq, off, monkeypatch, expect_pairs=False)
+    _with_and_without(_cfg(bcs, trim_side=5), seq, off, monkeypatch, expect_pairs=False, want_pass=False)
 
 
 def test_pairs_dual_c4_shape(monkeypatch):
