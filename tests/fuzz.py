@@ -106,6 +106,42 @@ def random_case_many_barcodes(seed: int, n_reads: int = 1500):
     return cfg, seq, off
 
 
+def random_case_wide(seed: int, n_reads: int = 1500):
+    """Round-3 domains: 100..520 barcodes of 24 nt (the wave kernel with queues sized from the chance hits, the pairs mode
+    with groups of 128 barcodes), or 16..60 barcodes of 65..128 nt (128-bit sweep words); mostly known-score configs at
+    rates 0.1..0.2, some with min_delta / trimming / summary; ragged reads, concatemers."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x31DE))
+    long_bc = rng.random() < 0.25
+    if long_bc:
+        B = int(rng.integers(16, 61))
+        lo = int(rng.integers(65, 129))
+        hi = lo if rng.random() < 0.5 else min(128, lo + int(rng.integers(1, 30)))
+        rate = float([0.05, 0.08, 0.1, 0.12][int(rng.integers(0, 4))])
+        max_len = int([200, 260, 320][int(rng.integers(0, 3))])
+        err = 0.03
+    else:
+        B = int(rng.integers(100, 521))
+        lo = int([24, 24, 24, 20, 28, 32][int(rng.integers(0, 6))])
+        hi = lo if rng.random() < 0.7 else min(32, lo + int(rng.integers(1, 5)))
+        rate = float([0.1, 0.1, 0.13, 0.17, 0.2, 0.2][int(rng.integers(0, 6))])
+        max_len = int([100, 150, 150, 152, 200][int(rng.integers(0, 5))])
+        err = float([0.02, 0.04, 0.06][int(rng.integers(0, 3))])
+    bcs = _rand_barcodes(rng, B, lo, hi, False)
+    kw = dict(
+        bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
+        max_error_rate=rate, min_delta=float([0.0, 0.0, 0.0, 0.05, 0.1][int(rng.integers(0, 5))]),
+        trim_side=[None, None, None, None, 3, 5][int(rng.integers(0, 6))],
+        summary=bool(rng.random() < 0.1),
+        matching_algorithm=["semiglobal"] * 6 + ["hamming"],
+    )
+    kw["matching_algorithm"] = kw["matching_algorithm"][int(rng.integers(0, 7))]
+    cfg = H.bdx.DemuxConfig(**kw)
+    repeat = dict(frac=0.3) if rng.random() < 0.25 else None
+    seq, off, _ = synth.make_ragged_reads(bcs, n_reads, max_len // 2 if rng.random() < 0.4 else max_len, max_len, seed=seed,
+                                          plant_frac=0.85, sub=err, ins=err / 3, dele=err / 3, n_rate=0.003, repeat=repeat)
+    return cfg, seq, off
+
+
 def random_case_tiers(seed: int, n_reads: int = 1500):
     """The tiered budgets' domain and its borders: 16..160 barcodes of 12..64 nt (capped budgets 0..7, 32- and 64-bit
     sweep words), rates whose full budget is 1..3 operations beyond the cap, min_delta around the score of an unseen

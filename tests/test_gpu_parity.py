@@ -98,6 +98,20 @@ def test_fuzz_tiers_vs_oracle(seed):
             assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_wide_vs_oracle(seed):
+    """Random configs in round 3's domains (fuzz.random_case_wide): 100..520 barcodes (wave kernel with queues sized from
+    the chance hits, pairs mode in groups of 128 barcodes) and barcodes of 65..128 nt (128-bit sweep words)."""
+    cfg, seq, off = fuzz.random_case_wide(seed, n_reads=1200)
+    for want_pass in (True, False):
+        oc = H.orc.OracleClassifier(cfg, nthreads=8, want_pass=want_pass)
+        exp = oc.classify(seq, off)
+        with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"seed {seed} pass outputs {want_pass} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+
+
 _BAND_RUNS = {"cases": 0, "band": 0}
 
 

@@ -119,6 +119,25 @@ for seed in range(lo5, hi5):
 print(f"context-reuse seeds {lo5}..{hi5 - 1}: {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
+# round-3 domains: hundreds of barcodes (wave kernel with sized queues, pairs mode in groups of 128), barcodes of 65..128 nt
+lo6, hi6 = int(os.environ.get("SEED6_LO", "80000")), int(os.environ.get("SEED6_HI", "80200"))
+paths6 = {}
+t0 = time.time()
+for seed in range(lo6, hi6):
+    cfg, seq, off = fuzz.random_case_wide(seed)
+    for want in (True, False):
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want).classify(seq, off)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                got = hc.classify(seq, off)
+                paths6[hc.kernel_path] = paths6.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"wide seed {seed} want_pass {want} [{hc.kernel_path}]")
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"wide seeds {lo6}..{hi6 - 1}: paths {paths6}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
 def stress(name, bcs, seq, off, **kw):
     global bad
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],
