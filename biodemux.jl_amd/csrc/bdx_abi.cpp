@@ -621,7 +621,7 @@ int build_wave_tables(bdx_ctx *ctx) {
         Btot += p.n_barcodes;
         cwt += (p.n_barcodes + 31) / 32;
     }
-    if (Btot > 1024 || (split && cwt > 4)) return BDX_OK;  // (split mode keeps four candidate words per read in LDS)
+    if (Btot > 1024 || (split && cwt > 16)) return BDX_OK;  // (split mode keeps the candidate words of a read in LDS: up to 512 barcodes)
     const int q = sp.q;
     struct Piece { int g, start; const uint8_t *bc; };
     std::vector<Piece> pieces;
@@ -690,6 +690,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.n_barcodes = Btot;
     wp.b0 = c.pass[0].n_barcodes;
     wp.split = split ? 1 : 0;
+    wp.cand_words = cwt;
     wp.bm_bytes = (1 << (2 * q)) / 8;
     wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
     // seed table: the bitmap is exact (one bit per key of the 4^q key space), so a hit's entry is found by the RANK of its
@@ -782,7 +783,7 @@ bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
         // queues: the planted barcode's pieces (up to kb + 1 = 3 hits, one or two records) + the chance hits, with slack
         const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * wp.chance));
         const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * wp.chance));
-        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap);
+        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.split ? wp.cand_words : 0);
         const int shapes[3] = {8, 16, 4};
         for (int w : shapes) {
             if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
@@ -907,6 +908,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.pairs_kb = KB;
     wp.nw = nw;
     wp.groups = groups;
+    wp.cand_words = cwt;
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 112 * 1024) return BDX_OK;  // (at least four waves' work areas must fit beside the tables)
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_tab = 0, o_peq = al(tab.size() * 4), o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4),
@@ -948,7 +950,7 @@ bool size_pairs(bdx_ctx *ctx, int read_len) {
     // drained several times per tile; a tile whose queue runs over between two drains is handed on / swept whole)
     wp.hq_cap = wp.groups > 1 ? 1024 : 56 * rw;
     wp.sq_cap = 0;
-    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0);
+    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.split ? wp.cand_words : 0);
     int best = 0;
     const int shapes[3] = {16, 8, 4};
     for (int w : shapes) {

@@ -191,6 +191,7 @@ struct BdxWavePlan {
     int span_cap;          // bytes of a tile's span the images hold
     int read_len_hint;     // the read length the geometry was planned for
     int hq_cap, sq_cap;    // entries of a tile's hit queue / sweep list (from the expected chance hits per read)
+    int cand_words;        // split mode: candidate mask words per read (both passes)
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
     // tables [kb + 2][256] of barcode masks, there is no hash
@@ -234,7 +235,7 @@ struct BdxWaveSplit {
 
 // Implemented in bdx_wave.hip.
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
-size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap);
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words);
 // Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
                             const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,

@@ -272,7 +272,6 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS int *scnt = (LDS int *)(wbase + O_SCNT);
     LDS int *flag = (LDS int *)(wbase + O_FLAG);
     LDS int *wcl1 = (LDS int *)(wbase + O_WCL1);
-    LDS uint32_t *cand = slots;  // split mode: candidate masks [RW][4 words: pass 0 then pass 1] (no replay, no slots)
     LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
     LDS int *rl = (LDS int *)(wbase + O_RL);
     LDS uint32_t *gid = (LDS uint32_t *)(wbase + O_GID);
@@ -280,6 +279,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
     LDS uint32_t *hq = img4 + ((2 * nvec_cap + 6 + 3) & ~3);  // u32[HQ]: seed hits: flat position << 16 | key (pairs mode: sweep entries)
     LDS uint32_t *recq = hq + HQ;                             // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
+    const int cwt = a.cw[0] + a.cw[1];                        // split mode: candidate mask words per read (pass 0 then pass 1)
+    LDS uint32_t *cand = recq + SQ;                           // u32[RW][cwt] (split mode)
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
@@ -402,8 +403,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
             if (SPLIT) {
                 wcl1[lane] = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) cand[lane * 4 + w] = 0u;
+                for (int w = 0; w < cwt; ++w) cand[lane * cwt + w] = 0u;
             }
         }
 
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     // hand them over: {barcode, first column of the restricted run, last column}, 1-based columns
                     const int pass = b >= a.B0 ? 1 : 0;
                     const int bl = b - (pass ? a.B0 : 0);
-                    __hip_atomic_fetch_or(&cand[t * 4 + (pass ? a.cw[0] : 0) + (bl >> 5)], 1u << (bl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&cand[t * cwt + (pass ? a.cw[0] : 0) + (bl >> 5)], 1u << (bl & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const int kx = __hip_atomic_fetch_add(pass ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (kx < BDX_WCAP && e_hi >= 0) {
                         const int jf_abs = lo + 1;  // 1-based column of sweep column 0
@@ -864,8 +864,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     scnt[t] = 0;
                     wcl1[t] = 0;
                     flag[t] = 0;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) cand[t * 4 + w] = 0u;
+                    for (int w = 0; w < cwt; ++w) cand[t * cwt + w] = 0u;
                 }
                 WAVE_SYNC();
                 const int n = rlen(t);
@@ -888,7 +887,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     if (pass == 1 && a.cw[1] == 0) break;
                     const int cwp = a.cw[pass];
                     uint32_t *dst = a.cand_out[pass] + rid_g * cwp;
-                    for (int w = 0; w < cwp; ++w) dst[w] = usable ? cand[lane * 4 + (pass ? a.cw[0] : 0) + w] : 0xFFFFFFFFu;
+                    for (int w = 0; w < cwp; ++w) dst[w] = usable ? cand[lane * cwt + (pass ? a.cw[0] : 0) + w] : 0xFFFFFFFFu;
                     const int c = pass ? wcl1[lane] : scnt[lane];
                     a.wcnt_out[pass][rid_g] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
                 }
@@ -1068,7 +1067,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap);
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.split ? wp.cand_words : 0);
     a.hq_cap = wp.hq_cap;
     a.sq_cap = wp.sq_cap;
     a.list = list;
@@ -1102,12 +1101,12 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
            2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
-size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap) {
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words) {
     const size_t nvec = (size_t)span_cap >> 4;
     const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4;  // record tables
     const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
                          (pairs ? 2 * (size_t)rw * 4 + 16 : 0);
-    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + ((2 * nvec + 6 + 3) & ~(size_t)3) * 4 + ((size_t)hq_cap + (pairs ? 0 : (size_t)sq_cap)) * 4;
+    const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + ((2 * nvec + 6 + 3) & ~(size_t)3) * 4 + ((size_t)hq_cap + (pairs ? 0 : (size_t)sq_cap) + (size_t)rw * (size_t)cand_words) * 4;
     return (o + 31) & ~(size_t)31;
 }
 

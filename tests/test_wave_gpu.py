@@ -327,7 +327,9 @@ def test_wave_split_mode_hamming_and_exact(kw, monkeypatch):
 # ---- many barcodes: the hit queue and the sweep list of a tile are sized from the expected chance hits per read ----
 @pytest.mark.parametrize("n_bc,kw,expect", [
     (192, dict(), True), (384, dict(), True), (700, dict(), True),          # chance hits per read 1.3 / 2.6 / 4.8
-    (384, dict(min_delta=0.05), True), (128, dict(trim_side=3), True),      # replay with with_delta / split mode (four mask words at most)
+    (384, dict(min_delta=0.05), True), (128, dict(trim_side=3), True),      # replay with with_delta / split mode
+    (384, dict(trim_side=3), True), (500, dict(trim_side=5, summary=True), True),   # split mode: 12 / 16 candidate words per read
+    (520, dict(trim_side=5), False),                                         # 17 words: the general kernel
     (300, dict(max_error_rate=0.2), True),                                  # as tier 1 (chance 2.1)
     (700, dict(max_error_rate=0.2), False),                                 # tier 1 beyond its limit of 3: the general kernel
     (1000, dict(), False),                                                  # beyond the plain limit of 6
