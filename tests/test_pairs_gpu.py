@@ -281,3 +281,44 @@ def test_pairs_full_size_c2d_equals_the_general_kernel(monkeypatch):
     soff = np.arange(len(idx) + 1, dtype=np.int64) * 150
     exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(sseq, soff)
     assert np.array_equal(res[True][0]["bc1"][idx], exp["bc1"])
+
+
+def test_pairs_bytes_outside_acgt(monkeypatch):
+    """Reads with N, lower case, IUPAC letters, control bytes and bytes that alias a letter's 3-bit index: none of them
+    equals a barcode base (classification.jl:185); the gathered slots carry the raw bytes, padding is 'N'."""
+    bcs = synth.make_barcodes(96, 24, seed=87)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=88, n_rate=0.0, sub=0.04, ins=0.01, dele=0.01)
+    rng = np.random.Generator(np.random.PCG64(89))
+    seq = seq.copy()
+    odd = np.frombuffer(b"NnacgtRYKMSWBDHVU*-.\x00\x01\x7f\xff@BDFPQRSUVEaceg\x21\x23\x27\x34", dtype=np.uint8)
+    pos = rng.choice(len(seq), size=len(seq) // 60, replace=False)
+    seq[pos] = odd[rng.integers(0, len(odd), size=len(pos))]
+    mat = seq.reshape(-1, 150)
+    mat[::97] = np.where((mat[::97] >= 65) & (mat[::97] <= 90), mat[::97] + 32, mat[::97])  # whole reads in lower case
+    for kw in (dict(), dict(trim_side=5, min_delta=0.05)):
+        exp = _with_and_without(_cfg(bcs, **kw), seq, off, monkeypatch, want_pass=kw == dict())
+    assert (exp["bc1"][::97] <= 0).all()
+    assert (exp["bc1"] > 0).mean() > 0.3
+
+
+def test_pairs_unaligned_device_buffers(monkeypatch):
+    """Device buffers that start at odd addresses: the gather funnels every dword out of the aligned dwords it straddles."""
+    import torch
+
+    bcs = synth.make_barcodes(96, 24, seed=90)
+    seq, off, _ = synth.make_ragged_reads(bcs, 9000, 60, 150, seed=91, sub=0.05, ins=0.01, dele=0.01)
+    cfg = _cfg(bcs)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(seq, off)
+    dev = torch.device("cuda:0")
+    n = len(off) - 1
+    for shift in (1, 2, 3, 5, 13):
+        raw = torch.zeros(len(seq) + 64, dtype=torch.uint8, device=dev)
+        raw[shift:shift + len(seq)] = torch.from_numpy(seq).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        out = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in ("bc1", "bc2", "keep_start", "keep_end")}
+        with H.bdx.HipClassifier(cfg) as hc:
+            hc.classify_device(raw.data_ptr() + shift, d_off.data_ptr(), n, **{k: v.data_ptr() for k, v in out.items()})
+            hc.sync()
+            assert hc.pair_launches > 0
+            for k, v in out.items():
+                assert np.array_equal(v.cpu().numpy(), exp[k]), (shift, k)
