@@ -570,23 +570,29 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const int c = on ? i - t * a.cpr : 0;
                 uint32_t ad[NX];  // LDS byte offset of the key's entry within a piece table
                 uint32_t Fl[NW], dmw[NW];
+                // chunk c holds the diagonals d = 16 c - 8 + j, j = 0 .. 15; position of piece t on diagonal d: d + 4 t.  The
+                // address of a position's key is computed when the walk over the diagonals first needs it (piece P - 1 of
+                // diagonal j) and dies after piece 0 of diagonal j + 4 (P - 1): ~21 of the 40 live at a time
+                const int gword = t * s16 + c;
+                uint32_t wm1 = 0u, w0 = 0u, w1 = 0u;
                 const auto keys = [&]() __attribute__((always_inline)) {
-                    // chunk c holds the diagonals d = 16 c - 8 + j, j = 0 .. 15; position of piece t on diagonal d: d + 4 t
-                    const int g = t * s16 + c;
-                    const uint32_t wm1 = img2[g - 1], w0 = img2[g], w1 = img2[g + 1];
-#pragma unroll
-                    for (int xi = 0; xi < NX; ++xi) {
-                        const int bit = 2 * (XLO + xi + 16) - (ESTRIDE == 16 ? 4 : 3);  // the key lands at bit 4 (3): times 16 (8)
-                        const int wi = bit >> 5, sh = bit & 31;
-                        const uint32_t lo = wi == 0 ? wm1 : (wi == 1 ? w0 : w1);
-                        const uint32_t hi = wi == 0 ? w0 : (wi == 1 ? w1 : 0u);
-                        ad[xi] = __builtin_amdgcn_alignbit(hi, lo, sh) & amask;
-                    }
+                    wm1 = img2[gword - 1];
+                    w0 = img2[gword];
+                    w1 = img2[gword + 1];
+                };
+                const auto key_addr = [&](const int xi) __attribute__((always_inline)) -> uint32_t {
+                    const int bit = 2 * (XLO + xi + 16) - (ESTRIDE == 16 ? 4 : 3);  // the key lands at bit 4 (3): times 16 (8)
+                    const int wi = bit >> 5, sh = bit & 31;
+                    const uint32_t lo = wi == 0 ? wm1 : (wi == 1 ? w0 : w1);
+                    const uint32_t hi = wi == 0 ? w0 : (wi == 1 ? w1 : 0u);
+                    return __builtin_amdgcn_alignbit(hi, lo, sh) & amask;
                 };
                 const auto diagonals = [&](const uint32_t gbase) __attribute__((always_inline)) {
                     uint32_t Ah[KB][NW];  // barcodes with any piece on each of the previous KB diagonals
 #pragma unroll
                     for (int j = -KB; j < 16; ++j) {
+#pragma unroll
+                        for (int xi = (j == -KB ? 0 : j + KB + 4 * (P - 1)); xi <= j + KB + 4 * (P - 1); ++xi) ad[xi] = key_addr(xi);
                         uint32_t H[P][NW];
 #pragma unroll
                         for (int tt = 0; tt < P; ++tt) {
