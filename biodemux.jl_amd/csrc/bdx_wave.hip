@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     if (kx < BDX_WCAP && e_hi >= 0) {
                         const int jf_abs = lo + 1;  // 1-based column of sweep column 0
                         // :semiglobal: first column of the restricted run; :hamming / :exact: first start position
-                        const int lb = !a.sg ? mm - 1 : (a.short_lb[pass] ? mm + kk : 2 * (mm + kk) + 1);
+                        const int lb = !a.sg ? mm - 1 : ((pass ? a.short_lb[1] : a.short_lb[0]) ? mm + kk : 2 * (mm + kk) + 1);  // (no run-time index into the argument arrays: that puts them in scratch)
                         const size_t rg = PAIRS ? (size_t)gid[t] : (size_t)(r0 + t);
                         uint32_t *dst = (pass ? a.wins_out[1] : a.wins_out[0]) + (rg * BDX_WCAP + kx) * 3;
                         dst[0] = (uint32_t)bl;
@@ -891,11 +891,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
                     if (pass == 1 && a.cw[1] == 0) break;
-                    const int cwp = a.cw[pass];
-                    uint32_t *dst = a.cand_out[pass] + rid_g * cwp;
+                    const int cwp = pass ? a.cw[1] : a.cw[0];
+                    uint32_t *dst = (pass ? a.cand_out[1] : a.cand_out[0]) + rid_g * cwp;
                     for (int w = 0; w < cwp; ++w) dst[w] = usable ? cand[lane * cwt + (pass ? a.cw[0] : 0) + w] : 0xFFFFFFFFu;
                     const int c = pass ? wcl1[lane] : scnt[lane];
-                    a.wcnt_out[pass][rid_g] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
+                    (pass ? a.wcnt_out[1] : a.wcnt_out[0])[rid_g] = (unsigned char)((usable && c <= BDX_WCAP) ? c : 255);
                 }
             }
             WAVE_SYNC();  // the next tile reuses the per-read tables
