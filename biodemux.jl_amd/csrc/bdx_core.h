@@ -1035,7 +1035,6 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                         }
                     }
                 }
-            no_band:
                 a = !need_tb ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                     : end_only ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, true, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                                : sg_core_clean<true, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi);

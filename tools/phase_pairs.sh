@@ -6,4 +6,4 @@ for d in 0 1 3 11 43 107; do
   BDX_DEBUG=$((d * 256)) rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d gpurun_out/phl$d -o ph --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-other-configs --reads ${READS:-4000000} $BENCH_ARGS > gpurun_out/phl$d.log 2>&1 || exit 1
   echo "done $d"
 done
-python tools/phase_table.py "${KERN:-false, 4, 3>}" 0 1 3 11 43 107
+python tools/phase_table.py "${KERN:-false, 4, 3, false>}" 0 1 3 11 43 107
