@@ -382,6 +382,8 @@ __global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list
 }  // namespace
 
 // ---- gather: the reads of a list -> slots (input of the wave kernel's pairs mode, bdx_pairs.hip) ----
+// (HBM-bound: 1.4 M scattered 150-byte reads fetch 435 MB of cache lines and write 216 MB of slots in 0.16 ms; four reads
+// per trip side by side took the same time and moved 40 % more bytes.)
 // Read list[k] of the batch is copied to slots[k * slot .. ) and padded with 'N' up to the slot size; lens[k] is its
 // length, or -1 when it is longer than the planned length (the consumer hands such a read on).  Sixteen lanes per read, one lane per dword:
 // the source is unaligned, so every dword is funnelled out of the two aligned dwords it straddles (the second one is
@@ -391,54 +393,35 @@ __global__ __launch_bounds__(256) void bdx_gather_kernel(const uint8_t *seq, con
                                                          long long n_cap, uint8_t *slots, int *lens, const int slot, const int max_len) {
     long long n = (long long)*count;
     if (n > n_cap) n = n_cap;
-    // sixteen lanes per read, four reads per group and trip (their list -> offsets -> bytes chains side by side).  The
-    // kernel is HBM-bound: 1.4 M scattered 150-byte reads fetch 435 MB of cache lines and write 216 MB of slots in 0.16 ms
-    // (4 TB/s) — one read per trip took the same time
+    // sixteen lanes per read (four reads per wave side by side: the list -> offsets -> bytes chain is latency-bound)
     const int sub = threadIdx.x & 15;
     const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
     const int dw = slot >> 2;
-    constexpr int U = 4;
-    for (long long kb = grp * U; kb < n; kb += ngrp * U) {
-        uint32_t id[U];
-        long long o0[U], len[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) id[u] = kb + u < n ? list[kb + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            o0[u] = kb + u < n ? off[id[u]] : 0;
-            len[u] = kb + u < n ? off[id[u] + 1] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            len[u] -= o0[u];
-            const bool fits = len[u] >= 0 && len[u] <= (long long)max_len;  // (the scan was planned for reads up to max_len <= slot)
-            if (sub == 0 && kb + u < n) lens[kb + u] = fits ? (int)len[u] : -1;
-            if (!fits) len[u] = 0;
-        }
+    for (long long k = grp; k < n; k += ngrp) {
+        const uint32_t id = list[k];
+        const long long o0 = off[id];
+        long long len = off[id + 1] - o0;
+        const bool fits = len >= 0 && len <= (long long)max_len;  // (the scan was planned for reads up to max_len <= slot)
+        if (!fits) len = 0;
+        if (sub == 0) lens[k] = fits ? (int)len : -1;
+        uint32_t *dst = (uint32_t *)(slots + (size_t)k * (size_t)slot);
         for (int w = sub; w < dw; w += 16) {
             const int b0 = 4 * w;
-            uint32_t v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                v[u] = 0x4E4E4E4Eu;
-                if (b0 < len[u]) {
-                    const uintptr_t A = (uintptr_t)(seq + o0[u] + b0);
-                    const uint32_t *al = (const uint32_t *)(A & ~(uintptr_t)3);
-                    const int mis = (int)(A & 3);
-                    const int valid = (int)(len[u] - b0);  // bytes of this dword that belong to the read
-                    const uint32_t lo = al[0];
-                    const uint32_t hi = (mis != 0 && 4 - mis < valid) ? al[1] : 0u;
-                    uint32_t x = mis ? __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)mis) : lo;
-                    if (valid < 4) {
-                        const uint32_t keep = (1u << (8 * valid)) - 1u;
-                        x = (x & keep) | (0x4E4E4E4Eu & ~keep);
-                    }
-                    v[u] = x;
+            uint32_t v = 0x4E4E4E4Eu;
+            if (b0 < len) {
+                const uintptr_t A = (uintptr_t)(seq + o0 + b0);
+                const uint32_t *al = (const uint32_t *)(A & ~(uintptr_t)3);
+                const int mis = (int)(A & 3);
+                const int valid = (int)(len - b0);  // bytes of this dword that belong to the read
+                const uint32_t lo = al[0];
+                const uint32_t hi = (mis != 0 && 4 - mis < valid) ? al[1] : 0u;
+                v = mis ? __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)mis) : lo;
+                if (valid < 4) {
+                    const uint32_t keep = (1u << (8 * valid)) - 1u;
+                    v = (v & keep) | (0x4E4E4E4Eu & ~keep);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (kb + u < n) ((uint32_t *)(slots + (size_t)(kb + u) * (size_t)slot))[w] = v[u];
+            dst[w] = v;
         }
     }
 }
@@ -448,7 +431,7 @@ hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const
                              long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream) {
     if (!d_seq || !d_off || !d_list || !d_count || !d_slots || !d_lens || slot < 16 || (slot & 15) || max_len > slot) return hipErrorInvalidValue;
     long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * 8;
-    const long long useful = (n_cap + 63) / 64;
+    const long long useful = (n_cap + 15) / 16;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bdx_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq, d_off, d_list, d_count, n_cap, d_slots, d_lens, slot, max_len);
