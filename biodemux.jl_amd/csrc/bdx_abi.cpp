@@ -48,6 +48,7 @@ BdxTuning read_tuning() {
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_wave = getenv("BDX_NO_WAVE") != nullptr;
     t.no_pairs = getenv("BDX_NO_PAIRS") != nullptr;
+    t.no_kend = getenv("BDX_NO_KEND") != nullptr;
     t.poison = getenv("BDX_POISON") != nullptr;
     if (const char *e = getenv("BDX_WAVE_RW")) t.wave_rw = atoi(e);
     if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
@@ -761,14 +762,31 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.d_meta = (const uint32_t *)(base + o_meta);
     wp.d_settle = (const uint32_t *)(base + o_settle);
     wp.enabled = 1;
+    // Known-end class: the known-score conditions with trim_side = 5 instead of none (single pass, no summary).  Only the
+    // alignment's END is observable then (keep_start = end + 1, classification.jl:912-914), and the reference keeps the
+    // leftmost end of the best score (:142-153: strict `<`): the sweep delivers it (bdx_wave.hip, KEND) — such a config
+    // gets its verdicts from the non-split kernel whenever the caller does not ask for start positions.
+    F.wplan_k = BdxWavePlan{};
+    if (split && !c.is_dual && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && c.pass[0].trim_side == 5 &&
+        !c.need_traceback && c.pass[0].explicit_window != BDX_WINDOW_ALIGN_ONE && !ctx->tune.no_known && !ctx->tune.no_kend) {
+        bool fits = true;  // entry = barcode << 22 | d << 16 | end
+        for (uint32_t x : meta) fits = fits && (((x >> 8) & 255u) == 255u || ((x >> 8) & 255u) < 64u);
+        if (fits && Btot <= 1023) {
+            F.wplan_k = wp;
+            F.wplan_k.split = 0;
+            F.wplan_k.cand_words = 0;
+            F.wplan_k.kend = 1;
+        }
+    }
     return BDX_OK;
 }
 
 // Geometry of the wave kernel for a batch: the tile size and workgroup shape that keep the most waves resident
 // per compute unit (tables once per workgroup + one work area per wave within 160 KiB, at most 16 waves: the
 // kernel is compiled for four waves per SIMD).  false: this batch runs the general kernel.
-bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) {
-    BdxWavePlan &wp = ctx->fs[set].wplan;
+bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads);
+bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) { return size_wave(ctx, ctx->fs[set].wplan, read_len, n_reads); }
+bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
     if (!wp.enabled || ctx->dev.vlen) return false;  // (window uploads stage per-read slots: general kernel)
     if (read_len < 1) read_len = 1;
     const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
@@ -2098,6 +2116,18 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 wave0 = size_bitpar(ctx, batch_len, n_reads, true);
             if (!tiered && !wave0) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
         }
+        // Known-end class (trim_side = 5, single pass, no start positions or statistics wanted): the same kernel in its
+        // known-end form answers the reads it can settle, trimmed keep range included; the listed rest goes through the
+        // split path (filter in list mode -> exact kernel in list mode).
+        bool wave1k = false, wave0k = false;
+        if (split && windows && !ctx->dev.vlen && !dense_w && npass == 1 && o.pass_start == nullptr && stp == nullptr) {
+            if (tiered)
+                wave1k = size_wave(ctx, ctx->fs[1].wplan_k, batch_len, n_reads);
+            else if (size_wave(ctx, ctx->fs[0].wplan_k, batch_len, n_reads)) {
+                wave0k = size_bitpar(ctx, batch_len, n_reads, true);
+                if (!wave0k) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
+            }
+        }
         // split configs (trimming, summary, weighted costs): the wave kernel as the FILTER of a dense launch — candidate
         // masks and column windows in the formats of the general kernel's split mode, every verdict from the exact
         // kernel as before.  Tiered: tier 1 (all reads); plain: the only filter launch.
@@ -2111,7 +2141,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             wsp.short_lb[k] = short_lb[k];
         }
         const BdxWaveSplit &wsp_all = wsp;
-        if (split && windows && !ctx->dev.vlen) {
+        if (split && windows && !ctx->dev.vlen && !wave1k && !wave0k) {
             if (tiered)
                 wsplit1 = ctx->fs[1].wplan.split && size_wave(ctx, 1, batch_len, n_reads);
             else
@@ -2126,6 +2156,14 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_list = (const uint32_t *)ctx->d_wlist.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
+        if (wave0k) {
+            HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, ctx->fs[0].wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                             ctx->counts, 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192), ctx->stream, ctx->tune.debug));
+            ctx->wave_launches += 1;
+            t0.in_list = (const uint32_t *)ctx->d_wlist.p;
+            t0.in_count = (const unsigned int *)(scratch + 192);
+        }
         if (tiered) {
             HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
             BdxTierArgs t1{1, (uint32_t *)ctx->d_tier.p, (unsigned int *)(scratch + 192), nullptr, nullptr};
@@ -2134,7 +2172,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.dense_w = 0;
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
-            if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
+            if (wave1k) {  // tier 1 as the known-end form of the wave kernel: verdicts + trimmed keep range of what it settles, the rest listed
+                HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, f1.wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
+                ctx->wave_launches += 1;
+            } else if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                              nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
                 ctx->wave_launches += 1;
@@ -2145,8 +2187,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             } else
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,
                                            o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0, n1, split ? 1 : 0, exc_list, exc_count, &t1));
-            if (split) HIP_TRY(ctx, poison_check(nullptr, nullptr, false, true));
-            if (split)  // the exact kernel answers what tier 1 settles and lists the rest (known-score configs: the fused kernel did)
+            if (split && !wave1k) HIP_TRY(ctx, poison_check(nullptr, nullptr, false, true));
+            if (split && !wave1k)  // the exact kernel answers what tier 1 settles and lists the rest (known-score / known-end configs: the filter kernel did)
                 HIP_TRY(ctx, bdx_launch_generic(band_cfg(f1), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o, ctx->counts,
                                                 c0, npass > 1 ? c1 : nullptr, ctx->stream, w0, npass > 1 ? w1 : nullptr, n0,
                                                 npass > 1 ? n1 : nullptr, nullptr, nullptr, stp, &t1, f1.bplan.tier_slo));
@@ -2155,7 +2197,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_list = (const uint32_t *)ctx->d_tier.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
-        if (tiered || wave0) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false));
+        if (tiered || wave0 || wave0k) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false));
         // Pairs mode of the wave kernel between tier 1 and the general kernel: the listed reads are gathered into slots and
         // filtered at the full budgets by the two-intact-pieces lemma.  Known-score configs: it answers them (what it cannot
         // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the
@@ -2198,16 +2240,17 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         } else
         HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, ctx->F().bplan, ctx->F().splan, d_seq_bytes,
                                        (const long long *)d_seq_off, n_reads, o, ctx->counts, c0, c1, ctx->stream, w0, w1, n0,
-                                       n1, split ? 1 : 0, exc_list, exc_count, (tiered || wave0) ? &t0 : nullptr));
+                                       n1, split ? 1 : 0, exc_list, exc_count, (tiered || wave0 || wave0k) ? &t0 : nullptr));
+        const bool listed = tiered || wave0k;  // split configs: the exact kernel's last launch walks a list
         if (split)
-            HIP_TRY(ctx, poison_check(tiered ? (uint32_t *)t0.in_list : nullptr, tiered ? t0.in_count : nullptr, false, true));
+            HIP_TRY(ctx, poison_check(listed ? (uint32_t *)t0.in_list : nullptr, listed ? t0.in_count : nullptr, false, true));
         else
             HIP_TRY(ctx, poison_check(exc_list, exc_count, true, false));
         if (split)  // (tiered: list mode over the reads tier 1 handed on)
             HIP_TRY(ctx, bdx_launch_generic(band_cfg(ctx->F()), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
-                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, tiered ? t0.in_list : nullptr,
-                                            tiered ? t0.in_count : nullptr, stp));
+                                            npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, listed ? t0.in_list : nullptr,
+                                            listed ? t0.in_count : nullptr, stp));
         else
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
@@ -2226,8 +2269,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         if (wsplit0) ctx->path = "wave+verify";
         if (pairs) ctx->path = split ? "pairs+verify" : "pairs > " + ctx->path;
-        if (tiered) ctx->path = ((wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = "wave > " + ctx->path;
+        if (wave0k) ctx->path = "wave(end) > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,

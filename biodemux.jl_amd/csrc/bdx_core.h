@@ -1081,7 +1081,9 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 // several entries of one barcode; each is the minimum over its window, the window holding the best
 // occurrence delivers the whole-window minimum d*, so the barcode's value is the SMALLEST of its
 // entries.  Ascending (barcode << 8 | d) order visits that one first; the others are skipped.
-template <class MLen>
+// KEND (known-end class, bdx_wave.hip): entries are barcode << 22 | d << 16 | 1-based end column — the same ascending order,
+// with the leftmost end first among equal distances of a barcode; the winner's end goes through the reducer.
+template <bool KEND = false, class MLen>
 __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const MLen mlen,
                                                   const uint32_t e0, const uint32_t e1, const uint32_t e2,
                                                   const uint32_t e3, const int count) {
@@ -1100,13 +1102,13 @@ __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const ML
         if (pick == 0xFFFFFFFFu) break;  // equal duplicates: fewer distinct entries than `count`
         last = pick;
         const uint32_t e = pick - 1u;
-        const int b = (int)(e >> 8);
-        const int d = (int)(e & 255u);
+        const int b = KEND ? (int)(e >> 22) : (int)(e >> 8);
+        const int d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u);
         if (b == fed_b) continue;  // a larger entry of the barcode just fed (another window of the same pair)
         fed_b = b;
         const int m = mlen(b);  // barcode length
         const int ae = (int)__builtin_floor(red.rate * (double)m);  // :254 with the tightened rate
-        AlignOut a{d <= ae ? d : BDX_INF32, -1, -1};
+        AlignOut a{d <= ae ? d : BDX_INF32, -1, KEND ? (int)(e & 0xFFFFu) : -1};
         const double score = a.raw >= BDX_INF32 ? __builtin_inf() : (double)a.raw / (double)m;  // :155-160
         red.feed(b, a, score);
     }
@@ -1244,7 +1246,8 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
 // determine_filename (classification.jl:871-938) for a read whose passes all sit in the known-score
 // class: both passes are reducer replays, nothing is aligned, nothing is trimmed (ScoreOnly configs
 // have no trim side; the keep range is the whole read as in :907-908, :932-935).
-template <class MLen0, class MLen1>
+// KEND: single pass of the known-end class (trim_side = 5): the keep range starts behind the winner's end (:912-914).
+template <bool KEND = false, class MLen0, class MLen1>
 __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0 m0, const MLen1 m1, const int n,
                                                const KnownPass kn0, const KnownPass kn1, Verdict &v, PassOut &p1,
                                                PassOut &p2) {
@@ -1252,7 +1255,7 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     p1 = kn0.dt ? run_pass_known_dense(cfg, m0, kn0.dt, kn0.cbits, kn0.cwords)
          : kn0.ent ? run_pass_known_ent(cfg, m0, kn0.ent, kn0.count)
-                   : run_pass_known(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
+                   : run_pass_known<KEND>(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
@@ -1268,11 +1271,12 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
         v.bc2 = p2.bc;
     }
     v.bc1 = p1.bc;
-    if (n < 1) {  // :932-935 (keep_start 1 > keep_end n)
+    const int keep_start = KEND ? p1.end + 1 : 1;  // :912-914 (trim_side = 5) / :907
+    if (keep_start > n) {  // :932-935 (keep_start > keep_end = n)
         v.keep_start = 1;
         v.keep_end = 0;
     } else {
-        v.keep_start = 1;
+        v.keep_start = keep_start;
         v.keep_end = n;
     }
 }

@@ -48,6 +48,7 @@ struct BdxTuning {
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
     int poison = 0;       // BDX_POISON: every hand-over buffer is filled with 0xA5 before each classify call (tests: a consumer that reads what no producer wrote gets garbage on every run, not only when the allocator happens to hand back dirty memory)
+    int no_kend = 0;      // BDX_NO_KEND: trim_side = 5 configs never take the known-end form of the wave kernel (filter + exact kernel instead)
     int no_pairs = 0;     // BDX_NO_PAIRS: never the pairs-mode kernel (bdx_pairs.hip) between tier 1 and the general kernel
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
@@ -71,6 +72,7 @@ struct BdxFilterSet {
     DevBuf bp_tables, seed_tables, seed_tables_alt;
     BdxWavePlan wplan{};   // wave-autonomous kernel (bdx_wave.hip) for this set, when the config qualifies
     DevBuf wave_tables;
+    BdxWavePlan wplan_k{};  // known-end class (ScoreOnly conditions + trim_side = 5): the same tables, the non-split kernel with end columns
     BdxWavePlan pplan{};   // the same kernel in pairs mode (bdx_pairs.hip) at this set's full budgets, over listed reads
     DevBuf pair_tables;
 };

@@ -192,6 +192,7 @@ struct BdxWavePlan {
     int read_len_hint;     // the read length the geometry was planned for
     int hq_cap, sq_cap;    // entries of a tile's hit queue / sweep list (from the expected chance hits per read)
     int cand_words;        // split mode: candidate mask words per read (both passes)
+    int kend;              // known-end class: the non-split kernel with end columns (bdx_wave_end.hip)
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
     // tables [kb + 2][256] of barcode masks, there is no hash
@@ -236,6 +237,10 @@ struct BdxWaveSplit {
 // Implemented in bdx_wave.hip.
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
 size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words);
+// Implemented in bdx_wave_end.hip (the known-end instantiations of the same kernel).
+hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                               long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
+                               unsigned int *list_count, hipStream_t stream, int dbg = 0);
 // Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
                             const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,

@@ -178,7 +178,10 @@ __device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
 
 // TRACKW: also note which columns have a score within the budget (split mode): bit 31 - j of `inm` for column j of the
 // block (kk1 = budget + 1: the sign bit of score - kk1 is shifted in).
-template <int TF, bool TRACKW>
+// TRACKW = 2 (known-end class): bit 31 - j instead says "column j lowered the running minimum" — the last such column of a
+// sweep is the FIRST column that attains its minimum (the reference keeps the leftmost end of the best score,
+// classification.jl:142-153 with trim_side = 5: strict `<`).
+template <int TF, int TRACKW>
 __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3,
                                             const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best, const int kk1,
                                             uint32_t &inm, const int ngr) {
@@ -204,8 +207,10 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
                 sweep_step<false>(Eq[h & 1][jj], Pv, Mv, score, best);
             } else {
                 if (j == TF && TF > 0) score = __builtin_popcount(Pv) - __builtin_popcount(Mv);
+                const int best_before = best;
                 sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
-                if (TRACKW) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
+                if (TRACKW == 1) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
+                if (TRACKW == 2) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - best_before), 31);  // (inm << 1) | (score < minimum so far)
             }
         }
     }
@@ -218,7 +223,9 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // scan below), the input is a gathered slot buffer, every flagged (barcode, diagonal run) is one sweep (no record
 // tables); NW: words of a barcode mask (table entries of 8 bytes for NW <= 2, else 16).
 // MG: pairs mode with more than 128 barcodes (groups of 128; the queue is drained inside the scan).
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false>
+// KEND: known-end class (ScoreOnly conditions + trim_side = 5, no start positions wanted): survivors carry the first
+// column of their minimum, the replay trims at it.
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
@@ -478,9 +485,14 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
                 const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
                 if (blk == 0)
-                    sweep_block<TF, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                    sweep_block<TF, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
                 else
-                    sweep_block<0, SPLIT>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                    sweep_block<0, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                if (KEND && !SPLIT) {
+                    // (junk columns never lower the minimum, §3.0; masked all the same)
+                    inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
+                    if (inm) e_hi = 32 * blk + 31 - (int)__builtin_ctz(inm);  // the last column that lowered the minimum
+                }
                 if (SPLIT) {
                     // first / last column of the window whose unit distance is within the budget; the
                     // junk columns behind the window are not columns
@@ -511,7 +523,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     }
                 } else {
                     const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (ks < 4) slots[t * 4 + ks] = ((uint32_t)b << 8) | (uint32_t)best;
+                    // known-end class: barcode << 22 | d << 16 | 1-based end column (ascending order = the replay's order:
+                    // per barcode the smallest distance first, and of equal ones the leftmost end)
+                    if (ks < 4) slots[t * 4 + ks] = KEND ? (((uint32_t)b << 22) | ((uint32_t)best << 16) | (uint32_t)(lo + e_hi + 1)) : (((uint32_t)b << 8) | (uint32_t)best);
                 }
             }
         };
@@ -929,9 +943,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
                 // IEEE operations (build_wave_tables); likewise tier 1's settle rule.  No Float64 here.
                 done = true;
+                int end1 = 0;  // known-end class: 1-based end column of the survivor's alignment
                 if (cnt == 1) {
                     const uint32_t e = slots[lane * 4];
-                    const int bb = (int)(e >> 8), d = (int)(e & 255u);
+                    const int bb = KEND ? (int)(e >> 22) : (int)(e >> 8), d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u);
+                    end1 = (int)(e & 0xFFFFu);
                     const int dmax = (int)((meta[bb] >> 16) & 255u);
                     vd.bc1 = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
                     if (a.tier) done = vd.bc1 > 0 && ((settle[bb] >> (d + (a.min_delta == 0.0 ? 0 : 16))) & 1u) != 0u;
@@ -942,6 +958,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 vd.bc2 = 0;
                 vd.keep_start = vd.bc1 > 0 ? 1 : -1;  // :907-908 / :879-883 (ScoreOnly: the whole read, n >= 1)
                 vd.keep_end = vd.bc1 > 0 ? n : -1;
+                if (KEND && vd.bc1 > 0) {  // trim_side = 5: keep what follows the alignment's end (:912-914), (1, 0) if nothing does (:932-935)
+                    vd.keep_start = end1 + 1 > n ? 1 : end1 + 1;
+                    vd.keep_end = end1 + 1 > n ? 0 : n;
+                }
             } else if (!flag[lane] && cnt <= 4 && n >= 1) {
                 const LDS uint32_t *e0 = slots + lane * 4;
                 const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
@@ -951,7 +971,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 cfg.is_dual = 0;
                 cfg.max_error_rate = a.max_error_rate;
                 cfg.min_delta = a.min_delta;
-                classify_known(cfg, m0, m0, n, kn0, kn1, vd, p1, p2);
+                cfg.pass[0].trim_side = KEND ? 5 : 0;
+                cfg.pass[1].trim_side = 0;
+                classify_known<KEND>(cfg, m0, m0, n, kn0, kn1, vd, p1, p2);
                 done = true;
                 if (a.tier) {
                     // tier settle rule (same code as bdx_bitpar.hip)
@@ -1040,17 +1062,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1099,7 +1121,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 
 }  // namespace
 
-#ifndef BDX_WAVE_TU_PAIRS
+#if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
@@ -1160,7 +1182,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
 #undef BDX_WAVE_SP
 }
 
-#else  // BDX_WAVE_TU_PAIRS: the pairs-mode instantiations live in a translation unit of their own (bdx_pairs.hip)
+#elif defined(BDX_WAVE_TU_PAIRS)  // the pairs-mode instantiations live in a translation unit of their own (bdx_pairs.hip)
 
 // Pairs mode over the reads of a list (gathered into slots by bdx_launch_gather): final verdicts at the full budgets for
 // the known-score class (what it cannot answer goes to `list`), candidate masks + windows in split mode.
@@ -1201,6 +1223,50 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 #undef BDX_PAIRS_KB
 #undef BDX_PAIRS_NW
 #undef BDX_PAIRS_SP
+}
+
+#else  // BDX_WAVE_TU_KEND: the known-end instantiations (bdx_wave_end.hip)
+
+// The kernel for configs of the known-end class (ScoreOnly conditions + trim_side = 5, no start positions wanted): same
+// launch as bdx_launch_wave for a known-score config, the verdicts carry the trimmed keep range.
+hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                               long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
+                               unsigned int *list_count, hipStream_t stream, int dbg) {
+    if (n_reads <= 0) return hipSuccess;
+    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr) return hipErrorInvalidValue;
+    WaveArgs a;
+    fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, nullptr);
+    a.seq = d_seq;
+    a.off = d_off;
+    a.n_reads = n_reads;
+    a.tier = tier1;
+    a.tier_slo = tier_slo;
+    const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
+    const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
+    long long blocks = (long long)wp.blocks;
+    const long long useful = (tiles + wp.waves - 1) / wp.waves;
+    if (blocks > useful) blocks = useful;
+    if (blocks < 1) blocks = 1;
+    const int tf = wp.track_from;
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
+    switch (wp.rw) {
+        case 32:
+            BDX_WAVE_TF(32);
+        case 16:
+            BDX_WAVE_TF(16);
+        case 8:
+            BDX_WAVE_TF(8);
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
 }
 
 #endif

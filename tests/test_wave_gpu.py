@@ -338,3 +338,80 @@ def test_wave_many_barcodes(n_bc, kw, expect, monkeypatch):
     bcs = synth.make_barcodes(n_bc, 24, seed=91, min_hamming=6)
     seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=92)
     _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, want_pass=False, expect_wave=expect)
+
+
+# ---- known-end class: trim_side = 5 without start positions — the wave kernel answers and trims itself ----
+def _kend_both(cfg, seq, off, monkeypatch, expect=True, hint=None):
+    """verdicts + keep range with and without the known-end form (BDX_NO_KEND: filter + exact kernel); both equal the oracle."""
+    oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False)
+    exp = oc.classify(seq, off)
+    for kend in (True, False):
+        if kend:
+            monkeypatch.delenv("BDX_NO_KEND", raising=False)
+        else:
+            monkeypatch.setenv("BDX_NO_KEND", "1")
+        with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+            monkeypatch.delenv("BDX_NO_KEND", raising=False)
+            if hint is not None:
+                hc.set_read_length_hint(hint)
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"known-end {kend} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), (kend, hc.kernel_path)
+            assert ("wave(end)" in hc.kernel_path) == (kend and expect), hc.kernel_path
+            fuzz.assert_same(hc.classify(seq, off), exp, f"known-end {kend}, second call [{hc.kernel_path}]")
+    return exp
+
+
+@pytest.mark.parametrize("kw", [
+    dict(trim_side=5), dict(trim_side=5, min_delta=0.05), dict(trim_side=5, max_error_rate=0.05), dict(trim_side=5, max_error_rate=0.0),
+    dict(trim_side=5, max_error_rate=0.2), dict(trim_side=5, max_error_rate=0.2, min_delta=0.1), dict(trim_side=5, max_error_rate=0.15),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_known_end_c2_shape(kw, monkeypatch):
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 50000, 150, seed=95, sub=0.03, ins=0.01, dele=0.01, repeat=dict(frac=0.15))
+    exp = _kend_both(_cfg(bcs, **kw), seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+    m = exp["bc1"] > 0
+    assert (exp["keep_start"][m] > 1).mean() > 0.9  # (the case is not vacuous: nearly every match is trimmed)
+
+
+def test_known_end_not_with_start_positions_or_other_trim_sides(monkeypatch):
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 20000, 150, seed=96)
+    for kw in (dict(trim_side=3), dict(trim_side=5, summary=True), dict(trim_side=5, mismatch=2, indel=2)):
+        _kend_both(_cfg(bcs, **kw), seq, off, monkeypatch, expect=False)
+    cfg = _cfg(bcs, trim_side=5)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=True).classify(seq, off)
+    with H.bdx.HipClassifier(cfg, want_pass=True) as hc:  # per-pass outputs include the start positions: filter + exact kernel
+        fuzz.assert_same(hc.classify(seq, off), exp, hc.kernel_path)
+        assert "wave(end)" not in hc.kernel_path
+
+
+def test_known_end_barcode_at_the_read_ends_and_ragged_reads(monkeypatch):
+    """Alignments that end at the last column (nothing is kept: (1, 0)), at the first columns, reads shorter than a barcode,
+    empty reads; ties between equally good ends (homopolymer runs behind the barcode)."""
+    rng = np.random.Generator(np.random.PCG64(97))
+    bcs = synth.make_barcodes(64, 24, seed=97)
+    reads = []
+    for i in range(16000):
+        b = bcs[int(rng.integers(0, 64))]
+        c = synth.mutate_copy(rng, b, int(rng.integers(0, 3))).decode()
+        body = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(0, 130))))
+        kind = i % 6
+        if kind == 0:
+            reads.append(body + c)                         # ends at the last column
+        elif kind == 1:
+            reads.append(c + body)
+        elif kind == 2:
+            reads.append(c + c[-1] * 6 + body)             # a run of the barcode's last base behind it
+        elif kind == 3:
+            reads.append(body[:20] + c + c[:12] + body)    # a second, partial copy
+        elif kind == 4:
+            reads.append(c[: int(rng.integers(0, 24))])    # shorter than the barcode (or empty)
+        else:
+            reads.append(body[:60] + c + body[60:])
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(trim_side=5), dict(trim_side=5, max_error_rate=0.2, min_delta=0.05)):
+        exp = _kend_both(_cfg(bcs, **kw), seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.4
+    assert ((exp["keep_start"] == 1) & (exp["keep_end"] == 0)).sum() > 500

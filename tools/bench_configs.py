@@ -88,6 +88,7 @@ def main():
     run("C2 rate0.2 (default)", C(**base, max_error_rate=0.2), seq, off)
     run("C2 rate0.1 min_delta0.1", C(**base, max_error_rate=0.1, min_delta=0.1), seq, off)
     run("C2 rate0.1 trim3", C(**base, max_error_rate=0.1, trim_side=3), seq, off, outs=("bc1", "keep_start", "keep_end"))
+    run("C2 rate0.1 trim5", C(**base, max_error_rate=0.1, trim_side=5), seq, off, outs=("bc1", "keep_start", "keep_end"))
     run("C2 rate0.2 trim5", C(**base, max_error_rate=0.2, trim_side=5), seq, off, outs=("bc1", "keep_start", "keep_end"))
     run("C2 rate0.2 summary", C(**base, max_error_rate=0.2, summary=True), seq, off)
     run("demo2 costs (mm1 indel2 r.25 d.15)", C(**base, max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), seq, off)
