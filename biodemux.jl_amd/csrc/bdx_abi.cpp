@@ -603,7 +603,6 @@ int build_wave_tables(bdx_ctx *ctx) {
     // "split" — it only filters, candidate masks and column windows go to the exact kernel (either pass count)
     bool split = false;
     for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
-    if (!split && c.is_dual) return BDX_OK;
     // :hamming / :exact (always split: their scans run in the exact kernel, restricted to the hand-over windows): the
     // budget is floor(rate * m) substitutions / 0, one operation costs 1
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
@@ -691,7 +690,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.n_barcodes = Btot;
     wp.b0 = c.pass[0].n_barcodes;
     wp.split = split ? 1 : 0;
-    wp.cand_words = cwt;
+    wp.cand_words = split ? cwt : (c.is_dual ? 4 : 0);  // (known-score dual configs: four survivor slots of pass 1 per read in that area)
     wp.bm_bytes = (1 << (2 * q)) / 8;
     wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
     // seed table: the bitmap is exact (one bit per key of the 4^q key space), so a hit's entry is found by the RANK of its
@@ -801,7 +800,7 @@ bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
         // queues: the planted barcode's pieces (up to kb + 1 = 3 hits, one or two records) + the chance hits, with slack
         const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * wp.chance));
         const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * wp.chance));
-        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.split ? wp.cand_words : 0);
+        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.cand_words);
         const int shapes[3] = {8, 16, 4};
         for (int w : shapes) {
             if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
@@ -844,7 +843,6 @@ int build_pair_tables(bdx_ctx *ctx) {
         return BDX_OK;
     bool split = false;
     for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
-    if (!split && c.is_dual) return BDX_OK;
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
     const int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
     if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
@@ -926,7 +924,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.pairs_kb = KB;
     wp.nw = nw;
     wp.groups = groups;
-    wp.cand_words = cwt;
+    wp.cand_words = split ? cwt : (c.is_dual ? 4 : 0);  // (known-score dual configs: the survivor slots of pass 1)
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 112 * 1024) return BDX_OK;  // (at least four waves' work areas must fit beside the tables)
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_tab = 0, o_peq = al(tab.size() * 4), o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4),
@@ -968,7 +966,7 @@ bool size_pairs(bdx_ctx *ctx, int read_len) {
     // drained several times per tile; a tile whose queue runs over between two drains is handed on / swept whole)
     wp.hq_cap = wp.groups > 1 ? 1024 : 56 * rw;
     wp.sq_cap = 0;
-    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.split ? wp.cand_words : 0);
+    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.cand_words);
     int best = 0;
     const int shapes[3] = {16, 8, 4};
     for (int w : shapes) {
@@ -2182,7 +2180,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 ctx->wave_launches += 1;
             } else if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                             ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
+                                             ctx->counts, (int *)(scratch + 256), 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug,
+                                             nullptr, f1.bplan.tier_slo[1]));
                 ctx->wave_launches += 1;
             } else
             HIP_TRY(ctx, bdx_launch_bitpar(ctx->dev, ctx->plan, f1.bplan, f1.splan, d_seq_bytes, (const long long *)d_seq_off, n_reads,

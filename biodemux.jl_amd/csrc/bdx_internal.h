@@ -250,7 +250,8 @@ hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const
                              long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr,
+                           double tier_slo1 = 0.0);
 
 // Implemented in bdx_device.hip.
 hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, const uint8_t *d_seq,

@@ -57,6 +57,8 @@ struct WaveArgs {
     int per_wave;            // LDS bytes of one wave's work area
     int tier;                // 1: tier 1 of the tiered budgets (settle rule applies)
     double tier_slo;
+    double tier_slo1;        // ... of pass 1 (dual configs)
+    int dual;                // two passes (known-score form: the survivors of pass 1 sit in the candidate-word area)
     uint32_t *list;          // reads this kernel does not answer ...
     unsigned int *list_count;  // ... and how many
     // split mode (trimming / summary / weighted costs: the exact kernel gives every verdict; this kernel only filters):
@@ -408,10 +410,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 rl[lane] = lv;
                 gid[lane] = iv;
             }
-            if (SPLIT) {
-                wcl1[lane] = 0;
+            wcl1[lane] = 0;  // (split mode: window entries of pass 1; known-score dual configs: survivors of pass 1)
+            if (SPLIT)
                 for (int w = 0; w < cwt; ++w) cand[lane * cwt + w] = 0u;
-            }
         }
 
         // ---- bytes (requested one tile ago): registers -> 2-bit / 4-bit images ----
@@ -522,10 +523,14 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         dst[2] = (uint32_t)(jf_abs + e_hi);
                     }
                 } else {
-                    const int ks = __hip_atomic_fetch_add(&scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (dual known-score configs: the survivors of pass 1 — barcodes numbered behind those of pass 0 — have their own
+                    // four slots, in the candidate-word area, and their own count)
+                    const bool second = b >= a.B0;
+                    const int bl = second ? b - a.B0 : b;
+                    const int ks = __hip_atomic_fetch_add(second ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // known-end class: barcode << 22 | d << 16 | 1-based end column (ascending order = the replay's order:
                     // per barcode the smallest distance first, and of equal ones the leftmost end)
-                    if (ks < 4) slots[t * 4 + ks] = KEND ? (((uint32_t)b << 22) | ((uint32_t)best << 16) | (uint32_t)(lo + e_hi + 1)) : (((uint32_t)b << 8) | (uint32_t)best);
+                    if (ks < 4) (second ? cand : slots)[t * 4 + ks] = KEND ? (((uint32_t)bl << 22) | ((uint32_t)best << 16) | (uint32_t)(lo + e_hi + 1)) : (((uint32_t)bl << 8) | (uint32_t)best);
                 }
             }
         };
@@ -932,12 +937,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         bool done = false;
         if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
             const int n = rlen(lane);
-            const int cnt = scnt[lane];
+            const int cnt = scnt[lane], cnt1 = a.dual ? wcl1[lane] : 0;
             // known-score class per read: this kernel only runs for configs whose ranges resolve to
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
             const bool simple = a.out.pass_start == nullptr && a.out.pass_end == nullptr && a.out.pass_raw == nullptr && a.out.pass_bc == nullptr &&
                                 a.out.pass_score == nullptr && a.out.pass_delta == nullptr;  // (kernel-uniform: only the verdict vectors are wanted)
-            if (simple && !flag[lane] && cnt <= 1 && n >= 1) {
+            if (simple && !a.dual && !flag[lane] && cnt <= 1 && n >= 1) {
                 // No or one survivor and nobody asked for scores: the reducers' answer for a lone survivor with distance d is a
                 // per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
                 // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
@@ -962,27 +967,33 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     vd.keep_start = end1 + 1 > n ? 1 : end1 + 1;
                     vd.keep_end = end1 + 1 > n ? 0 : n;
                 }
-            } else if (!flag[lane] && cnt <= 4 && n >= 1) {
+            } else if (!flag[lane] && cnt <= 4 && cnt1 <= 4 && n >= 1) {
                 const LDS uint32_t *e0 = slots + lane * 4;
+                const LDS uint32_t *e1 = cand + lane * 4;  // (dual only)
                 const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
-                const KnownPass kn1{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+                const KnownPass kn1 = a.dual ? KnownPass{true, e1[0], e1[1], e1[2], e1[3], cnt1, nullptr, nullptr, nullptr, 0}
+                                             : KnownPass{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
                 const auto m0 = [&](const int bb) { return (int)(meta[bb] & 255u); };
-                BdxDevCfg cfg;  // (only the fields the replay reads; single pass)
-                cfg.is_dual = 0;
+                const auto m1 = [&](const int bb) { return (int)(meta[a.B0 + bb] & 255u); };
+                BdxDevCfg cfg;  // (only the fields the replay reads)
+                cfg.is_dual = a.dual;
                 cfg.max_error_rate = a.max_error_rate;
                 cfg.min_delta = a.min_delta;
                 cfg.pass[0].trim_side = KEND ? 5 : 0;
                 cfg.pass[1].trim_side = 0;
-                classify_known<KEND>(cfg, m0, m0, n, kn0, kn1, vd, p1, p2);
+                classify_known<KEND>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
                 done = true;
                 if (a.tier) {
                     // tier settle rule (same code as bdx_bitpar.hip)
                     const bool nd = a.min_delta == 0.0;
-                    bool ok = cnt >= 1 && (p1.score < a.tier_slo);
-                    if (ok && !nd) {
-                        ok = (cnt >= 2 && p1.sub <= a.tier_slo) ||
-                             (a.out.pass_delta == nullptr && (a.tier_slo - p1.score) >= a.min_delta && p1.status == 1);
-                    }
+                    const auto settled = [&](const PassOut &po, const int c, const double slo) {
+                        if (c < 1 || !(po.score < slo)) return false;
+                        if (nd) return true;
+                        if (c >= 2 && po.sub <= slo) return true;
+                        return a.out.pass_delta == nullptr && (slo - po.score) >= a.min_delta && po.status == 1;
+                    };
+                    bool ok = settled(p1, cnt, a.tier_slo);
+                    if (ok && a.dual && p1.status == 1) ok = settled(p2, cnt1, a.tier_slo1);
                     done = ok;
                 }
             }
@@ -1031,7 +1042,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
             // DemuxStats scalar counters (classification.jl:942-978), accumulated in LDS across the workgroup's tiles
             if (a.counts) {
-                const int slot = vd.bc1 > 0 ? 4 + (vd.bc1 - 1) * a.counts_stride2 : -1;
+                const int slot = vd.bc1 > 0 ? 4 + (vd.bc1 - 1) * a.counts_stride2 + (vd.bc2 > 0 ? vd.bc2 - 1 : 0) : -1;
                 const int cls = vd.bc1 > 0 ? 1 : (vd.bc1 == 0 ? 2 : 3);
                 __hip_atomic_fetch_add(&hist[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&hist[cls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1095,7 +1106,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.split ? wp.cand_words : 0);
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.cand_words);
     a.hq_cap = wp.hq_cap;
     a.sq_cap = wp.sq_cap;
     a.list = list;
@@ -1111,6 +1122,8 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     }
     a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
     a.ngroups = wp.groups > 0 ? wp.groups : 1;
+    a.tier_slo1 = 0.0;
+    a.dual = 0;
     a.slot = 0;
     a.cpr = 1;
     a.cpr_inv = 65536;
@@ -1140,7 +1153,8 @@ size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_
 
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
-                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
+                           double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp,
+                           double tier_slo1) {
     if (n_reads <= 0) return hipSuccess;
     (void)d_tile_counter;  // (tiles are dealt round robin: no queue)
     WaveArgs a;
@@ -1150,6 +1164,9 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.n_reads = n_reads;
     a.tier = tier1;
     a.tier_slo = tier_slo;
+    a.tier_slo1 = tier_slo1;
+    a.dual = (!wp.split && cfg.is_dual) ? 1 : 0;
+    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;  // (the survivors of pass 1 live in the candidate-word area: four per read)
     if (wp.pairs_kb > 0) return hipErrorInvalidValue;
     if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
@@ -1203,6 +1220,8 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.lens = d_lens;
     a.idmap = d_idmap;
     a.n_dev = d_count;
+    a.dual = (!wp.split && cfg.is_dual) ? 1 : 0;
+    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;
     if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
     if (wp.rw * wp.cpr > 32 * 40 || (wp.slot & 15) || wp.rw * wp.slot + 16 > wp.span_cap) return hipErrorInvalidValue;
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;

@@ -322,3 +322,21 @@ def test_pairs_unaligned_device_buffers(monkeypatch):
             assert hc.pair_launches > 0
             for k, v in out.items():
                 assert np.array_equal(v.cpu().numpy(), exp[k]), (shift, k)
+
+
+def test_pairs_dual_known_score(monkeypatch):
+    """Dual barcodes without trimming at the default rate: tier 1 and the pairs mode both replay two passes."""
+    b1 = synth.make_barcodes(24, 24, seed=111)
+    b2 = synth.make_barcodes(16, 24, seed=112)
+    seq, off, _ = synth.make_reads(b1, 30000, 150, seed=113, plant_lo=0, plant_hi=40, second=(b2, 100, 126), sub=0.05, ins=0.012, dele=0.012)
+    for kw in (dict(), dict(min_delta=0.08)):
+        cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                                bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.2, **kw)
+        exp = _with_and_without(cfg, seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.3
+    b1 = synth.make_barcodes(100, 24, seed=114, min_hamming=6)   # 100 + 60 barcodes: two groups of 128
+    b2 = synth.make_barcodes(60, 24, seed=115, min_hamming=6)
+    seq, off, _ = synth.make_reads(b1, 15000, 150, seed=116, plant_lo=0, plant_hi=40, second=(b2, 100, 126), sub=0.05, ins=0.012, dele=0.012)
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 100, ids=[f"x{i}" for i in range(100)], is_dual=True, bc_seqs2=b2,
+                            bc_lengths_no_N2=[24] * 60, ids2=[f"y{i}" for i in range(60)], max_error_rate=0.2)
+    _with_and_without(cfg, seq, off, monkeypatch, want_pass=False)

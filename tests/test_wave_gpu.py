@@ -415,3 +415,36 @@ def test_known_end_barcode_at_the_read_ends_and_ragged_reads(monkeypatch):
         exp = _kend_both(_cfg(bcs, **kw), seq, off, monkeypatch)
     assert (exp["bc1"] > 0).mean() > 0.4
     assert ((exp["keep_start"] == 1) & (exp["keep_end"] == 0)).sum() > 500
+
+
+# ---- dual barcodes in the known-score class: both passes replayed by the wave kernel ----
+@pytest.mark.parametrize("kw", [
+    dict(), dict(min_delta=0.05), dict(max_error_rate=0.05), dict(max_error_rate=0.2), dict(max_error_rate=0.2, min_delta=0.08),
+    dict(max_error_rate=0.17),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "dual")
+def test_wave_dual_known_score(kw, monkeypatch):
+    b1 = synth.make_barcodes(24, 24, seed=101)
+    b2 = synth.make_barcodes(16, 24, seed=102)
+    seq, off, _ = synth.make_reads(b1, 40000, 150, seed=103, plant_lo=0, plant_hi=40, second=(b2, 100, 126), sub=0.03, ins=0.008, dele=0.008,
+                                   repeat=dict(frac=0.1))
+    base = dict(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.1)
+    base.update(kw)
+    cfg = H.bdx.DemuxConfig(**base)
+    for want_pass in (True, False):
+        exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=want_pass)
+    assert (exp["bc1"] > 0).mean() > 0.3 and (exp["bc2"] > 0).mean() > 0.3
+
+
+def test_wave_dual_many_survivors_and_mixed_lengths(monkeypatch):
+    """Pass 1 with a family of near-identical barcodes (more than four survivors: the read is handed on), pass 0 with barcodes
+    of 20..28 nt (different budgets and piece counts per barcode)."""
+    lens = np.random.Generator(np.random.PCG64(104)).choice([20, 24, 26, 28], size=40)
+    b1 = synth.make_barcodes(40, 24, seed=104, lengths=lens)
+    base = synth.make_barcodes(1, 24, seed=105)[0]
+    fam = [base] + [base[:j] + ("A" if base[j] != "A" else "C") + base[j + 1:] for j in (1, 3, 5, 7, 9, 11)]
+    b2 = fam + synth.make_barcodes(9, 24, seed=106)
+    seq, off, _ = synth.make_reads(b1, 30000, 160, seed=107, plant_lo=0, plant_hi=40, second=(b2, 100, 134))
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[len(b) for b in b1], ids=[f"x{i}" for i in range(40)], is_dual=True, bc_seqs2=b2,
+                            bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.1, min_delta=0.02)
+    _both_kernels(cfg, seq, off, monkeypatch)
