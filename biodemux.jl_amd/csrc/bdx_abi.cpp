@@ -610,9 +610,16 @@ int build_wave_tables(bdx_ctx *ctx) {
     if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     int Btot = 0, cwt = 0;
+    bool ranged = false;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
-        if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        // (a ref_search_range is allowed for :semiglobal: the kernel resolves every read's column window itself, classification.jl:795-807;
+        // start / end ranges that could bind stay on the general kernel)
+        if (p.explicit_window != 0 || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        if (!whole(p.ref_search_range)) {
+            if (c.algorithm != BDX_ALG_SEMIGLOBAL) return BDX_OK;
+            ranged = true;
+        }
         if (p.n_barcodes < 1) return BDX_OK;
         for (uint32_t i = 0; i < p.bc_off[p.n_barcodes]; ++i) {
             const uint8_t ch = p.bc_bytes[i];
@@ -690,6 +697,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.n_barcodes = Btot;
     wp.b0 = c.pass[0].n_barcodes;
     wp.split = split ? 1 : 0;
+    wp.ranged = ranged ? 1 : 0;
     wp.cand_words = split ? cwt : (c.is_dual ? 4 : 0);  // (known-score dual configs: four survivor slots of pass 1 per read in that area)
     wp.bm_bytes = (1 << (2 * q)) / 8;
     wp.track_from = track < 0 ? 0 : (track > 28 ? 28 : track);
@@ -800,7 +808,7 @@ bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
         // queues: the planted barcode's pieces (up to kb + 1 = 3 hits, one or two records) + the chance hits, with slack
         const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * wp.chance));
         const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * wp.chance));
-        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.cand_words);
+        const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.cand_words + (wp.ranged ? 4 : 0));
         const int shapes[3] = {8, 16, 4};
         for (int w : shapes) {
             if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
@@ -848,9 +856,16 @@ int build_pair_tables(bdx_ctx *ctx) {
     if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     int Btot = 0, cwt = 0;
+    bool ranged = false;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
-        if (p.explicit_window != 0 || !whole(p.ref_search_range) || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        // (a ref_search_range is allowed for :semiglobal: the kernel resolves every read's column window itself, classification.jl:795-807;
+        // start / end ranges that could bind stay on the general kernel)
+        if (p.explicit_window != 0 || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        if (!whole(p.ref_search_range)) {
+            if (c.algorithm != BDX_ALG_SEMIGLOBAL) return BDX_OK;
+            ranged = true;
+        }
         if (p.n_barcodes < 1) return BDX_OK;
         for (uint32_t i = 0; i < p.bc_off[p.n_barcodes]; ++i) {
             const uint8_t ch = p.bc_bytes[i];
@@ -924,6 +939,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.pairs_kb = KB;
     wp.nw = nw;
     wp.groups = groups;
+    wp.ranged = ranged ? 1 : 0;
     wp.cand_words = split ? cwt : (c.is_dual ? 4 : 0);  // (known-score dual configs: the survivor slots of pass 1)
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 112 * 1024) return BDX_OK;  // (at least four waves' work areas must fit beside the tables)
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
@@ -966,7 +982,7 @@ bool size_pairs(bdx_ctx *ctx, int read_len) {
     // drained several times per tile; a tile whose queue runs over between two drains is handed on / swept whole)
     wp.hq_cap = wp.groups > 1 ? 1024 : 56 * rw;
     wp.sq_cap = 0;
-    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.cand_words);
+    const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.cand_words + (wp.ranged ? 4 : 0));
     int best = 0;
     const int shapes[3] = {16, 8, 4};
     for (int w : shapes) {

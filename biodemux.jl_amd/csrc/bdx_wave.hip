@@ -77,6 +77,9 @@ struct WaveArgs {
     int cpr_inv;             // ceil(2^16 / cpr)
     int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
     int ngroups;             // pairs mode: groups of 128 barcodes (one set of piece tables each)
+    int cand_area;           // words per read of the area behind the sweep list (candidate masks / survivors of pass 1)
+    int ranged;              // some pass has a ref_search_range: per read the column window [first, last] of each pass (classification.jl:795-807)
+    BdxDevPass dpass[2];     // the passes' ranges (ranged only)
     const int *lens;         // [count] read lengths
     const uint32_t *idmap;   // [count] batch read numbers (= the list the reads were gathered from)
     const unsigned int *n_dev;  // the number of gathered reads lives on the device
@@ -290,6 +293,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint32_t *recq = hq + HQ;                             // u32[SQ]: the tile's records in use (slot numbers) = its sweeps
     const int cwt = a.cw[0] + a.cw[1];                        // split mode: candidate mask words per read (pass 0 then pass 1)
     LDS uint32_t *cand = recq + SQ;                           // u32[RW][cwt] (split mode)
+    // ranged configs: per read and pass the 0-based first column and the last column (1-based = exclusive end) of the window
+    LDS int *wwin = (LDS int *)(cand + RW * a.cand_area);     // int[4][RW]: first0, last0, first1, last1
+    const auto win_lo = [&](const int t, const bool second) -> int { return a.ranged ? wwin[(second ? 2 : 0) * RW + t] : 0; };
+    const auto win_hi = [&](const int t, const bool second, const int n) -> int { return a.ranged ? wwin[(second ? 3 : 1) * RW + t] : n; };
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
@@ -443,6 +450,24 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         const uint32_t iv_after = load_gid(tile_next + nwaves);
         WAVE_SYNC();
 
+        if (a.ranged && lane < RW) {
+            // the passes' column windows for this read; a read outside the known-score class (a binding start / end range,
+            // the :805 sanity check) goes to the list — in split mode the exact kernel decides anyway, an empty window
+            // just leaves the read without candidates
+            const int n = lane < nr ? rlen(lane) : 0;
+            bool known = true;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                PassWindow w{1, 0, 0, 0};
+                const bool ok = (p == 0 || a.B0 < B) && lane < nr && pass_window(a.dpass[p], n, w);
+                wwin[(2 * p) * RW + lane] = ok ? w.first - 1 : 0;
+                wwin[(2 * p + 1) * RW + lane] = ok ? w.last : 0;
+                if (p == 0 || a.B0 < B) known = known && ok && n > 0 && w.max_start >= n && w.min_end <= 1;
+            }
+            if (!SPLIT && !known && lane < nr) flag[lane] = 1;
+        }
+        if (a.ranged) WAVE_SYNC();
+
         // uniform read length of the tile (0: mixed) for the hit -> read mapping
         int ulen = 0;
         {
@@ -552,8 +577,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 valid = valid && kk != 255;
                 const int n = rl[t];
                 int lo = dlo - kk, hi = dlo + wd + mm + kk;
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > n ? n : hi;
+                const int wlo = win_lo(t, b >= a.B0), whi = win_hi(t, b >= a.B0, n);
+                lo = lo < wlo ? wlo : lo;
+                hi = hi > whi ? whi : hi;
                 sweep_lane(valid, t, b, lo, hi);
             }
             nhq = 0;
@@ -784,7 +810,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         do {
                             const uint32_t e = ent[idx];
                             idx = e >> 16;
-                            {
+                            bool inwin = true;  // (ranged configs: the seed must lie inside the pass's column window)
+                            if (a.ranged) {
+                                const bool second_b = (int)(e & 2047u) - 1 >= a.B0;
+                                inwin = p >= wwin[(second_b ? 2 : 0) * RW + t] && p + q <= wwin[(second_b ? 3 : 1) * RW + t];
+                            }
+                            if (inwin) {
                                 const uint32_t pb = e & 2047u;  // barcode + 1
                                 const int kk = (int)((meta[pb - 1u] >> 8) & 255u);
                                 const int diag = p - (int)((e >> 11) & 31u);
@@ -870,8 +901,13 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const int n = rlen(t);
                 lo = dmin - kk - 1;
                 hi = dmax + mm + kk + 1;
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > n ? n : hi;
+                int wlo = 0, whi = n;
+                if (a.ranged) {
+                    wlo = wwin[(b >= a.B0 ? 2 : 0) * RW + t];
+                    whi = wwin[(b >= a.B0 ? 3 : 1) * RW + t];
+                }
+                lo = lo < wlo ? wlo : lo;
+                hi = hi > whi ? whi : hi;
             }
             sweep_lane(valid, t, b, lo, hi);
         }
@@ -896,7 +932,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 for (int b0 = 0; b0 < B; b0 += 64) {
                     const int b = b0 + lane < B ? b0 + lane : 0;
                     const bool valid = b0 + lane < B && ((meta[b] >> 8) & 255u) != 255u;  // (255: the barcode can never be recorded)
-                    sweep_lane(valid, t, b, 0, n);
+                    sweep_lane(valid, t, b, win_lo(t, b >= a.B0), win_hi(t, b >= a.B0, n));
                 }
                 WAVE_SYNC();
             }
@@ -1106,7 +1142,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.cand_words);
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.cand_words + (wp.ranged ? 4 : 0));
     a.hq_cap = wp.hq_cap;
     a.sq_cap = wp.sq_cap;
     a.list = list;
@@ -1122,6 +1158,10 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     }
     a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
     a.ngroups = wp.groups > 0 ? wp.groups : 1;
+    a.cand_area = wp.cand_words;
+    a.ranged = wp.ranged;
+    a.dpass[0] = cfg.pass[0];
+    a.dpass[1] = cfg.pass[1];
     a.tier_slo1 = 0.0;
     a.dual = 0;
     a.slot = 0;

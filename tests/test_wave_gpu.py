@@ -448,3 +448,40 @@ def test_wave_dual_many_survivors_and_mixed_lengths(monkeypatch):
     cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[len(b) for b in b1], ids=[f"x{i}" for i in range(40)], is_dual=True, bc_seqs2=b2,
                             bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.1, min_delta=0.02)
     _both_kernels(cfg, seq, off, monkeypatch)
+
+
+# ---- ref_search_range: the kernel resolves every read's column window itself (classification.jl:795-807) ----
+@pytest.mark.parametrize("rng_s,kw", [
+    ("1:60", dict()), ("1:60", dict(min_delta=0.05)), ("end-59:end", dict()), ("5:end-3", dict()), ("20:90", dict()),
+    ("1:60", dict(max_error_rate=0.2)), ("1:40", dict(max_error_rate=0.2, min_delta=0.05)),     # tiers + pairs mode on windows
+    ("1:60", dict(trim_side=5)), ("end-70:end", dict(trim_side=5, max_error_rate=0.2)),            # known-end class
+    ("1:60", dict(trim_side=3)), ("10:100", dict(trim_side=3, summary=True, max_error_rate=0.2)),  # split mode
+], ids=lambda v: v if isinstance(v, str) else ",".join(f"{k}={x}" for k, x in v.items()) or "plain")
+def test_wave_ref_search_range(rng_s, kw, monkeypatch):
+    bcs = synth.make_barcodes(96, 24, seed=121)
+    # barcodes planted anywhere: many lie outside or across the window's edges
+    seq, off, _ = synth.make_ragged_reads(bcs, 40000, 30, 150, seed=122, sub=0.03, ins=0.01, dele=0.01, repeat=dict(frac=0.1))
+    cfg = _cfg(bcs, ref_search_range=H.bdx.parse_dynamic_range(rng_s), **kw)
+    exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=False)
+    assert 0.05 < (exp["bc1"] > 0).mean() < 0.95
+    if "summary" not in kw:
+        _both_kernels(cfg, seq, off, monkeypatch, want_pass=True)
+
+
+def test_wave_ref_search_range_dual(monkeypatch):
+    b1 = synth.make_barcodes(24, 24, seed=123)
+    b2 = synth.make_barcodes(16, 24, seed=124)
+    seq, off, _ = synth.make_reads(b1, 30000, 150, seed=125, plant_lo=0, plant_hi=50, second=(b2, 90, 126), sub=0.03, ins=0.008, dele=0.008)
+    for kw in (dict(), dict(max_error_rate=0.2), dict(trim_side=5, trim_side2=3, max_error_rate=0.2)):
+        cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                                bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=kw.pop("max_error_rate", 0.1),
+                                ref_search_range=H.bdx.parse_dynamic_range("1:60"), ref_search_range2=H.bdx.parse_dynamic_range("end-59:end"), **kw)
+        exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=False)
+    assert (exp["bc1"] > 0).mean() > 0.2
+
+
+def test_wave_not_with_binding_start_or_end_ranges(monkeypatch):
+    bcs = synth.make_barcodes(96, 24, seed=126)
+    seq, off, _ = synth.make_reads(bcs, 10000, 150, seed=127)
+    for kw in (dict(barcode_start_range=H.bdx.parse_dynamic_range("1:20")), dict(barcode_end_range=H.bdx.parse_dynamic_range("30:end"))):
+        _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, want_pass=False, expect_wave=False)
