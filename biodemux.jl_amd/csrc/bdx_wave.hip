@@ -230,7 +230,9 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // MG: pairs mode with more than 128 barcodes (groups of 128; the queue is drained inside the scan).
 // KEND: known-end class (ScoreOnly conditions + trim_side = 5, no start positions wanted): survivors carry the first
 // column of their minimum, the replay trims at it.
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false>
+// GEN: the general form — dual configs and ref_search_range windows; false: single pass over whole reads (the headline
+// configuration: those checks are compiled out).
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false, bool GEN = true>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     const int B = a.B;
     constexpr int q = Q;  // seed length
     // (pairs mode: the number of gathered reads is only known on the device)
+    const bool ranged = GEN && a.ranged != 0, dual = GEN && a.dual != 0;
     const long long n_reads = PAIRS ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint32_t *cand = recq + SQ;                           // u32[RW][cwt] (split mode)
     // ranged configs: per read and pass the 0-based first column and the last column (1-based = exclusive end) of the window
     LDS int *wwin = (LDS int *)(cand + RW * a.cand_area);     // int[4][RW]: first0, last0, first1, last1
-    const auto win_lo = [&](const int t, const bool second) -> int { return a.ranged ? wwin[(second ? 2 : 0) * RW + t] : 0; };
-    const auto win_hi = [&](const int t, const bool second, const int n) -> int { return a.ranged ? wwin[(second ? 3 : 1) * RW + t] : n; };
+    const auto win_lo = [&](const int t, const bool second) -> int { return ranged ? wwin[(second ? 2 : 0) * RW + t] : 0; };
+    const auto win_hi = [&](const int t, const bool second, const int n) -> int { return ranged ? wwin[(second ? 3 : 1) * RW + t] : n; };
 
     // ---- tables -> LDS (the only workgroup barrier of the kernel besides the final histogram flush) ----
     for (int i = tid; i < a.bm_bytes / 4; i += blockDim.x) ((LDS uint32_t *)bm)[i] = ((const uint32_t *)a.bitmap)[i];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         const uint32_t iv_after = load_gid(tile_next + nwaves);
         WAVE_SYNC();
 
-        if (a.ranged && lane < RW) {
+        if (ranged && lane < RW) {
             // the passes' column windows for this read; a read outside the known-score class (a binding start / end range,
             // the :805 sanity check) goes to the list — in split mode the exact kernel decides anyway, an empty window
             // just leaves the read without candidates
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             }
             if (!SPLIT && !known && lane < nr) flag[lane] = 1;
         }
-        if (a.ranged) WAVE_SYNC();
+        if (ranged) WAVE_SYNC();
 
         // uniform read length of the tile (0: mixed) for the hit -> read mapping
         int ulen = 0;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 } else {
                     // (dual known-score configs: the survivors of pass 1 — barcodes numbered behind those of pass 0 — have their own
                     // four slots, in the candidate-word area, and their own count)
-                    const bool second = b >= a.B0;
+                    const bool second = GEN && b >= a.B0;
                     const int bl = second ? b - a.B0 : b;
                     const int ks = __hip_atomic_fetch_add(second ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // known-end class: barcode << 22 | d << 16 | 1-based end column (ascending order = the replay's order:
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                             const uint32_t e = ent[idx];
                             idx = e >> 16;
                             bool inwin = true;  // (ranged configs: the seed must lie inside the pass's column window)
-                            if (a.ranged) {
+                            if (ranged) {
                                 const bool second_b = (int)(e & 2047u) - 1 >= a.B0;
                                 inwin = p >= wwin[(second_b ? 2 : 0) * RW + t] && p + q <= wwin[(second_b ? 3 : 1) * RW + t];
                             }
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 lo = dmin - kk - 1;
                 hi = dmax + mm + kk + 1;
                 int wlo = 0, whi = n;
-                if (a.ranged) {
+                if (ranged) {
                     wlo = wwin[(b >= a.B0 ? 2 : 0) * RW + t];
                     whi = wwin[(b >= a.B0 ? 3 : 1) * RW + t];
                 }
@@ -973,12 +976,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         bool done = false;
         if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
             const int n = rlen(lane);
-            const int cnt = scnt[lane], cnt1 = a.dual ? wcl1[lane] : 0;
+            const int cnt = scnt[lane], cnt1 = dual ? wcl1[lane] : 0;
             // known-score class per read: this kernel only runs for configs whose ranges resolve to
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
             const bool simple = a.out.pass_start == nullptr && a.out.pass_end == nullptr && a.out.pass_raw == nullptr && a.out.pass_bc == nullptr &&
                                 a.out.pass_score == nullptr && a.out.pass_delta == nullptr;  // (kernel-uniform: only the verdict vectors are wanted)
-            if (simple && !a.dual && !flag[lane] && cnt <= 1 && n >= 1) {
+            if (simple && !dual && !flag[lane] && cnt <= 1 && n >= 1) {
                 // No or one survivor and nobody asked for scores: the reducers' answer for a lone survivor with distance d is a
                 // per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
                 // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
@@ -1007,12 +1010,12 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const LDS uint32_t *e0 = slots + lane * 4;
                 const LDS uint32_t *e1 = cand + lane * 4;  // (dual only)
                 const KnownPass kn0{true, e0[0], e0[1], e0[2], e0[3], cnt, nullptr, nullptr, nullptr, 0};
-                const KnownPass kn1 = a.dual ? KnownPass{true, e1[0], e1[1], e1[2], e1[3], cnt1, nullptr, nullptr, nullptr, 0}
+                const KnownPass kn1 = dual ? KnownPass{true, e1[0], e1[1], e1[2], e1[3], cnt1, nullptr, nullptr, nullptr, 0}
                                              : KnownPass{false, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
                 const auto m0 = [&](const int bb) { return (int)(meta[bb] & 255u); };
                 const auto m1 = [&](const int bb) { return (int)(meta[a.B0 + bb] & 255u); };
                 BdxDevCfg cfg;  // (only the fields the replay reads)
-                cfg.is_dual = a.dual;
+                cfg.is_dual = dual ? 1 : 0;
                 cfg.max_error_rate = a.max_error_rate;
                 cfg.min_delta = a.min_delta;
                 cfg.pass[0].trim_side = KEND ? 5 : 0;
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         return a.out.pass_delta == nullptr && (slo - po.score) >= a.min_delta && po.status == 1;
                     };
                     bool ok = settled(p1, cnt, a.tier_slo);
-                    if (ok && a.dual && p1.status == 1) ok = settled(p2, cnt1, a.tier_slo1);
+                    if (ok && dual && p1.status == 1) ok = settled(p2, cnt1, a.tier_slo1);
                     done = ok;
                 }
             }
@@ -1109,17 +1112,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false, bool GEN = true>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1174,6 +1177,9 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 
 }  // namespace
 
+// (the argument block crosses translation units as bytes: WaveArgs is this file's, compiled into each of them)
+hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+
 #if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
@@ -1217,8 +1223,11 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     if (blocks < 1) blocks = 1;
     const int tf = wp.track_from;
     // instantiated: seeds of 8 bases with every score-tracking start, 7 and 6 bases with the plain ones
+    // (known-score dual configs and configs with a ref_search_range take the general form of the non-split kernel: it is
+    // instantiated in bdx_wave_end.hip)
+    if (!wp.split && (a.dual || a.ranged)) return bdx_launch_wave_gen(&a, wp, lds, blocks, stream);
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV)                                                              \
-    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0>(a, lds, wp.waves, blocks, stream))
+    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream))
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1308,6 +1317,31 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
     if (blocks < 1) blocks = 1;
     const int tf = wp.track_from;
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
+    switch (wp.rw) {
+        case 32:
+            BDX_WAVE_TF(32);
+        case 16:
+            BDX_WAVE_TF(16);
+        case 8:
+            BDX_WAVE_TF(8);
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
+}
+
+// The general form of the non-split kernel (dual configs, ref_search_range windows) for bdx_launch_wave.
+hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    const int tf = wp.track_from;
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, true>(a, lds, wp.waves, blocks, stream)
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
