@@ -1179,6 +1179,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 
 // (the argument block crosses translation units as bytes: WaveArgs is this file's, compiled into each of them)
 hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 
 #if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
@@ -1226,8 +1227,9 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     // (known-score dual configs and configs with a ref_search_range take the general form of the non-split kernel: it is
     // instantiated in bdx_wave_end.hip)
     if (!wp.split && (a.dual || a.ranged)) return bdx_launch_wave_gen(&a, wp, lds, blocks, stream);
+    if (wp.split && a.ranged) return bdx_launch_wave_split_gen(&a, wp, lds, blocks, stream);  // (bdx_pairs.hip)
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV)                                                              \
-    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream))
+    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream))
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1291,6 +1293,31 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 #undef BDX_PAIRS_KB
 #undef BDX_PAIRS_NW
 #undef BDX_PAIRS_SP
+}
+
+// The split-mode kernel with per-read column windows (ref_search_range), for bdx_launch_wave.
+hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    const int tf = wp.track_from;
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
+    switch (wp.rw) {
+        case 32:
+            BDX_WAVE_TF(32);
+        case 16:
+            BDX_WAVE_TF(16);
+        case 8:
+            BDX_WAVE_TF(8);
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
 }
 
 #else  // BDX_WAVE_TU_KEND: the known-end instantiations (bdx_wave_end.hip)
