@@ -981,25 +981,44 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
             const bool simple = a.out.pass_start == nullptr && a.out.pass_end == nullptr && a.out.pass_raw == nullptr && a.out.pass_bc == nullptr &&
                                 a.out.pass_score == nullptr && a.out.pass_delta == nullptr;  // (kernel-uniform: only the verdict vectors are wanted)
-            if (simple && !dual && !flag[lane] && cnt <= 1 && n >= 1) {
-                // No or one survivor and nobody asked for scores: the reducers' answer for a lone survivor with distance d is a
-                // per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
+            if (simple && !flag[lane] && cnt <= 1 && cnt1 <= 1 && n >= 1) {
+                // No or one survivor per pass and nobody asked for scores: the reducers' answer for a lone survivor with distance d
+                // is a per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
                 // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
-                // IEEE operations (build_wave_tables); likewise tier 1's settle rule.  No Float64 here.
+                // IEEE operations (build_wave_tables); likewise tier 1's settle rule.  No Float64 here.  Dual configs: pass 2 runs
+                // only behind a matched pass 1, and a pass 2 without a match makes the read unknown (:887-895).
                 done = true;
                 int end1 = 0;  // known-end class: 1-based end column of the survivor's alignment
+                const int sbit = a.min_delta == 0.0 ? 0 : 16;
+                bool settled_all = true;
                 if (cnt == 1) {
                     const uint32_t e = slots[lane * 4];
                     const int bb = KEND ? (int)(e >> 22) : (int)(e >> 8), d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u);
                     end1 = (int)(e & 0xFFFFu);
                     const int dmax = (int)((meta[bb] >> 16) & 255u);
                     vd.bc1 = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
-                    if (a.tier) done = vd.bc1 > 0 && ((settle[bb] >> (d + (a.min_delta == 0.0 ? 0 : 16))) & 1u) != 0u;
+                    settled_all = vd.bc1 > 0 && ((settle[bb] >> (d + sbit)) & 1u) != 0u;
                 } else {
                     vd.bc1 = 0;
-                    if (a.tier) done = false;  // (nothing within the capped budgets: tier 0 decides)
+                    settled_all = false;  // (nothing within the capped budgets: tier 0 decides)
                 }
                 vd.bc2 = 0;
+                if (dual && vd.bc1 > 0) {
+                    int bc2v = 0;
+                    bool s2 = false;
+                    if (cnt1 == 1) {
+                        const uint32_t e = cand[lane * 4];
+                        const int bb = (int)(e >> 8), d = (int)(e & 255u), g = a.B0 + bb;
+                        const int dmax = (int)((meta[g] >> 16) & 255u);
+                        bc2v = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
+                        s2 = bc2v > 0 && ((settle[g] >> (d + sbit)) & 1u) != 0u;
+                    }
+                    settled_all = settled_all && s2;
+                    vd.bc2 = bc2v;
+                    if (bc2v == 0) vd.bc1 = 0;  // (:891-894: the verdict is pass 2's status)
+                    if (bc2v == 0) vd.bc2 = 0;
+                }
+                if (a.tier) done = settled_all;
                 vd.keep_start = vd.bc1 > 0 ? 1 : -1;  // :907-908 / :879-883 (ScoreOnly: the whole read, n >= 1)
                 vd.keep_end = vd.bc1 > 0 ? n : -1;
                 if (KEND && vd.bc1 > 0) {  // trim_side = 5: keep what follows the alignment's end (:912-914), (1, 0) if nothing does (:932-935)
