@@ -961,12 +961,23 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.d_settle = (const uint32_t *)(base + o_settle);
     ctx->pair_mmin = mmin;
     wp.enabled = 1;
+    // known-end class (see build_wave_tables): the listed reads of a trim_side = 5 config get verdict and keep range from the
+    // pairs mode too, in its non-split form
+    F.pplan_k = BdxWavePlan{};
+    if (split && !c.is_dual && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && c.pass[0].trim_side == 5 &&
+        !c.need_traceback && !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1) {
+        F.pplan_k = wp;
+        F.pplan_k.split = 0;
+        F.pplan_k.cand_words = 0;
+        F.pplan_k.kend = 1;
+    }
     return BDX_OK;
 }
 
 // Geometry of the pairs mode for a batch: 16-read tiles of slots of `read_len` rounded up to 16 bytes.
-bool size_pairs(bdx_ctx *ctx, int read_len) {
-    BdxWavePlan &wp = ctx->fs[0].pplan;
+bool size_pairs(bdx_ctx *ctx, BdxWavePlan &wp, int read_len);
+bool size_pairs(bdx_ctx *ctx, int read_len) { return size_pairs(ctx, ctx->fs[0].pplan, read_len); }
+bool size_pairs(bdx_ctx *ctx, BdxWavePlan &wp, int read_len) {
     if (!wp.enabled || ctx->dev.vlen) return false;
     if (read_len < 1) read_len = 1;
     const int slot = (read_len + 15) & ~15;
@@ -2217,7 +2228,32 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // filtered at the full budgets by the two-intact-pieces lemma.  Known-score configs: it answers them (what it cannot
         // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the
         // listed reads for the exact kernel).
-        bool pairs = false;
+        bool pairs = false, pairs_k = false;
+        if (tiered && split && windows && !dense_w && npass == 1 && o.pass_start == nullptr && stp == nullptr && !ctx->dev.vlen &&
+            size_pairs(ctx, ctx->fs[0].pplan_k, tier_len)) {
+            // known-end class: the pairs mode answers the listed reads itself (verdict + trimmed keep range); what it cannot
+            // answer goes on to the split path in list mode
+            const BdxWavePlan &pp = ctx->fs[0].pplan_k;
+            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
+            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
+            HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            if (ctx->tune.poison) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
+            }
+            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, t0.in_list, t0.in_count, n_reads, (uint8_t *)ctx->d_gseq.p,
+                                           (int *)ctx->d_glen.p, pp.slot, tier_len, ctx->n_cu, ctx->stream));
+            uint32_t *list2 = (uint32_t *)ctx->d_wlist.p;
+            unsigned int *count2 = (unsigned int *)(scratch + 320);
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, t0.in_list,
+                                          t0.in_count, o, ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, nullptr));
+            ctx->pair_launches += 1;
+            pairs = pairs_k = true;
+            t0.in_list = list2;
+            t0.in_count = count2;
+            HIP_TRY(ctx, poison_check(list2, count2, true, false));
+        } else
         if (tiered && (!split || windows) && !dense_w && size_pairs(ctx, tier_len)) {
             const BdxWavePlan &pp = ctx->fs[0].pplan;
             HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
@@ -2246,7 +2282,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
         ctx->F().bplan.dbg = ctx->tune.debug;
-        if (pairs && split) {
+        if (pairs && split && !pairs_k) {
             // (tier 0's filter already ran: the pairs mode wrote the listed reads' masks and windows)
         } else if (wsplit0) {
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -2283,7 +2319,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         if (wsplit0) ctx->path = "wave+verify";
-        if (pairs) ctx->path = split ? "pairs+verify" : "pairs > " + ctx->path;
+        if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
         if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = "wave > " + ctx->path;
         if (wave0k) ctx->path = "wave(end) > " + ctx->path;

@@ -75,6 +75,7 @@ struct BdxFilterSet {
     BdxWavePlan wplan_k{};  // known-end class (ScoreOnly conditions + trim_side = 5): the same tables, the non-split kernel with end columns
     BdxWavePlan pplan{};   // the same kernel in pairs mode (bdx_pairs.hip) at this set's full budgets, over listed reads
     DevBuf pair_tables;
+    BdxWavePlan pplan_k{};  // ... in its known-end form (trim_side = 5 configs)
 };
 
 struct bdx_ctx {

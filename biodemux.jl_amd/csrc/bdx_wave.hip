@@ -1298,13 +1298,15 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     const long long blocks = wp.blocks < 1 ? 1 : wp.blocks;
     const int tf = wp.track_from;
 #define BDX_PAIRS_SP(RWV, TFV, NVV, KBV, NWV)                                                                                  \
-    (wp.split ? launch_wave<RWV, TFV, NVV, 4, true, KBV, NWV>(a, lds, wp.waves, blocks, stream)                                \
-              : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
+    (wp.split  ? launch_wave<RWV, TFV, NVV, 4, true, KBV, NWV>(a, lds, wp.waves, blocks, stream)                               \
+     : wp.kend ? launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV, false, true>(a, lds, wp.waves, blocks, stream)                 \
+               : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
 #define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.groups > 1 ? launch_wave<RWV, TFV, NVV, 4, false, KBV, 4, true>(a, lds, wp.waves, blocks, stream) : wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
 #define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
 #define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
-    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split))) return hipErrorInvalidValue;
+    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
+    if (wp.kend && out.pass_start != nullptr) return hipErrorInvalidValue;
     if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
     if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
     return hipErrorInvalidValue;
