@@ -48,6 +48,7 @@ struct BdxTuning {
     int no_dense = 0;     // BDX_NO_DENSE: plain-sweep kernels keep the 4-entry slots / window entries also for short barcodes
     int no_band = 0;      // BDX_NO_BAND: the exact kernel never takes the diagonal-band DP
     int poison = 0;       // BDX_POISON: every hand-over buffer is filled with 0xA5 before each classify call (tests: a consumer that reads what no producer wrote gets garbage on every run, not only when the allocator happens to hand back dirty memory)
+    int tier0_div = 0;    // BDX_TIER0_DIV: tier 0's list is planned for n_reads / this many reads (default 16; 1: the whole batch)
     int no_kend = 0;      // BDX_NO_KEND: trim_side = 5 configs never take the known-end form of the wave kernel (filter + exact kernel instead)
     int no_pairs = 0;     // BDX_NO_PAIRS: never the pairs-mode kernel (bdx_pairs.hip) between tier 1 and the general kernel
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
