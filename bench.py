@@ -40,7 +40,8 @@ def _parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=["C2", "C2d", "C4", "C5"])
+    ap.add_argument("--config", default="C2", choices=["C2", "C2d", "C4", "C5", "C2t5", "C2r60", "C2dual"],
+                    help="BASELINE configs C2 (headline) / C2d / C4 / C5; C2t5, C2r60, C2dual: common variants of the headline shape (developer legs)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the config's size)")
     ap.add_argument("--filter", default="auto", help="auto|off|qgram|bitpar (all give identical results)")
     ap.add_argument("--max-error-rate", type=float, default=None, help="override the config's rate")

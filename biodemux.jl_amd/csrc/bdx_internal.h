@@ -192,6 +192,7 @@ struct BdxWavePlan {
     int read_len_hint;     // the read length the geometry was planned for
     int hq_cap, sq_cap;    // entries of a tile's hit queue / sweep list (from the expected chance hits per read)
     int cand_words;        // split mode: candidate mask words per read (both passes)
+    int scan_gpr;          // ranged single-pass configs (per batch): groups of sixteen positions scanned per read, 0: the whole flat image
     int ranged;            // some pass has a ref_search_range other than the whole read: per-read column windows in the kernel
     int kend;              // known-end class: the non-split kernel with end columns (bdx_wave_end.hip)
     double chance;         // expected chance seed hits per 150-base read (config)

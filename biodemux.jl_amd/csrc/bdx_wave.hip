@@ -77,6 +77,7 @@ struct WaveArgs {
     int cpr_inv;             // ceil(2^16 / cpr)
     int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
     int ngroups;             // pairs mode: groups of 128 barcodes (one set of piece tables each)
+    int scan_gpr, scan_gpr_inv;  // ranged single-pass configs: groups of sixteen positions scanned per read (0: the flat image) and ceil(2^16 / it)
     int cand_area;           // words per read of the area behind the sweep list (candidate masks / survivors of pass 1)
     int ranged;              // some pass has a ref_search_range: per read the column window [first, last] of each pass (classification.jl:795-807)
     BdxDevPass dpass[2];     // the passes' ranges (ranged only)
@@ -726,11 +727,36 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             constexpr uint32_t KMASK = (1u << (2 * Q)) - 1u;
             uint32_t amask = AMASK;
             asm volatile("" : "+v"(amask));  // (in a vector register: a literal or scalar operand slows the AND down)
-            for (int g0i = 0; g0i < (BDX_DBG(8) ? 0 : nvec); g0i += 64) {
-                const int g = g0i + lane;
+            // ranged single-pass configs whose window is much shorter than the read (ref_search_range = "1:60"): only the groups
+            // of sixteen positions that overlap each read's window are scanned — lane = (read, group of its window) instead of
+            // lane = group of the flat image.  A tile with a window longer than planned (a read beyond the length hint) takes
+            // the flat scan.
+            int gpr = (GEN && ranged && !dual) ? a.scan_gpr : 0;
+            if (gpr > 0) {
+                bool over = false;
+                if (lane < nr) {
+                    const int s0 = fb[lane] + wwin[lane], s1 = fb[lane] + wwin[RW + lane] - Q;  // first / last flat seed start of the window
+                    over = s1 >= s0 && (s1 >> 4) - (s0 >> 4) + 1 > gpr;
+                }
+                if (__builtin_amdgcn_ballot_w64(over)) gpr = 0;
+            }
+            const int nscan = BDX_DBG(8) ? 0 : (gpr > 0 ? nr * gpr : nvec);
+            for (int g0i = 0; g0i < nscan; g0i += 64) {
+                int g = g0i + lane;
+                bool ong = g < nscan;
+                uint32_t keep = 0xFFFFu;  // positions of the group that are this lane's to report
+                if (gpr > 0) {
+                    const int i = g0i + lane;
+                    const int t = ong ? (int)(((uint32_t)i * (uint32_t)a.scan_gpr_inv) >> 16) : 0;
+                    const int s0 = fb[t] + wwin[t], f1 = fb[t + 1];
+                    g = (s0 >> 4) + (i - t * gpr);
+                    const int below = s0 - 16 * g, above = f1 - 16 * g;  // bits < below lie in front of the window, bits >= above in the next read
+                    ong = ong && above > 0 && g < nvec;
+                    keep = (below > 0 ? (0xFFFFu << (below > 16 ? 16 : below)) : 0xFFFFu) & (above < 16 ? ((1u << (above < 0 ? 0 : above)) - 1u) : 0xFFFFu) & 0xFFFFu;
+                }
                 uint32_t hits = 0;
                 uint32_t w0 = 0, w1 = 0;
-                if (g < nvec) {
+                if (ong) {
                     w0 = img2[g];
                     w1 = img2[g + 1];
                     const uint32_t wm = __builtin_amdgcn_alignbit(w1, w0, 16);  // bases 8 .. 23 of the group's window
@@ -748,6 +774,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         for (int i = 0; i < 8; ++i) hits = __builtin_amdgcn_alignbit(word[i] >> (Wk[8 * h + i] & 31u), hits, 1);
                     }
                     hits >>= 16;
+                    hits &= keep;
                 }
                 // append: one trip per "layer" of hits (the lowest remaining hit of every lane that has one)
                 unsigned long long mk = __builtin_amdgcn_ballot_w64(hits != 0u);
@@ -1181,6 +1208,8 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.sg = cfg.algorithm == BDX_ALG_SEMIGLOBAL ? 1 : 0;
     a.ngroups = wp.groups > 0 ? wp.groups : 1;
     a.cand_area = wp.cand_words;
+    a.scan_gpr = wp.scan_gpr;
+    a.scan_gpr_inv = wp.scan_gpr > 0 ? (65536 + wp.scan_gpr - 1) / wp.scan_gpr : 0;
     a.ranged = wp.ranged;
     a.dpass[0] = cfg.pass[0];
     a.dpass[1] = cfg.pass[1];
