@@ -456,6 +456,7 @@ def test_wave_dual_many_survivors_and_mixed_lengths(monkeypatch):
     ("1:60", dict(max_error_rate=0.2)), ("1:40", dict(max_error_rate=0.2, min_delta=0.05)),     # tiers + pairs mode on windows
     ("1:60", dict(trim_side=5)), ("end-70:end", dict(trim_side=5, max_error_rate=0.2)),            # known-end class
     ("1:60", dict(trim_side=3)), ("10:100", dict(trim_side=3, summary=True, max_error_rate=0.2)),  # split mode
+    ("1:end-60", dict()), ("end-40:end-10", dict(trim_side=5)), ("1:70", dict(min_delta=0.03, max_error_rate=0.13)),  # windows that depend on the read length; empty for short reads
 ], ids=lambda v: v if isinstance(v, str) else ",".join(f"{k}={x}" for k, x in v.items()) or "plain")
 def test_wave_ref_search_range(rng_s, kw, monkeypatch):
     bcs = synth.make_barcodes(96, 24, seed=121)
