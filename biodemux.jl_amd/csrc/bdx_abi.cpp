@@ -835,15 +835,20 @@ bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
     // ranged single-pass configs: the seed scan only walks the groups of sixteen positions that overlap a read's window when
     // the window (resolved at the planned read length, classification.jl:795-800) is much shorter than the read
     wp.scan_gpr = 0;
-    if (wp.ranged && !ctx->dev.is_dual) {
-        const BdxDevRange &dr = ctx->dev.pass[0].ref_search;
-        long long f = dr.start_from_end ? read_len + dr.start_offset : dr.start_offset;
-        long long l = dr.end_from_end ? read_len + dr.end_offset : dr.end_offset;
-        if (f < 1) f = 1;
-        if (l > read_len) l = read_len;
-        const long long wlen = l >= f ? l - f + 1 : 0;
-        const long long gpr = (wlen + 15) / 16 + 1;
-        if (gpr * 16 * 10 <= (long long)read_len * 7 && (long long)wp.rw * gpr < 2048) wp.scan_gpr = (int)gpr;
+    if (wp.ranged) {
+        const int npw = ctx->dev.is_dual ? 2 : 1;
+        long long gpr = 0;
+        for (int k = 0; k < npw; ++k) {
+            const BdxDevRange &dr = ctx->dev.pass[k].ref_search;
+            long long f = dr.start_from_end ? read_len + dr.start_offset : dr.start_offset;
+            long long l = dr.end_from_end ? read_len + dr.end_offset : dr.end_offset;
+            if (f < 1) f = 1;
+            if (l > read_len) l = read_len;
+            const long long wlen = l >= f ? l - f + 1 : 0;
+            const long long g = (wlen + 15) / 16 + 1;
+            if (g > gpr) gpr = g;
+        }
+        if (gpr * npw * 16 * 10 <= (long long)read_len * 7 && (long long)wp.rw * npw * gpr < 2048) wp.scan_gpr = (int)gpr;
     }
     return true;
 }

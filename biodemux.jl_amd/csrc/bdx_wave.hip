@@ -731,25 +731,39 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // of sixteen positions that overlap each read's window are scanned — lane = (read, group of its window) instead of
             // lane = group of the flat image.  A tile with a window longer than planned (a read beyond the length hint) takes
             // the flat scan.
-            int gpr = (GEN && ranged && !dual) ? a.scan_gpr : 0;
+            // (dual configs: the windows of both passes, one after the other; what the first one's lanes cover is not reported twice)
+            int gpr = (GEN && ranged) ? a.scan_gpr : 0;
+            const int npw = (GEN && a.B0 < B) ? 2 : 1;  // windows per read
             if (gpr > 0) {
                 bool over = false;
                 if (lane < nr) {
-                    const int s0 = fb[lane] + wwin[lane], s1 = fb[lane] + wwin[RW + lane] - Q;  // first / last flat seed start of the window
-                    over = s1 >= s0 && (s1 >> 4) - (s0 >> 4) + 1 > gpr;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        if (p < npw) {
+                            const int s0 = fb[lane] + wwin[(2 * p) * RW + lane], s1 = fb[lane] + wwin[(2 * p + 1) * RW + lane] - Q;  // first / last flat seed start of the window
+                            over = over || (s1 >= s0 && (s1 >> 4) - (s0 >> 4) + 1 > gpr);
+                        }
+                    }
                 }
                 if (__builtin_amdgcn_ballot_w64(over)) gpr = 0;
             }
-            const int nscan = BDX_DBG(8) ? 0 : (gpr > 0 ? nr * gpr : nvec);
+            const int nscan = BDX_DBG(8) ? 0 : (gpr > 0 ? nr * npw * gpr : nvec);
             for (int g0i = 0; g0i < nscan; g0i += 64) {
                 int g = g0i + lane;
                 bool ong = g < nscan;
                 uint32_t keep = 0xFFFFu;  // positions of the group that are this lane's to report
                 if (gpr > 0) {
                     const int i = g0i + lane;
-                    const int t = ong ? (int)(((uint32_t)i * (uint32_t)a.scan_gpr_inv) >> 16) : 0;
-                    const int s0 = fb[t] + wwin[t], f1 = fb[t + 1];
-                    g = (s0 >> 4) + (i - t * gpr);
+                    const int tw = ong ? (int)(((uint32_t)i * (uint32_t)a.scan_gpr_inv) >> 16) : 0;  // (read, window) number
+                    const int t = npw == 2 ? tw >> 1 : tw, which = npw == 2 ? tw & 1 : 0;
+                    int s0 = fb[t] + wwin[(2 * which) * RW + t];
+                    const int f1 = fb[t + 1];
+                    g = (s0 >> 4) + (i - tw * gpr);
+                    if (which) {  // positions the lanes of the read's first window report already
+                        const int c0 = (((fb[t] + wwin[t]) >> 4) + gpr) << 4;
+                        const int a0 = fb[t] + wwin[t];
+                        if (s0 >= a0 && s0 < c0) s0 = c0;
+                    }
                     const int below = s0 - 16 * g, above = f1 - 16 * g;  // bits < below lie in front of the window, bits >= above in the next read
                     ong = ong && above > 0 && g < nvec;
                     keep = (below > 0 ? (0xFFFFu << (below > 16 ? 16 : below)) : 0xFFFFu) & (above < 16 ? ((1u << (above < 0 ? 0 : above)) - 1u) : 0xFFFFu) & 0xFFFFu;

@@ -486,3 +486,18 @@ def test_wave_not_with_binding_start_or_end_ranges(monkeypatch):
     seq, off, _ = synth.make_reads(bcs, 10000, 150, seed=127)
     for kw in (dict(barcode_start_range=H.bdx.parse_dynamic_range("1:20")), dict(barcode_end_range=H.bdx.parse_dynamic_range("30:end"))):
         _both_kernels(_cfg(bcs, **kw), seq, off, monkeypatch, want_pass=False, expect_wave=False)
+
+
+def test_wave_ref_search_range_dual_long_reads(monkeypatch):
+    """300-base reads, a window at either end: the scan walks the two windows of every read only."""
+    b1 = synth.make_barcodes(24, 24, seed=131)
+    b2 = synth.make_barcodes(16, 24, seed=132)
+    seq, off, _ = synth.make_reads(b1, 20000, 300, seed=133, plant_lo=0, plant_hi=30, second=(b2, 245, 276), sub=0.03, ins=0.008, dele=0.008)
+    matched = []
+    for rs1, rs2, kw in (("1:60", "end-59:end", dict()), ("1:80", "end-80:end-5", dict(min_delta=0.04)), ("1:70", "end-69:end", dict(max_error_rate=0.2))):
+        cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                                bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=kw.pop("max_error_rate", 0.1),
+                                ref_search_range=H.bdx.parse_dynamic_range(rs1), ref_search_range2=H.bdx.parse_dynamic_range(rs2), **kw)
+        exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=False)
+        matched.append(float((exp["bc1"] > 0).mean()))
+    assert min(matched) > 0.3, matched
