@@ -501,3 +501,34 @@ def test_wave_ref_search_range_dual_long_reads(monkeypatch):
         exp = _both_kernels(cfg, seq, off, monkeypatch, want_pass=False)
         matched.append(float((exp["bc1"] > 0).mean()))
     assert min(matched) > 0.3, matched
+
+
+def test_known_end_with_per_pass_outputs_but_no_start_positions():
+    """The device entry point with pass_end / pass_score / pass_bc / pass_delta requested and pass_start not: still the
+    known-end class; the per-pass vectors equal the oracle's (the end is the reference's leftmost best end)."""
+    import torch
+
+    bcs = synth.make_barcodes(96, 24, seed=141)
+    seq, off, _ = synth.make_reads(bcs, 30000, 150, seed=142, sub=0.03, ins=0.01, dele=0.01, repeat=dict(frac=0.2))
+    n = len(off) - 1
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    for kw in (dict(trim_side=5), dict(trim_side=5, max_error_rate=0.2, min_delta=0.05)):
+        cfg = _cfg(bcs, **kw)
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=True).classify(seq, off)
+        out_i = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in ("bc1", "bc2", "keep_start", "keep_end")}
+        out_p = {k: torch.empty((n, 2), dtype=torch.int32, device=dev) for k in ("pass_end", "pass_bc")}
+        out_f = {k: torch.empty((n, 2), dtype=torch.float64, device=dev) for k in ("pass_score", "pass_delta")}
+        with H.bdx.HipClassifier(cfg) as hc:
+            hc.set_read_length_hint(150)
+            hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, **{k: v.data_ptr() for k, v in {**out_i, **out_p, **out_f}.items()})
+            hc.sync()
+            assert "wave(end)" in hc.kernel_path, hc.kernel_path
+        for k, v in {**out_i, **out_p}.items():
+            got = v.cpu().numpy()
+            assert np.array_equal(got, exp[k]), (kw, k, np.flatnonzero((got != exp[k]).reshape(n, -1).any(axis=1))[:5])
+        for k, v in out_f.items():
+            got = v.cpu().numpy()
+            same = (got == exp[k]) | (np.isnan(got) & np.isnan(exp[k]))
+            assert same.all(), (kw, k)
