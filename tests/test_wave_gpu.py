@@ -532,3 +532,18 @@ def test_known_end_with_per_pass_outputs_but_no_start_positions():
             got = v.cpu().numpy()
             same = (got == exp[k]) | (np.isnan(got) & np.isnan(exp[k]))
             assert same.all(), (kw, k)
+
+
+@pytest.mark.parametrize("div", ["1", "4", "64"])
+def test_tier0_planned_for_a_fraction_of_the_batch(div, monkeypatch):
+    """BDX_TIER0_DIV only changes the tile size tier 0's list launch is planned with (28-nt barcodes at rate 0.2: a budget of 5,
+    beyond the pairs mode — the general kernel is tier 0)."""
+    bcs = synth.make_barcodes(60, 28, seed=151)
+    seq, off, _ = synth.make_ragged_reads(bcs, 30000, 40, 150, seed=152, sub=0.05, ins=0.012, dele=0.012)
+    cfg = _cfg(bcs, max_error_rate=0.2)
+    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False).classify(seq, off)
+    monkeypatch.setenv("BDX_TIER0_DIV", div)
+    with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+        monkeypatch.delenv("BDX_TIER0_DIV")
+        fuzz.assert_same(hc.classify(seq, off), exp, f"div {div} [{hc.kernel_path}]")
+        assert hc.kernel_path.startswith("tier1:") and hc.pair_launches == 0, hc.kernel_path
