@@ -634,6 +634,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     struct Piece { int g, start; const uint8_t *bc; };
     std::vector<Piece> pieces;
     std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);  // (stride 9: bank spread, see the kernel)
+    std::vector<uint32_t> peq8r((size_t)Btot * 9, 0u);  // the reversed barcodes (known-trim class: trim_side = 3 passes are swept right to left)
     int track = 1 << 20, g = 0;
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
@@ -650,6 +651,11 @@ int build_wave_tables(bdx_ctx *ctx) {
                     for (int i = 0; i < m; ++i)
                         if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
                 peq8[(size_t)g * 9 + code] = mask;
+                uint32_t maskr = pad;
+                if (code < 4)
+                    for (int i = 0; i < m; ++i)
+                        if (((bc[m - 1 - i] >> 1) & 3) == code) maskr |= 1u << (shift + i);
+                peq8r[(size_t)g * 9 + code] = maskr;
             }
             const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);  // (normalisation = m)
             if (ae < 0) {  // can never be recorded: neither seeded nor swept (budget field 255)
@@ -752,7 +758,8 @@ int build_wave_tables(bdx_ctx *ctx) {
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_bm = 0, o_rank = al(bitmap.size()), o_ent = o_rank + al(rank.size() * 2), o_peq = o_ent + al(ent.size() * 4),
-                 o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4), bytes = o_settle + al(settle.size() * 4);
+                 o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4), o_peqr = o_settle + al(settle.size() * 4),
+                 bytes = o_peqr + al(peq8r.size() * 4);
     std::vector<uint8_t> blob(bytes, 0);
     memcpy(blob.data() + o_bm, bitmap.data(), bitmap.size());
     memcpy(blob.data() + o_rank, rank.data(), rank.size() * 2);
@@ -760,6 +767,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
     memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
     memcpy(blob.data() + o_settle, settle.data(), settle.size() * 4);
+    memcpy(blob.data() + o_peqr, peq8r.data(), peq8r.size() * 4);
     HIP_TRY(ctx, F.wave_tables.ensure(bytes));
     HIP_TRY(ctx, hipMemcpy(F.wave_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)F.wave_tables.p;
@@ -769,20 +777,26 @@ int build_wave_tables(bdx_ctx *ctx) {
     wp.d_peq8 = (const uint32_t *)(base + o_peq);
     wp.d_meta = (const uint32_t *)(base + o_meta);
     wp.d_settle = (const uint32_t *)(base + o_settle);
+    wp.d_peq8r = (const uint32_t *)(base + o_peqr);
     wp.enabled = 1;
-    // Known-end class: the known-score conditions with trim_side = 5 instead of none (single pass, no summary).  Only the
-    // alignment's END is observable then (keep_start = end + 1, classification.jl:912-914), and the reference keeps the
-    // leftmost end of the best score (:142-153: strict `<`): the sweep delivers it (bdx_wave.hip, KEND) — such a config
-    // gets its verdicts from the non-split kernel whenever the caller does not ask for start positions.
+    // Known-trim class: the known-score conditions with a trim side in some pass (either pass count, no summary).  What a trim
+    // side makes observable is one position per pass — trim_side = 5: the alignment's END (keep_start = end + 1,
+    // classification.jl:912-914; the reference keeps the leftmost end of the best score, :142-153: strict `<`); trim_side = 3: its
+    // START (keep_end = max(1, start) - 1, :910-911; the largest start among the alignments of the best score, :142-153 tie rule
+    // + :310-321 origin order) — and the sweep delivers both (bdx_wave.hip, KEND: the lowering mask of a left-to-right sweep /
+    // of a right-to-left sweep with the reversed barcode).  Such a config gets its verdicts from the non-split kernel whenever
+    // the caller does not ask for per-pass start positions (nor for end positions of a trim_side = 3 pass).
     F.wplan_k = BdxWavePlan{};
-    if (split && !c.is_dual && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && c.pass[0].trim_side == 5 &&
-        !c.need_traceback && c.pass[0].explicit_window != BDX_WINDOW_ALIGN_ONE && !ctx->tune.no_known && !ctx->tune.no_kend) {
-        bool fits = true;  // entry = barcode << 22 | d << 16 | end
+    bool trims_ok = true;
+    for (int k = 0; k < npass; ++k) trims_ok = trims_ok && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE;
+    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !c.need_traceback &&
+        !ctx->tune.no_known && !ctx->tune.no_kend) {
+        bool fits = true;  // entry = barcode << 22 | d << 16 | position key
         for (uint32_t x : meta) fits = fits && (((x >> 8) & 255u) == 255u || ((x >> 8) & 255u) < 64u);
-        if (fits && Btot <= 1023) {
+        if (fits && c.pass[0].n_barcodes <= 1023 && (!c.is_dual || c.pass[1].n_barcodes <= 1023)) {
             F.wplan_k = wp;
             F.wplan_k.split = 0;
-            F.wplan_k.cand_words = 0;
+            F.wplan_k.cand_words = c.is_dual ? 4 : 0;  // (the four survivor slots of pass 1)
             F.wplan_k.kend = 1;
         }
     }
@@ -901,7 +915,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     if (const char *e = getenv("BDX_PAIRS_NW")) nw = atoi(e) > nw ? atoi(e) : nw;  // (tuning experiment)
     if (nw > 4) nw = 4;
     const int estride = nw <= 2 ? 8 : 16;
-    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u);
+    std::vector<uint32_t> meta((size_t)Btot, 0u), peq8((size_t)Btot * 9, 0u), settle((size_t)Btot, 0u), peq8r((size_t)Btot * 9, 0u);
     int kmax = 0, track = 1 << 20, mmin = 1 << 20, g = 0;
     struct Bc { int g, m, kb; const uint8_t *bc; };
     std::vector<Bc> bcs;
@@ -920,6 +934,11 @@ int build_pair_tables(bdx_ctx *ctx) {
                     for (int i = 0; i < m; ++i)
                         if (((bc[i] >> 1) & 3) == code) mask |= 1u << (shift + i);
                 peq8[(size_t)g * 9 + code] = mask;
+                uint32_t maskr = pad;  // (the reversed barcode: known-trim class, see build_wave_tables)
+                if (code < 4)
+                    for (int i = 0; i < m; ++i)
+                        if (((bc[m - 1 - i] >> 1) & 3) == code) maskr |= 1u << (shift + i);
+                peq8r[(size_t)g * 9 + code] = maskr;
             }
             const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);
             if (ae < 0) {  // can never be recorded: in no table entry, never swept
@@ -963,12 +982,13 @@ int build_pair_tables(bdx_ctx *ctx) {
     if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 112 * 1024) return BDX_OK;  // (at least four waves' work areas must fit beside the tables)
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_tab = 0, o_peq = al(tab.size() * 4), o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4),
-                 bytes = o_settle + al(settle.size() * 4);
+                 o_peqr = o_settle + al(settle.size() * 4), bytes = o_peqr + al(peq8r.size() * 4);
     std::vector<uint8_t> blob(bytes, 0);
     memcpy(blob.data() + o_tab, tab.data(), tab.size() * 4);
     memcpy(blob.data() + o_peq, peq8.data(), peq8.size() * 4);
     memcpy(blob.data() + o_meta, meta.data(), meta.size() * 4);
     memcpy(blob.data() + o_settle, settle.data(), settle.size() * 4);
+    memcpy(blob.data() + o_peqr, peq8r.data(), peq8r.size() * 4);
     HIP_TRY(ctx, F.pair_tables.ensure(bytes));
     HIP_TRY(ctx, hipMemcpy(F.pair_tables.p, blob.data(), bytes, hipMemcpyHostToDevice));
     const uint8_t *base = (const uint8_t *)F.pair_tables.p;
@@ -978,16 +998,19 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.d_peq8 = (const uint32_t *)(base + o_peq);
     wp.d_meta = (const uint32_t *)(base + o_meta);
     wp.d_settle = (const uint32_t *)(base + o_settle);
+    wp.d_peq8r = (const uint32_t *)(base + o_peqr);
     ctx->pair_mmin = mmin;
     wp.enabled = 1;
-    // known-end class (see build_wave_tables): the listed reads of a trim_side = 5 config get verdict and keep range from the
-    // pairs mode too, in its non-split form
+    // known-trim class (see build_wave_tables): the listed reads of a config with trim sides get verdict and keep range from
+    // the pairs mode too, in its non-split form
     F.pplan_k = BdxWavePlan{};
-    if (split && !c.is_dual && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && c.pass[0].trim_side == 5 &&
-        !c.need_traceback && !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1) {
+    bool trims_ok = true;
+    for (int k = 0; k < npass; ++k) trims_ok = trims_ok && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE;
+    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !c.need_traceback &&
+        !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1) {
         F.pplan_k = wp;
         F.pplan_k.split = 0;
-        F.pplan_k.cand_words = 0;
+        F.pplan_k.cand_words = c.is_dual ? 4 : 0;
         F.pplan_k.kend = 1;
     }
     return BDX_OK;
@@ -2164,7 +2187,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // known-end form answers the reads it can settle, trimmed keep range included; the listed rest goes through the
         // split path (filter in list mode -> exact kernel in list mode).
         bool wave1k = false, wave0k = false;
-        if (split && windows && !ctx->dev.vlen && !dense_w && npass == 1 && o.pass_start == nullptr && stp == nullptr) {
+        bool trim3 = false;  // (a trim_side = 3 pass of the known-trim class knows its start only)
+        for (int k = 0; k < npass; ++k) trim3 |= ctx->dev.pass[k].trim_side == 3;
+        const bool kend_ok = split && windows && !ctx->dev.vlen && !dense_w && o.pass_start == nullptr && stp == nullptr && !(trim3 && o.pass_end != nullptr);
+        if (kend_ok) {
             if (tiered)
                 wave1k = size_wave(ctx, ctx->fs[1].wplan_k, batch_len, n_reads);
             else if (size_wave(ctx, ctx->fs[0].wplan_k, batch_len, n_reads)) {
@@ -2218,7 +2244,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.dbg = ctx->tune.debug;
             if (wave1k) {  // tier 1 as the known-end form of the wave kernel: verdicts + trimmed keep range of what it settles, the rest listed
                 HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, f1.wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
+                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug, f1.bplan.tier_slo[1]));
                 ctx->wave_launches += 1;
             } else if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -2253,8 +2279,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the
         // listed reads for the exact kernel).
         bool pairs = false, pairs_k = false;
-        if (tiered && split && windows && !dense_w && npass == 1 && o.pass_start == nullptr && stp == nullptr && !ctx->dev.vlen &&
-            size_pairs(ctx, ctx->fs[0].pplan_k, tier_len)) {
+        if (tiered && kend_ok && size_pairs(ctx, ctx->fs[0].pplan_k, tier_len)) {
             // known-end class: the pairs mode answers the listed reads itself (verdict + trimmed keep range); what it cannot
             // answer goes on to the split path in list mode
             const BdxWavePlan &pp = ctx->fs[0].pplan_k;

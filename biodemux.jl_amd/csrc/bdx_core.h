@@ -1081,8 +1081,10 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
 // several entries of one barcode; each is the minimum over its window, the window holding the best
 // occurrence delivers the whole-window minimum d*, so the barcode's value is the SMALLEST of its
 // entries.  Ascending (barcode << 8 | d) order visits that one first; the others are skipped.
-// KEND (known-end class, bdx_wave.hip): entries are barcode << 22 | d << 16 | 1-based end column — the same ascending order,
-// with the leftmost end first among equal distances of a barcode; the winner's end goes through the reducer.
+// KEND (known-trim class, bdx_wave.hip): entries are barcode << 22 | d << 16 | position key — the same ascending order; the key
+// is the 1-based end column for a trim_side = 5 pass (the leftmost end first among equal distances of a barcode), 0xFFFF - start
+// for a trim_side = 3 pass (the largest start first); the winner's key goes through the reducer in AlignOut::end and
+// classify_known turns it into the pass's start or end.
 template <bool KEND = false, class MLen>
 __device__ __forceinline__ PassOut run_pass_known(const BdxDevCfg &cfg, const MLen mlen,
                                                   const uint32_t e0, const uint32_t e1, const uint32_t e2,
@@ -1246,7 +1248,19 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
 // determine_filename (classification.jl:871-938) for a read whose passes all sit in the known-score
 // class: both passes are reducer replays, nothing is aligned, nothing is trimmed (ScoreOnly configs
 // have no trim side; the keep range is the whole read as in :907-908, :932-935).
-// KEND: single pass of the known-end class (trim_side = 5): the keep range starts behind the winner's end (:912-914).
+// KEND: the known-trim class — the passes' entries carry position keys (run_pass_known): the winner's start (trim_side = 3) or end
+// (trim_side = 5) trims the keep range as in :910-929.
+template <bool KEND>
+__device__ __forceinline__ void known_positions(PassOut &po, const int trim_side) {
+    if (!KEND) return;
+    const int key = po.end;  // (-1: no winner)
+    po.start = -1;
+    po.end = -1;
+    if (key < 0) return;
+    if (trim_side == 3) po.start = 0xFFFF - key;
+    if (trim_side == 5) po.end = key;
+}
+
 template <bool KEND = false, class MLen0, class MLen1>
 __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0 m0, const MLen1 m1, const int n,
                                                const KnownPass kn0, const KnownPass kn1, Verdict &v, PassOut &p1,
@@ -1256,6 +1270,7 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
     p1 = kn0.dt ? run_pass_known_dense(cfg, m0, kn0.dt, kn0.cbits, kn0.cwords)
          : kn0.ent ? run_pass_known_ent(cfg, m0, kn0.ent, kn0.count)
                    : run_pass_known<KEND>(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
+    known_positions<KEND>(p1, cfg.pass[0].trim_side);
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
@@ -1263,7 +1278,8 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.dt ? run_pass_known_dense(cfg, m1, kn1.dt, kn1.cbits, kn1.cwords)
              : kn1.ent ? run_pass_known_ent(cfg, m1, kn1.ent, kn1.count)
-                       : run_pass_known(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
+                       : run_pass_known<KEND>(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
+        known_positions<KEND>(p2, cfg.pass[1].trim_side);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;
@@ -1271,13 +1287,29 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
         v.bc2 = p2.bc;
     }
     v.bc1 = p1.bc;
-    const int keep_start = KEND ? p1.end + 1 : 1;  // :912-914 (trim_side = 5) / :907
-    if (keep_start > n) {  // :932-935 (keep_start > keep_end = n)
+    int keep_start = 1, keep_end = n;  // :907-908
+    if (KEND) {
+        const int ts1 = cfg.pass[0].trim_side, ts2 = cfg.pass[1].trim_side;
+        if (ts1 == 3)  // :910-919
+            keep_end = (p1.start > 1 ? p1.start : 1) - 1;
+        else if (ts1 == 5)
+            keep_start = p1.end + 1;
+        if (cfg.is_dual) {  // :921-929
+            if (ts2 == 3) {
+                const int e2 = (p2.start > 1 ? p2.start : 1) - 1;
+                keep_end = keep_end < e2 ? keep_end : e2;
+            } else if (ts2 == 5) {
+                const int s2 = p2.end + 1;
+                keep_start = keep_start > s2 ? keep_start : s2;
+            }
+        }
+    }
+    if (keep_start > keep_end) {  // :932-935
         v.keep_start = 1;
         v.keep_end = 0;
     } else {
         v.keep_start = keep_start;
-        v.keep_end = n;
+        v.keep_end = keep_end;
     }
 }
 

@@ -182,6 +182,7 @@ struct BdxWavePlan {
     const uint16_t *d_rank;      // [bm_bytes / 4]: keys present below each 32-bit word of the bitmap
     const uint32_t *d_ent;       // barcode + 1 | piece start << 11 | next entry of the same key << 16
     const uint32_t *d_peq8;      // [B][9] (stride 9 dwords): rows A, C, T, G ((byte >> 1) & 3), 4..7 = symbols no barcode contains
+    const uint32_t *d_peq8r;     // the same for the reversed barcodes (known-trim class: trim_side = 3 passes are swept right to left)
     const uint32_t *d_meta;      // [B]: m | kb << 8 | lone-survivor accept threshold << 16
     const uint32_t *d_settle;    // [B]: tier 1 settle bits of a lone survivor per distance (no_delta | with_delta << 16)
     // per batch (size_wave)
@@ -194,7 +195,7 @@ struct BdxWavePlan {
     int cand_words;        // split mode: candidate mask words per read (both passes)
     int scan_gpr;          // ranged single-pass configs (per batch): groups of sixteen positions scanned per read, 0: the whole flat image
     int ranged;            // some pass has a ref_search_range other than the whole read: per-read column windows in the kernel
-    int kend;              // known-end class: the non-split kernel with end columns (bdx_wave_end.hip)
+    int kend;              // known-trim class (any trim side per pass, no per-pass start positions wanted): the non-split kernel with position keys (bdx_wave_end.hip)
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
     // tables [kb + 2][256] of barcode masks, there is no hash
@@ -242,7 +243,7 @@ size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_
 // Implemented in bdx_wave_end.hip (the known-end instantiations of the same kernel).
 hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
-                               unsigned int *list_count, hipStream_t stream, int dbg = 0);
+                               unsigned int *list_count, hipStream_t stream, int dbg = 0, double tier_slo1 = 0.0);
 // Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
                             const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,

@@ -49,6 +49,8 @@ struct WaveArgs {
     const uint32_t *ent;     // [n_ent]: barcode + 1 | piece start << 11 | next entry with the same key << 16 (0: none); entry i < keys present belongs to the i-th key
     int n_ent;
     const uint32_t *peq8;    // [B][9]: sweep word of barcode b for symbol code c (4..7: "other"; the ninth word pads the stride)
+    const uint32_t *peq8r;   // [B][9]: the same for the REVERSED barcode (known-trim class: the sweeps of trim_side = 3 passes run right to left)
+    int trim0, trim1;        // known-trim class: the passes' trim sides (0 / 3 / 5)
     const uint32_t *meta;    // [B]: m | kb << 8 | (largest distance the reducer accepts for a lone survivor, 255: none) << 16
     const uint32_t *settle;  // [B]: tier 1, lone survivor: bit d = a read whose only survivor has distance d is settled (no_delta: low half, with_delta: high half)
     int B;
@@ -144,9 +146,10 @@ __device__ __forceinline__ void pack16(const u32x4 v, uint32_t &p2, uint32_t &nl
 // One column of Myers' recurrence on a top-aligned pattern (bdx_bitpar.hip `step`); TRACK: the horizontal delta
 // of the barcode's last row is the carry-out of the shift and updates the score.
 template <bool TRACK>
-__device__ __forceinline__ void sweep_step(const uint32_t Eq, uint32_t &Pv, uint32_t &Mv, int &score, int &best) {
+__device__ __forceinline__ uint32_t sweep_step(const uint32_t Eq, uint32_t &Pv, uint32_t &Mv, int &score, int &best) {
     const uint32_t Xv = Eq | Mv;
-    const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    const uint32_t ep = Eq & Pv;  // (returned: its top bit is the known-start class's "the diagonal move into the last row is optimal")
+    const uint32_t Xh = ((ep + Pv) ^ Pv) | Eq;
     uint32_t Ph = Mv | ~(Xh | Pv);
     uint32_t Mh = Pv & Xh;
     if (TRACK) {
@@ -162,6 +165,7 @@ __device__ __forceinline__ void sweep_step(const uint32_t Eq, uint32_t &Pv, uint
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
     if (TRACK) best = score < best ? score : best;
+    return ep;
 }
 
 // 32 columns of one sweep; columns [0, TF) cannot end an alignment within any barcode's budget (the score after
@@ -186,11 +190,14 @@ __device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
 // block (kk1 = budget + 1: the sign bit of score - kk1 is shifted in).
 // TRACKW = 2 (known-end class): bit 31 - j instead says "column j lowered the running minimum" — the last such column of a
 // sweep is the FIRST column that attains its minimum (the reference keeps the leftmost end of the best score,
-// classification.jl:142-153 with trim_side = 5: strict `<`).
+// classification.jl:142-153 with trim_side = 5: strict `<`).  `inm2` (same bit numbering) then notes, per column, the top
+// bit of Eq & Pv BEFORE the step: "the barcode's last row matches this column and its vertical delta was +1", i.e. the
+// diagonal move into the last row attains the column's value (needed by the reversed sweeps of trim_side = 3 passes, see
+// sweep_lane: there the last row is the barcode's FIRST base).
 template <int TF, int TRACKW>
 __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3,
                                             const uint32_t pbase, uint32_t &Pv, uint32_t &Mv, int &score, int &best, const int kk1,
-                                            uint32_t &inm, const int ngr) {
+                                            uint32_t &inm, uint32_t &inm2, const int ngr) {
     const uint32_t A[4] = {A0, A1, A2, A3};
     uint32_t Eq[2][8];
     const auto issue = [&](const int h) __attribute__((always_inline)) {
@@ -201,6 +208,7 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
     };
     issue(0);
     inm = 0u;
+    inm2 = 0u;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {  // the Eq words of the next eight columns fly while these eight are worked on
         if (h >= ngr) break;       // (wave-uniform: no lane has a column in the remaining groups of eight)
@@ -214,13 +222,15 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
             } else {
                 if (j == TF && TF > 0) score = __builtin_popcount(Pv) - __builtin_popcount(Mv);
                 const int best_before = best;
-                sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
+                const uint32_t ep = sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
                 if (TRACKW == 1) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
                 if (TRACKW == 2) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - best_before), 31);  // (inm << 1) | (score < minimum so far)
+                if (TRACKW == 2) inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
             }
         }
     }
     if (TRACKW && ngr < 4) inm <<= 32 - 8 * ngr;  // (bit 31 - j stands for column j also when the block stopped early)
+    if (TRACKW == 2 && ngr < 4) inm2 <<= 32 - 8 * ngr;
 }
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
@@ -229,8 +239,11 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // scan below), the input is a gathered slot buffer, every flagged (barcode, diagonal run) is one sweep (no record
 // tables); NW: words of a barcode mask (table entries of 8 bytes for NW <= 2, else 16).
 // MG: pairs mode with more than 128 barcodes (groups of 128; the queue is drained inside the scan).
-// KEND: known-end class (ScoreOnly conditions + trim_side = 5, no start positions wanted): survivors carry the first
-// column of their minimum, the replay trims at it.
+// KEND: known-trim class (ScoreOnly conditions with any trim side per pass, no per-pass start positions wanted): survivors carry
+// what their pass's trim side makes observable — trim_side = 5: the first column of the minimum (the reference's end,
+// classification.jl:142-153, :912-914); trim_side = 3: the LARGEST origin among the optimal alignments (the reference's start,
+// :142-153 tie rule + :310-321 origin order, :910-911), delivered by sweeping the window right to left with the reversed barcode
+// (sweep_lane) — and the replay trims with them.
 // GEN: the general form — dual configs and ref_search_range windows; false: single pass over whole reads (the headline
 // configuration: those checks are compiled out).
 template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false, bool GEN = true>
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint16_t *rnk = (LDS uint16_t *)take(PAIRS ? 0 : (size_t)a.bm_bytes / 2);
     LDS uint32_t *ent = (LDS uint32_t *)take((size_t)a.n_ent * 4);
     LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 36);  // 9 dwords per barcode: (9 b + code) mod 32 spreads over every bank
+    LDS uint32_t *peqr = (LDS uint32_t *)take(KEND ? (size_t)B * 36 : 0);  // the reversed barcodes' words (known-trim class)
     LDS uint32_t *meta = (LDS uint32_t *)take((size_t)B * 4);
     LDS uint32_t *settle = (LDS uint32_t *)take((size_t)B * 4);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
@@ -310,6 +324,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
     if (PAIRS && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
+    if (KEND)
+        for (int i = tid; i < B * 9; i += blockDim.x) peqr[i] = a.peq8r[i];
     for (int i = tid; i < B; i += blockDim.x) {
         meta[i] = a.meta[i];
         settle[i] = a.settle[i];
@@ -318,6 +334,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     __syncthreads();
 
     const uint32_t peq_base = (uint32_t)(uintptr_t)peq;
+    const uint32_t peqr_base = (uint32_t)(uintptr_t)peqr;
     const int ntiles = (int)((n_reads + RW - 1) / RW);  // (< 2^29: a batch holds fewer than 2^32 reads)
 
     // Tiles are dealt round robin over all waves of the grid (tile = wave + k x waves): no queue, no atomics.  The
@@ -490,38 +507,70 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             uint32_t Pv = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm));
             uint32_t Mv = 0;
             int score = mm, best = 0x7FFFFFFF;
-            const uint32_t pbase = peq_base + (uint32_t)b * 36u;
+            // Known-trim class, trim_side = 3 passes: the sweep runs RIGHT TO LEFT over the window with the reversed barcode.  After
+            // the column of 0-based read position p its score is the smallest cost of an alignment that leaves row 0 at node (0, p)
+            // (consumes the read from position p on); the reference's start is the largest origin — the column at which row 1 is
+            // entered — among the alignments of the best score: its origin rule (deletion, then substitution if strictly less, then
+            // insertion, classification.jl:310-321) walks back along the rightmost optimal path, and its recording rule keeps the best
+            // score's largest start (:142-153 with trim_side = 3; no early exit on a zero, :420-430).  That is  p* + s :  p* = the
+            // largest node an optimal alignment leaves from = the column that lowered the running minimum LAST in sweep order, s = 1
+            // iff the diagonal move is optimal there (top bit of Eq & Pv before the step) — a vertical first move enters row 1 at
+            // column p* itself; if p* is the pass window's first column the alignment comes out of the reference's initial column,
+            // whose origins are 1 - i <= 0 (:278-283): reported as 0 (keep_end = max(1, start) - 1 = 0 either way, :910-911).
+            // Model + proof by enumeration: oracle orc_known_start / orc_selftest_known_start.
+            const bool second_b = GEN && b >= a.B0;
+            const int trim_b = KEND ? (second_b ? a.trim1 : a.trim0) : 0;
+            const bool rev = KEND && trim_b == 3;
+            const uint32_t pbase = (rev ? peqr_base : peq_base) + (uint32_t)b * 36u;
             const int sb0 = fb[t] + lo;  // flat index of the window's first base
+            const int se0 = fb[t] + hi - 32;  // reversed sweeps: flat index of the lowest of the first block's 32 positions
             int e_lo = 0, e_hi = -1;     // split mode: first / last column (of the sweep) with a distance within the budget
+            uint32_t sflag = 0u;         // known-trim class, reversed sweeps: s of the column e_hi
             for (int blk = 0;; ++blk) {
                 const int rem = ncol - 32 * blk;
                 if (!__builtin_amdgcn_ballot_w64(rem > 0)) break;
-                const int sb = sb0 + 32 * blk;
-                const int d0 = sb >> 3, shb = (sb & 7) * 4;
+                const int sb = rev ? se0 - 32 * blk : sb0 + 32 * blk;
+                const int d0 = sb >> 3, shb = (sb & 7) * 4;  // (reversed: sb >= -31 while rem > 0, the words in front of the 4-bit image belong to the 2-bit image's padding)
                 uint32_t W[5];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) W[u] = valid ? img4[d0 + u] : 0u;
+                for (int u = 0; u < 5; ++u) W[u] = (valid && (!KEND || rem > 0)) ? img4[d0 + u] : 0u;
                 uint32_t A[4];
 #pragma unroll
+                for (int u = 0; u < 4; ++u) A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
+                if (KEND) {
+                    // column c of a reversed sweep is flat position sb + 31 - c: the 32 four-bit codes in reverse order
+                    uint32_t R[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t y = __builtin_amdgcn_perm(0u, A[3 - u], 0x00010203u);
+                        R[u] = ((y & 0x0F0F0F0Fu) << 4) | ((y >> 4) & 0x0F0F0F0Fu);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) A[u] = rev ? R[u] : A[u];
+                }
+#pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
                     // columns beyond the window become "other" symbols: they match no barcode row, and a column that
                     // matches nothing never lowers the running minimum (D[i][j] >= D[i][j-1] for every row)
                     const int nv = rem - 8 * u;
                     const uint32_t junk = nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
                     A[u] |= junk;
                 }
-                uint32_t inm = 0u;
+                uint32_t inm = 0u, inm2 = 0u;
                 // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
                 const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
                 if (blk == 0)
-                    sweep_block<TF, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                    sweep_block<TF, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
                 else
-                    sweep_block<0, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, ngr);
+                    sweep_block<0, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
                 if (KEND && !SPLIT) {
                     // (junk columns never lower the minimum, §3.0; masked all the same)
                     inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
-                    if (inm) e_hi = 32 * blk + 31 - (int)__builtin_ctz(inm);  // the last column that lowered the minimum
+                    if (inm) {  // the last column that lowered the minimum
+                        const int tz = (int)__builtin_ctz(inm);
+                        e_hi = 32 * blk + 31 - tz;
+                        sflag = (inm2 >> tz) & 1u;
+                    }
                 }
                 if (SPLIT) {
                     // first / last column of the window whose unit distance is within the budget; the
@@ -557,9 +606,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     const bool second = GEN && b >= a.B0;
                     const int bl = second ? b - a.B0 : b;
                     const int ks = __hip_atomic_fetch_add(second ? &wcl1[t] : &scnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    // known-end class: barcode << 22 | d << 16 | 1-based end column (ascending order = the replay's order:
-                    // per barcode the smallest distance first, and of equal ones the leftmost end)
-                    if (ks < 4) (second ? cand : slots)[t * 4 + ks] = KEND ? (((uint32_t)bl << 22) | ((uint32_t)best << 16) | (uint32_t)(lo + e_hi + 1)) : (((uint32_t)bl << 8) | (uint32_t)best);
+                    // known-trim class: barcode << 22 | d << 16 | position key; ascending order = the replay's order: per barcode the
+                    // smallest distance first, and of equal ones — trim_side = 5: key = 1-based end column, the leftmost end first;
+                    // trim_side = 3: key = 0xFFFF - start, the largest start first (no trim side: 0)
+                    uint32_t pkey = 0u;
+                    if (KEND && trim_b == 5) pkey = (uint32_t)(lo + e_hi + 1);
+                    if (KEND && rev) {
+                        const int pstar = hi - 1 - e_hi;  // 0-based read position = node the last lowering column stands for
+                        const int origin = (sflag == 0u && pstar <= win_lo(t, second)) ? 0 : pstar + (int)sflag;
+                        pkey = 0xFFFFu - (uint32_t)origin;
+                    }
+                    if (ks < 4) (second ? cand : slots)[t * 4 + ks] = KEND ? (((uint32_t)bl << 22) | ((uint32_t)best << 16) | pkey) : (((uint32_t)bl << 8) | (uint32_t)best);
                 }
             }
         };
@@ -1029,13 +1086,13 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 // IEEE operations (build_wave_tables); likewise tier 1's settle rule.  No Float64 here.  Dual configs: pass 2 runs
                 // only behind a matched pass 1, and a pass 2 without a match makes the read unknown (:887-895).
                 done = true;
-                int end1 = 0;  // known-end class: 1-based end column of the survivor's alignment
+                int pos1 = 0, pos2 = 0;  // known-trim class: position keys of the two passes' survivors (end column / 0xFFFF - start)
                 const int sbit = a.min_delta == 0.0 ? 0 : 16;
                 bool settled_all = true;
                 if (cnt == 1) {
                     const uint32_t e = slots[lane * 4];
                     const int bb = KEND ? (int)(e >> 22) : (int)(e >> 8), d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u);
-                    end1 = (int)(e & 0xFFFFu);
+                    pos1 = (int)(e & 0xFFFFu);
                     const int dmax = (int)((meta[bb] >> 16) & 255u);
                     vd.bc1 = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
                     settled_all = vd.bc1 > 0 && ((settle[bb] >> (d + sbit)) & 1u) != 0u;
@@ -1049,7 +1106,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     bool s2 = false;
                     if (cnt1 == 1) {
                         const uint32_t e = cand[lane * 4];
-                        const int bb = (int)(e >> 8), d = (int)(e & 255u), g = a.B0 + bb;
+                        const int bb = KEND ? (int)(e >> 22) : (int)(e >> 8), d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u), g = a.B0 + bb;
+                        pos2 = (int)(e & 0xFFFFu);
                         const int dmax = (int)((meta[g] >> 16) & 255u);
                         bc2v = (dmax != 255 && d <= dmax) ? bb + 1 : 0;
                         s2 = bc2v > 0 && ((settle[g] >> (d + sbit)) & 1u) != 0u;
@@ -1062,9 +1120,26 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 if (a.tier) done = settled_all;
                 vd.keep_start = vd.bc1 > 0 ? 1 : -1;  // :907-908 / :879-883 (ScoreOnly: the whole read, n >= 1)
                 vd.keep_end = vd.bc1 > 0 ? n : -1;
-                if (KEND && vd.bc1 > 0) {  // trim_side = 5: keep what follows the alignment's end (:912-914), (1, 0) if nothing does (:932-935)
-                    vd.keep_start = end1 + 1 > n ? 1 : end1 + 1;
-                    vd.keep_end = end1 + 1 > n ? 0 : n;
+                if (KEND && vd.bc1 > 0) {
+                    // trim_side = 5: keep what follows the alignment's end (:912-914); trim_side = 3: what precedes its start
+                    // (:910-911); a second pass narrows the range (:921-929); (1, 0) if nothing is left (:932-935)
+                    int ks = 1, ke = n;
+                    if (a.trim0 == 3) {
+                        const int st = 0xFFFF - pos1;
+                        ke = (st > 1 ? st : 1) - 1;
+                    } else if (a.trim0 == 5) {
+                        ks = pos1 + 1;
+                    }
+                    if (dual) {
+                        if (a.trim1 == 3) {
+                            const int st = 0xFFFF - pos2, e2 = (st > 1 ? st : 1) - 1;
+                            ke = ke < e2 ? ke : e2;
+                        } else if (a.trim1 == 5) {
+                            ks = ks > pos2 + 1 ? ks : pos2 + 1;
+                        }
+                    }
+                    vd.keep_start = ks > ke ? 1 : ks;
+                    vd.keep_end = ks > ke ? 0 : ke;
                 }
             } else if (!flag[lane] && cnt <= 4 && cnt1 <= 4 && n >= 1) {
                 const LDS uint32_t *e0 = slots + lane * 4;
@@ -1078,8 +1153,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 cfg.is_dual = dual ? 1 : 0;
                 cfg.max_error_rate = a.max_error_rate;
                 cfg.min_delta = a.min_delta;
-                cfg.pass[0].trim_side = KEND ? 5 : 0;
-                cfg.pass[1].trim_side = 0;
+                cfg.pass[0].trim_side = KEND ? a.trim0 : 0;
+                cfg.pass[1].trim_side = KEND ? a.trim1 : 0;
                 classify_known<KEND>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
                 done = true;
                 if (a.tier) {
@@ -1200,6 +1275,9 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.ent = wp.d_ent;
     a.n_ent = wp.n_ent;
     a.peq8 = wp.d_peq8;
+    a.peq8r = wp.d_peq8r;
+    a.trim0 = cfg.pass[0].trim_side;
+    a.trim1 = cfg.is_dual ? cfg.pass[1].trim_side : 0;
     a.meta = wp.d_meta;
     a.settle = wp.d_settle;
     a.B = wp.n_barcodes;
@@ -1248,7 +1326,7 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
     return al((size_t)wp.bm_bytes) + al(wp.pairs_kb > 0 ? 0 : (size_t)wp.bm_bytes / 2) + al((size_t)wp.n_ent * 4) + al((size_t)wp.n_barcodes * 36) +
-           2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
+           al(wp.kend ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
 size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words) {
@@ -1349,7 +1427,8 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 #define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
     if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
-    if (wp.kend && out.pass_start != nullptr) return hipErrorInvalidValue;
+    if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return hipErrorInvalidValue;
+    if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
     if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
     if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
     return hipErrorInvalidValue;
@@ -1390,16 +1469,20 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 // launch as bdx_launch_wave for a known-score config, the verdicts carry the trimmed keep range.
 hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
-                               unsigned int *list_count, hipStream_t stream, int dbg) {
+                               unsigned int *list_count, hipStream_t stream, int dbg, double tier_slo1) {
     if (n_reads <= 0) return hipSuccess;
-    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr) return hipErrorInvalidValue;
+    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr || !wp.d_peq8r) return hipErrorInvalidValue;
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, nullptr);
+    if (out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;  // (a trim_side = 3 pass knows its start only)
     a.seq = d_seq;
     a.off = d_off;
     a.n_reads = n_reads;
     a.tier = tier1;
     a.tier_slo = tier_slo;
+    a.tier_slo1 = tier_slo1;
+    a.dual = cfg.is_dual ? 1 : 0;
+    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;  // (the survivors of pass 1 live in the candidate-word area: four per read)
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
     long long blocks = (long long)wp.blocks;

@@ -1571,3 +1571,141 @@ int64_t orc_selftest_windowed_exact(uint64_t seed, int64_t iters, int64_t *first
     }
     return bad;
 }
+
+/* ---- model of the HIP wave kernel's known-trim class (csrc/bdx_wave.hip, KEND), test-only ------------------------------
+ * Claim: in the known-score class (SimpleScoring 0 / 1 / 1, start / end ranges that do not bind) the
+ * (score, start) a trim_side = 3 pass of the reference reports for one barcode — recording rule classification.jl:142-153
+ * ("strictly better, or equal with a larger start"), origin rule :310-321 (deletion, then substitution if strictly less,
+ * then insertion if strictly less), no early exit on a zero (:420-430) — is
+ *      score = d* = the smallest unit-cost distance of the barcode to a substring of the column window, and
+ *      start = the LARGEST origin (column at which row 1 is entered) among all alignments of cost d*,
+ * and Myers' bit-vector sweep run RIGHT TO LEFT over the window with the REVERSED barcode delivers that start: after the
+ * column of 0-based read position p the score is the smallest cost of an alignment leaving row 0 at node (0, p); the largest
+ * such node with score d* is the column that lowered the running minimum LAST in sweep order (p*), and the start is p* + 1
+ * when the diagonal move into the sweep's last row (= the barcode's FIRST base) is optimal there — top bit of Eq & Pv before
+ * the step — else p* (a vertical first move enters row 1 at column p* itself); at the window's first column such an
+ * alignment comes out of the reference's initial column (origins 1 - i <= 0, :278-283): reported as 0, which
+ * max(1, start) - 1 (:910-911) cannot tell from the reference's value.
+ * Likewise trim_side = 5 (the existing known-end class): end = the FIRST column of a left-to-right sweep that attains d*.
+ * orc_known_trim_positions is the 32-bit model (top-aligned patterns, the kernel's operations in the kernel's order);
+ * orc_selftest_known_start compares it with the line-faithful core. */
+static void known_sweep32(const uint8_t *q, int64_t m, const uint8_t *r, int64_t lo, int64_t hi, int reversed,
+                          int64_t *best_out, int64_t *col_out, int *sflag_out) {
+    /* columns c = 0 .. hi - lo - 1 of the sweep: forward c <-> 0-based position lo + c, reversed c <-> hi - 1 - c */
+    const int shift = (int)(32 - m);
+    const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
+    uint32_t peq[256];
+    for (int ch = 0; ch < 256; ch++) peq[ch] = ~rows; /* virtual rows below the barcode match everything */
+    for (int64_t i = 0; i < m; i++) peq[reversed ? q[m - 1 - i] : q[i]] |= 1u << (shift + i);
+    uint32_t Pv = rows, Mv = 0;
+    int64_t score = m, best = INT64_MAX, col = -1;
+    int sflag = 0;
+    for (int64_t c = 0; c < hi - lo; c++) {
+        const uint8_t ch = r[reversed ? hi - 1 - c : lo + c];
+        const uint32_t Eq = peq[ch];
+        const uint32_t Xv = Eq | Mv;
+        const uint32_t ep = Eq & Pv;
+        const uint32_t Xh = ((ep + Pv) ^ Pv) | Eq;
+        uint32_t Ph = Mv | ~(Xh | Pv);
+        uint32_t Mh = Pv & Xh;
+        score += (int64_t)(Ph >> 31);
+        score -= (int64_t)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        if (score < best) { /* this column lowered the running minimum */
+            best = score;
+            col = c;
+            sflag = (int)(ep >> 31);
+        }
+    }
+    *best_out = best;
+    *col_out = col;
+    *sflag_out = sflag;
+}
+
+/* (d*, position) of one barcode over the 0-based column window [lo, hi) of read r: trim_side 5 -> the 1-based end column,
+ * trim_side 3 -> the start (0 stands for "<= 0"); returns 0 when the window is empty */
+int orc_known_trim_positions(const uint8_t *q, int64_t m, const uint8_t *r, int64_t lo, int64_t hi, int32_t trim_side,
+                             int64_t *d_out, int64_t *pos_out) {
+    if (hi <= lo || m < 1 || m > 32) return 0;
+    int64_t best, col;
+    int sflag;
+    known_sweep32(q, m, r, lo, hi, trim_side == 3, &best, &col, &sflag);
+    *d_out = best;
+    if (trim_side == 3) {
+        const int64_t pstar = hi - 1 - col;
+        *pos_out = (!sflag && pstar <= lo) ? 0 : pstar + sflag;
+    } else {
+        *pos_out = lo + col + 1;
+    }
+    return 1;
+}
+
+int64_t orc_selftest_known_start(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[5] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[200];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0, n_start = 0, n_edge = 0, n_end = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 1 + (int64_t)(st_next(&s) % 32);
+        int64_t n = 1 + (int64_t)(st_next(&s) % 160);
+        const int nal = (st_next(&s) % 5) ? 4 : 2; /* low-complexity pairs: many ties */
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % (uint64_t)nal];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[(st_next(&s) % 50) ? st_next(&s) % (uint64_t)nal : 4];
+        int64_t first = 1, last = n;
+        if (st_next(&s) % 2) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        int copies = (int)(st_next(&s) % 3); /* 0, 1 or 2 mutated copies; half of them at the window's edges */
+        for (int cpy = 0; cpy < copies; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            const uint64_t where = st_next(&s) % 6;
+            if (where == 0) pos = first - 1;
+            if (where == 1) pos = first - 2 >= 0 ? first - 2 : 0;
+            if (where == 2) pos = last - m + (int64_t)(st_next(&s) % 3) - 1;
+            if (pos < 0) pos = 0;
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 6) r[pos++] = (uint8_t)AL[st_next(&s) % (uint64_t)nal];
+                else if (u < 10) continue;
+                else if (u < 14) { r[pos++] = (uint8_t)AL[st_next(&s) % (uint64_t)nal]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        const double rate = RATES[st_next(&s) % 8];
+        const int32_t trim = (st_next(&s) % 3) ? 3 : 5;
+        const int64_t max_start = n + (int64_t)(st_next(&s) % 2) * 50, min_end = 1 - (int64_t)(st_next(&s) % 2);
+        orc_align_t a = orc_semiglobal_core(DP, OG, q, m, r, n, rate, 0, 1, 1, 0, 0, ORC_OUT_TRACEBACK, trim, first, last,
+                                            max_start, min_end, m);
+        int64_t d = 0, pos = 0;
+        const int have = orc_known_trim_positions(q, m, r, first - 1, last, trim, &d, &pos);
+        const int64_t ae = (int64_t)floor(rate * (double)m);
+        int ok;
+        if (!have || d > ae) {
+            ok = a.raw >= INF_INT;
+        } else if (trim == 3) { /* the start, exactly when it is a column of the read; "<= 0" as a class */
+            ok = a.raw == d && ((a.start >= 1 && a.start == pos) || (a.start < 1 && pos == 0));
+            n_start += a.start >= 1;
+            n_edge += a.start < 1;
+        } else {
+            ok = a.raw == d && a.end == pos;
+            n_end++;
+        }
+        if (!ok) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = a.raw;
+                first_bad[4] = d; first_bad[5] = a.start; first_bad[6] = trim == 3 ? pos : a.end; first_bad[7] = trim == 3 ? trim : pos;
+            }
+            bad++;
+        }
+    }
+    if (bad == 0 && first_bad) { /* coverage: recorded starts inside the read / "<= 0" starts / recorded ends compared */
+        first_bad[1] = n_start; first_bad[2] = n_edge; first_bad[3] = n_end;
+    }
+    return bad;
+}

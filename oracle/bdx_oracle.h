@@ -168,6 +168,10 @@ int64_t orc_selftest_cone(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_clean_class(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_clean_short_lookback(uint64_t seed, int64_t iters, int64_t *first_bad);
 int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad);
+/* model of the wave kernel's known-trim class: (d*, end column | start) of one barcode over the 0-based column window [lo, hi) */
+int orc_known_trim_positions(const uint8_t *q, int64_t m, const uint8_t *r, int64_t lo, int64_t hi, int32_t trim_side,
+                             int64_t *d_out, int64_t *pos_out);
+int64_t orc_selftest_known_start(uint64_t seed, int64_t iters, int64_t *first_bad);
 
 #ifdef __cplusplus
 }

@@ -71,3 +71,15 @@ def test_diagonal_band_dp_records_what_the_reference_records():
     bad = H.orc.lib().orc_selftest_band_class(20260515, 600_000, fb)
     assert bad == 0, list(fb)
     assert fb[1] > 50_000 and fb[2] > 20_000 and fb[3] > 5_000, list(fb)  # compared exactly / with traceback / band across the first column
+
+
+def test_known_trim_class_reversed_sweep_gives_the_reference_start():
+    """in the known-score class a trim_side = 3 pass reports the LARGEST origin among the alignments of the
+    best score, and a right-to-left bit-vector sweep with the reversed barcode delivers it (last column that lowers the
+    running minimum + the top bit of Eq & Pv there); trim_side = 5: the first column of a left-to-right sweep that attains
+    the minimum.  The 32-bit model of the wave kernel's sweeps (oracle orc_known_trim_positions) against the line-faithful
+    core: random and low-complexity pairs (ties), copies at the window's edges, column windows that start inside the read."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_known_start(20260515, 600_000, fb)
+    assert bad == 0, f"first disagreement (iter, m, n, core.raw, model d, core.start, model pos | core.end, trim | model pos): {list(fb)}"
+    assert fb[1] > 50_000 and fb[2] > 500 and fb[3] > 20_000, list(fb)  # starts inside the read / starts <= 0 / ends compared
