@@ -798,6 +798,8 @@ int build_wave_tables(bdx_ctx *ctx) {
             F.wplan_k.split = 0;
             F.wplan_k.cand_words = c.is_dual ? 4 : 0;  // (the four survivor slots of pass 1)
             F.wplan_k.kend = 1;
+            for (int k = 0; k < npass; ++k)
+                if (c.pass[k].trim_side == 3) F.wplan_k.kend = 2;  // (reversed sweeps: bdx_wave_rev.hip)
         }
     }
     return BDX_OK;
@@ -1012,6 +1014,8 @@ int build_pair_tables(bdx_ctx *ctx) {
         F.pplan_k.split = 0;
         F.pplan_k.cand_words = c.is_dual ? 4 : 0;
         F.pplan_k.kend = 1;
+        for (int k = 0; k < npass; ++k)
+            if (c.pass[k].trim_side == 3) F.pplan_k.kend = 2;
     }
     return BDX_OK;
 }

@@ -188,9 +188,9 @@ __device__ __forceinline__ void lds_wait8(uint32_t (&d)[8]) {
 
 // TRACKW: also note which columns have a score within the budget (split mode): bit 31 - j of `inm` for column j of the
 // block (kk1 = budget + 1: the sign bit of score - kk1 is shifted in).
-// TRACKW = 2 (known-end class): bit 31 - j instead says "column j lowered the running minimum" — the last such column of a
+// TRACKW >= 2 (known-trim class): bit 31 - j instead says "column j lowered the running minimum" — the last such column of a
 // sweep is the FIRST column that attains its minimum (the reference keeps the leftmost end of the best score,
-// classification.jl:142-153 with trim_side = 5: strict `<`).  `inm2` (same bit numbering) then notes, per column, the top
+// classification.jl:142-153 with trim_side = 5: strict `<`).  TRACKW = 3: `inm2` (same bit numbering) also notes, per column, the top
 // bit of Eq & Pv BEFORE the step: "the barcode's last row matches this column and its vertical delta was +1", i.e. the
 // diagonal move into the last row attains the column's value (needed by the reversed sweeps of trim_side = 3 passes, see
 // sweep_lane: there the last row is the barcode's FIRST base).
@@ -224,13 +224,13 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
                 const int best_before = best;
                 const uint32_t ep = sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
                 if (TRACKW == 1) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
-                if (TRACKW == 2) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - best_before), 31);  // (inm << 1) | (score < minimum so far)
-                if (TRACKW == 2) inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
+                if (TRACKW >= 2) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - best_before), 31);  // (inm << 1) | (score < minimum so far)
+                if (TRACKW == 3) inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
             }
         }
     }
     if (TRACKW && ngr < 4) inm <<= 32 - 8 * ngr;  // (bit 31 - j stands for column j also when the block stopped early)
-    if (TRACKW == 2 && ngr < 4) inm2 <<= 32 - 8 * ngr;
+    if (TRACKW == 3 && ngr < 4) inm2 <<= 32 - 8 * ngr;
 }
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
@@ -246,9 +246,10 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // (sweep_lane) — and the replay trims with them.
 // GEN: the general form — dual configs and ref_search_range windows; false: single pass over whole reads (the headline
 // configuration: those checks are compiled out).
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false, bool GEN = true>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
+    constexpr bool KREV = KEND == 2;  // known-trim class with a trim_side = 3 pass: reversed sweeps (1: trim sides 5 / none only — the sweeps of round 3's known-end class)
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
     // seed hits per tile (pairs mode: flagged (barcode, run of diagonals)s = sweeps) / sweeps (= records) per tile: sized per
     // config from the expected chance hits (size_wave) — the two queues sit behind the images, at run-time offsets
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint16_t *rnk = (LDS uint16_t *)take(PAIRS ? 0 : (size_t)a.bm_bytes / 2);
     LDS uint32_t *ent = (LDS uint32_t *)take((size_t)a.n_ent * 4);
     LDS uint32_t *peq = (LDS uint32_t *)take((size_t)B * 36);  // 9 dwords per barcode: (9 b + code) mod 32 spreads over every bank
-    LDS uint32_t *peqr = (LDS uint32_t *)take(KEND ? (size_t)B * 36 : 0);  // the reversed barcodes' words (known-trim class)
+    LDS uint32_t *peqr = (LDS uint32_t *)take(KREV ? (size_t)B * 36 : 0);  // the reversed barcodes' words (known-trim class)
     LDS uint32_t *meta = (LDS uint32_t *)take((size_t)B * 4);
     LDS uint32_t *settle = (LDS uint32_t *)take((size_t)B * 4);
     LDS int *hist = (LDS int *)take((size_t)a.hist_entries * 4);
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
     if (PAIRS && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
-    if (KEND)
+    if (KREV)
         for (int i = tid; i < B * 9; i += blockDim.x) peqr[i] = a.peq8r[i];
     for (int i = tid; i < B; i += blockDim.x) {
         meta[i] = a.meta[i];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // Model + proof by enumeration: oracle orc_known_start / orc_selftest_known_start.
             const bool second_b = GEN && b >= a.B0;
             const int trim_b = KEND ? (second_b ? a.trim1 : a.trim0) : 0;
-            const bool rev = KEND && trim_b == 3;
+            const bool rev = KREV && trim_b == 3;
             const uint32_t pbase = (rev ? peqr_base : peq_base) + (uint32_t)b * 36u;
             const int sb0 = fb[t] + lo;  // flat index of the window's first base
             const int se0 = fb[t] + hi - 32;  // reversed sweeps: flat index of the lowest of the first block's 32 positions
@@ -533,11 +534,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const int d0 = sb >> 3, shb = (sb & 7) * 4;  // (reversed: sb >= -31 while rem > 0, the words in front of the 4-bit image belong to the 2-bit image's padding)
                 uint32_t W[5];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) W[u] = (valid && (!KEND || rem > 0)) ? img4[d0 + u] : 0u;
+                for (int u = 0; u < 5; ++u) W[u] = (valid && (!KREV || rem > 0)) ? img4[d0 + u] : 0u;
                 uint32_t A[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
-                if (KEND) {
+                if (KREV) {
                     // column c of a reversed sweep is flat position sb + 31 - c: the 32 four-bit codes in reverse order
                     uint32_t R[4];
 #pragma unroll
@@ -560,9 +561,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 // groups of eight columns some lane still needs (the tail block of a 33..48-column window is mostly junk)
                 const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
                 if (blk == 0)
-                    sweep_block<TF, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
+                    sweep_block<TF, (SPLIT ? 1 : KEND ? 1 + KEND : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
                 else
-                    sweep_block<0, (SPLIT ? 1 : KEND ? 2 : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
+                    sweep_block<0, (SPLIT ? 1 : KEND ? 1 + KEND : 0)>(A[0], A[1], A[2], A[3], pbase, Pv, Mv, score, best, kk + 1, inm, inm2, ngr);
                 if (KEND && !SPLIT) {
                     // (junk columns never lower the minimum, §3.0; masked all the same)
                     inm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     // trim_side = 3: key = 0xFFFF - start, the largest start first (no trim side: 0)
                     uint32_t pkey = 0u;
                     if (KEND && trim_b == 5) pkey = (uint32_t)(lo + e_hi + 1);
-                    if (KEND && rev) {
+                    if (KREV && rev) {
                         const int pstar = hi - 1 - e_hi;  // 0-based read position = node the last lowering column stands for
                         const int origin = (sflag == 0u && pstar <= win_lo(t, second)) ? 0 : pstar + (int)sflag;
                         pkey = 0xFFFFu - (uint32_t)origin;
@@ -1155,7 +1156,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 cfg.min_delta = a.min_delta;
                 cfg.pass[0].trim_side = KEND ? a.trim0 : 0;
                 cfg.pass[1].trim_side = KEND ? a.trim1 : 0;
-                classify_known<KEND>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
+                classify_known<(KEND != 0)>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
                 done = true;
                 if (a.tier) {
                     // tier settle rule (same code as bdx_bitpar.hip)
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, bool KEND = false, bool GEN = true>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
@@ -1320,13 +1321,16 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 // (the argument block crosses translation units as bytes: WaveArgs is this file's, compiled into each of them)
 hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+// (bdx_wave_rev.hip: the known-trim instantiations with reversed sweeps, KEND = 2)
+hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 
-#if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND)
+#if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND) && !defined(BDX_WAVE_TU_KREV)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
     return al((size_t)wp.bm_bytes) + al(wp.pairs_kb > 0 ? 0 : (size_t)wp.bm_bytes / 2) + al((size_t)wp.n_ent * 4) + al((size_t)wp.n_barcodes * 36) +
-           al(wp.kend ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
+           al(wp.kend == 2 ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
 size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words) {
@@ -1369,7 +1373,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     if (!wp.split && (a.dual || a.ranged)) return bdx_launch_wave_gen(&a, wp, lds, blocks, stream);
     if (wp.split && a.ranged) return bdx_launch_wave_split_gen(&a, wp, lds, blocks, stream);  // (bdx_pairs.hip)
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV)                                                              \
-    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, false>(a, lds, wp.waves, blocks, stream))
+    (wp.split ? launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, 0, false>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 0, false>(a, lds, wp.waves, blocks, stream))
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1420,7 +1424,7 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     const int tf = wp.track_from;
 #define BDX_PAIRS_SP(RWV, TFV, NVV, KBV, NWV)                                                                                  \
     (wp.split  ? launch_wave<RWV, TFV, NVV, 4, true, KBV, NWV>(a, lds, wp.waves, blocks, stream)                               \
-     : wp.kend ? launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV, false, true>(a, lds, wp.waves, blocks, stream)                 \
+     : wp.kend ? launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV, false, 1>(a, lds, wp.waves, blocks, stream)                    \
                : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
 #define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.groups > 1 ? launch_wave<RWV, TFV, NVV, 4, false, KBV, 4, true>(a, lds, wp.waves, blocks, stream) : wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
 #define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
@@ -1429,6 +1433,8 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
     if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return hipErrorInvalidValue;
     if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
+    if ((wp.kend == 2) != (wp.kend && (a.trim0 == 3 || a.trim1 == 3))) return hipErrorInvalidValue;
+    if (wp.kend == 2) return bdx_launch_pairs_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)
     if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
     if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
     return hipErrorInvalidValue;
@@ -1442,7 +1448,7 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
     const WaveArgs &a = *(const WaveArgs *)wave_args;
     const int tf = wp.track_from;
-#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, true, 0, 0, false, 0, true>(a, lds, wp.waves, blocks, stream)
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1463,7 +1469,7 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 #undef BDX_WAVE_SP
 }
 
-#else  // BDX_WAVE_TU_KEND: the known-end instantiations (bdx_wave_end.hip)
+#elif defined(BDX_WAVE_TU_KEND)  // the known-trim instantiations without reversed sweeps + the general non-split form (bdx_wave_end.hip)
 
 // The kernel for configs of the known-end class (ScoreOnly conditions + trim_side = 5, no start positions wanted): same
 // launch as bdx_launch_wave for a known-score config, the verdicts carry the trimmed keep range.
@@ -1489,8 +1495,10 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
     const long long useful = (tiles + wp.waves - 1) / wp.waves;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
+    if ((wp.kend == 2) != (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
+    if (wp.kend == 2) return bdx_launch_wave_end_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)
     const int tf = wp.track_from;
-#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 1>(a, lds, wp.waves, blocks, stream)
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1515,7 +1523,7 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
 hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
     const WaveArgs &a = *(const WaveArgs *)wave_args;
     const int tf = wp.track_from;
-#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, false, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 0, true>(a, lds, wp.waves, blocks, stream)
 #define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
 #define BDX_WAVE_TF(RWV)                                                                             \
     return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
@@ -1534,6 +1542,46 @@ hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, siz
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
 #undef BDX_WAVE_SP
+}
+
+#else  // BDX_WAVE_TU_KREV: the known-trim instantiations with reversed sweeps (a trim_side = 3 pass; bdx_wave_rev.hip)
+
+hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    const int tf = wp.track_from;
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 2>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
+    switch (wp.rw) {
+        case 32:
+            BDX_WAVE_TF(32);
+        case 16:
+            BDX_WAVE_TF(16);
+        case 8:
+            BDX_WAVE_TF(8);
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
+}
+
+hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    if (wp.pairs_kb > 4 || wp.nw > 4 || wp.track_from < 12 || wp.groups > 1 || wp.split || wp.kend != 2) return hipErrorInvalidValue;
+#define BDX_PAIRS_SP(RWV, NVV, KBV, NWV) launch_wave<RWV, 12, NVV, 4, false, KBV, NWV, false, 2>(a, lds, wp.waves, blocks, stream)
+#define BDX_PAIRS_NW(RWV, NVV, KBV) (wp.nw <= 2 ? BDX_PAIRS_SP(RWV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, NVV, KBV, 4))
+#define BDX_PAIRS_KB(RWV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, NVV, 3) : BDX_PAIRS_NW(RWV, NVV, 4))
+    if (wp.rw == 16 && wp.span_cap <= 3 * 1024) return BDX_PAIRS_KB(16, 3);
+    if (wp.rw == 16 && wp.span_cap <= 6 * 1024) return BDX_PAIRS_KB(16, 6);
+    return hipErrorInvalidValue;
+#undef BDX_PAIRS_KB
+#undef BDX_PAIRS_NW
+#undef BDX_PAIRS_SP
 }
 
 #endif
