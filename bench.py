@@ -50,6 +50,8 @@ def _parse():
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end FASTQ leg (0: skip)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--allow-wrong-results", action="store_true",
+                    help="tuning only (tools/phase_*.sh: phase-skip timing experiments of a -DBDX_TUNING build give wrong results by design): skip the counter-vector consistency checks of the headline run")
     return ap.parse_args()
 
 
@@ -159,6 +161,22 @@ def build_workload(name: str, n_reads: int, first_read: int, rate_override=None)
     raise KeyError(name)
 
 
+def kernel_source_sha16() -> str:
+    """sha256 over the sources the HIP library is built from (csrc/*.hip, *.h, *.cpp except the host-only I/O and the
+    generator, include/*.h), first 16 hex digits — the identity of "these kernels" for the committed counter profiles."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "biodemux.jl_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc)
+                   if f.endswith((".hip", ".h", ".cpp", ".inc")) and f not in ("bdx_io.cpp",))
+    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _profile_counters(config: str, n: int):
     """(traffic bytes per step, source, per-kernel VALU figures) from the latest committed rocprofv3 --pmc summary of
     this config (profiles/*_<config>_*pmc.json, tools/summarize_prof.py), or (None, None, None)."""
@@ -170,6 +188,11 @@ def _profile_counters(config: str, n: int):
         pj = json.load(open(os.path.join(ROOT, "profiles", tagged[-1])))
         if pj.get("reads_per_launch") != n:
             return None, None, None
+        # the counters belong to the kernels they were collected on: a profile taken on other kernel sources than the
+        # ones this library was built from is not paired with this run's time (tools/summarize_prof.py records the hash)
+        if pj.get("kernel_source_sha16") != kernel_source_sha16():
+            return None, (f"profiles/{tagged[-1]} is STALE: taken on kernel sources {pj.get('kernel_source_sha16')}, this tree has "
+                          f"{kernel_source_sha16()} — re-profile (tools/profile_round.sh)"), None
         tot, src = 0.0, []
         for kname, e in pj["kernels"].items():
             if "hbm_read_bytes_corrected" in e:
@@ -187,7 +210,7 @@ def _profile_counters(config: str, n: int):
                     "valu_wave_instr_per_read": round(c.get("SQ_INSTS_VALU", 0.0) / n, 1),
                     "simd_cycles_per_valu_instr": (round(c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0 / c["SQ_INSTS_VALU"], 2)
                                                    if c.get("SQ_BUSY_CYCLES") else None),
-                    "valu_ceiling_cycles_per_instr": 3.2,
+                    "valu_ceiling_cycles_per_instr_by_class": {"v_and/or/xor/add/sub/lshrrev": 2.4, "everything else": 4.3, "source": "profiles/r03_ubench_ops.txt"},
                     "wave_issue_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}]
         if src:
             traffic, src_s = tot, f"profiles/{tagged[-1]} ({' + '.join(src)})"
@@ -247,17 +270,18 @@ def run_leg(name: str, dev, dev_index: int, steps: int = 5, warmup: int = 2, sam
     algo = wl["algo_bytes"]
     achieved = algo * n / (kern_ms * 1e-3) / 1e9
     traffic, tsrc, _ = _profile_counters(name, n)
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_read": algo, "survey_bytes_per_read": wl.get("survey_bytes", algo)}
+    if traffic is not None or tsrc is not None:  # (a config without a committed counter profile carries no traffic fields at all)
+        roof.update({"traffic": traffic, "traffic_ratio": (traffic / (algo * n)) if traffic else None, "traffic_source": tsrc})
     return {"name": name, "workload": wl["desc"], "value": n * steps / elapsed, "unit": "reads/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kern_ms, "kernel_path": path,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_read": algo, "survey_bytes_per_read": wl.get("survey_bytes", algo),
-                         "traffic": traffic, "traffic_ratio": (traffic / (algo * n)) if traffic else None, "traffic_source": tsrc},
+            "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kern_ms, "kernel_path": path, "roofline": roof,
             "oracle_checked_reads": int(k), "gen_seconds": round(gen_s, 1)}
 
 
 def run_e2e(n: int, dev_index: int, expect_matched=None):
     """End to end: a FASTQ file of the C2 shape on tmpfs -> execute_demultiplexing (native reader /
-    packer, ONE C-ABI classify call per 2^20-read batch, native in-order writer) -> 97 files.  reads/s of the whole
+    packer, ONE C-ABI classify call per 2^19-read batch, native in-order writer) -> 97 files.  reads/s of the whole
     call, the busy seconds of the three overlapped stages and which of them bounds it."""
     import shutil
     import tempfile
@@ -430,7 +454,7 @@ def main():
     kern_ms_avg = float(np.mean(kern_ms)) if kern_ms else float("nan")
 
     counts = hc.reduced_counts if allreduce_via.startswith("C-ABI") else total.cpu().numpy()
-    if not os.environ.get("BDX_DEBUG"):  # (phase-skip timing experiments of a -DBDX_TUNING build give wrong results by design)
+    if not args.allow_wrong_results:  # (only tools/phase_*.sh pass the flag; a stray environment variable disables nothing)
         assert counts[0] == n * world, (counts[0], n * world)
         assert counts[1] + counts[2] + counts[3] == counts[0] and counts[4:].sum() == counts[1], "counter vector inconsistent"
 
@@ -552,6 +576,17 @@ def main():
             except Exception as e:  # noqa: BLE001
                 e2e = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
+    # what the communicator itself says about the job (world > 1): its size as RCCL sees it and the library version —
+    # the first real multi-GPU run proves its N ranks by this line alone
+    comm_info = {}
+    if world > 1:
+        comm_info["comm_size"] = int(hc.lib.bdx_comm_size(hc.h)) if allreduce_via.startswith("C-ABI") else int(torch.distributed.get_world_size())
+        comm_info["comm_size_source"] = "bdx_comm_size (ncclCommCount of the C-ABI communicator)" if allreduce_via.startswith("C-ABI") else "torch.distributed.get_world_size"
+        try:
+            comm_info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            comm_info["rccl_version"] = f"unavailable ({type(e).__name__})"
+        comm_info["counts_total_reads"] = int(counts[0])
     if rank == 0:
         reads_total = n * world * args.steps
         value = reads_total / elapsed_max
@@ -567,7 +602,7 @@ def main():
                        "read_length_hint": wl["read_len"],
                        "kernel_path": path, "threads_per_block": info["threads_per_block"],
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "parallelism": f"reads sharded x{world}",
-                       "allreduce": allreduce_via,
+                       "allreduce": allreduce_via, **comm_info,
                        "matched_fraction": float(counts[1]) / max(float(counts[0]), 1.0), "gen_seconds": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per step (all kernels of one classify call)",

@@ -1954,6 +1954,7 @@ void bdx_destroy(bdx_ctx *ctx) {
         f.seed_tables.release();
         f.seed_tables_alt.release();
         f.wave_tables.release();
+        f.pair_tables.release();
     }
     ctx->d_wlist.release();
     ctx->d_gseq.release();

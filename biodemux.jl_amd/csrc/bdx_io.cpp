@@ -11,6 +11,7 @@
 // The reference does this with one reader and one writer task; here line indexing, packing and
 // the per-file gather are spread over host threads so the 1 G reads/s kernel is not starved more
 // than the file system dictates.
+#include <cerrno>
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/mman.h>
@@ -354,8 +355,10 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
     int64_t scanned_to = start;
     int64_t region = std::min<int64_t>(size - start, std::max<int64_t>(1 << 20, max_reads * 400));
     while (nlines < want && scanned_to < size) {
-        const int64_t hi = std::min(size, scanned_to + region);
-        const int T = std::max(1, std::min<int>(nthreads, (int)((hi - scanned_to) >> 20) + 1));
+        // (newline positions are 32-bit offsets from the slice start: a slice stays below 4 GiB whatever `region` has
+        // doubled to on input with very long lines)
+        const int64_t hi = std::min(size, scanned_to + std::min<int64_t>(region, (int64_t)std::max(1, nthreads) * 0xFFFF0000LL));
+        const int T = std::max(1, std::min<int>(nthreads, (int)std::min<int64_t>((hi - scanned_to) >> 20, 1 << 20) + 1));
         const int64_t span = (hi - scanned_to + T - 1) / T;
         std::vector<std::unique_ptr<uint32_t[]>> pos((size_t)T);
         std::vector<int64_t> cnt((size_t)T, 0);
@@ -815,7 +818,8 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                         while (left > 0 && !ds.fail) {
                             const int n = (int)std::min<int64_t>(left, 1024);  // IOV_MAX
                             ssize_t w = writev(fd, v, n);
-                            if (w < 0) {
+                            if (w < 0 && errno == EINTR) continue;  // interrupted before anything went out: again
+                            if (w <= 0) {  // (0 bytes of a non-empty request would spin forever)
                                 ds.fail = 1;
                                 break;
                             }
@@ -836,6 +840,7 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                         int64_t left = csize[(size_t)c];
                         while (left > 0) {
                             const ssize_t w = write(fd, p, (size_t)left);
+                            if (w < 0 && errno == EINTR) continue;
                             if (w <= 0) {
                                 ds.fail = 1;
                                 break;

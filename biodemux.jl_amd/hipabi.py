@@ -217,6 +217,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_band_launches.argtypes = [vp]
     L.bdx_wave_launches.restype = C.c_int64
     L.bdx_wave_launches.argtypes = [vp]
+    L.bdx_pair_launches.restype = C.c_int64
+    L.bdx_pair_launches.argtypes = [vp]
     L.bdx_pipelined_calls.restype = C.c_int64
     L.bdx_pipelined_calls.argtypes = [vp]
     L.bdx_rejected_windows.restype = C.c_int64

@@ -164,7 +164,17 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
     def reader():
         try:
             while True:
-                buf = free.get()
+                # (a batch dropped on an error path never comes back through `free`: poll, and stop once anything failed —
+                # the reader must always reach its final q_in.put(None), or the caller waits for it forever)
+                while True:
+                    try:
+                        buf = free.get(timeout=0.05)
+                        break
+                    except queue.Empty:
+                        if errors:
+                            return
+                if errors:
+                    return
                 t0 = time.perf_counter()
                 n1, off1, ln1 = f1.next_batch(batch_reads, T, buf.get("off1"), buf.get("ln1"))
                 buf["off1"], buf["ln1"] = off1, ln1
@@ -253,8 +263,11 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                     free.put(buf)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
-            while qw.get() is not None:  # keep draining so the producer never blocks
-                pass
+            while True:  # keep draining so the producer never blocks; the dropped batches' buffers go back
+                item = qw.get()
+                if item is None:
+                    break
+                free.put(item[10])
 
     tr = threading.Thread(target=reader, name="bdx-reader")
     tws = [threading.Thread(target=writer, args=(wi,), name=f"bdx-writer-{wi}") for wi in range(len(ranges))]
@@ -267,6 +280,7 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
             if item is None:
                 break
             if errors:
+                free.put(item[-1])
                 continue
             n, off1, ln1, off2, ln2, seq, so, cur1, cur2, buf = item
             tc0 = time.perf_counter()
@@ -306,8 +320,11 @@ def demux_native(fastq1: str, fastq2: Optional[str], config, output_directory: s
                 qw.put((n, off1, ln1, off2, ln2, cls, ks, ke, cur1, cur2, buf, pending, used))
     except BaseException as e:  # noqa: BLE001
         errors.append(e)
-        while q_in.get() is not None:
-            pass
+        while True:
+            item = q_in.get()
+            if item is None:
+                break
+            free.put(item[-1])
     finally:
         for qw in q_outs:
             qw.put(None)

@@ -203,3 +203,56 @@ def test_parallel_inflate_rejects_a_corrupt_member(tmp_path):
         assert f.size == -1
     finally:
         f.close()
+
+
+@pytest.mark.parametrize("where", ["classify", "write"])
+def test_pipeline_errors_propagate_instead_of_hanging(tmp_path, where):
+    """An error in the classify stage (a BdxError) or in the writer (ENOSPC, a vanished directory) with many batches still
+    to come must come out of execute_demultiplexing: no batch buffer may stay behind on an error path (the reader waits
+    for buffers) — the pipeline used to hang there, holding the GPU context."""
+    import shutil
+    import threading
+
+    bcs = synth.make_barcodes(6, 12, seed=7, min_hamming=4)
+    seq, off, _ = synth.make_ragged_reads(bcs, 2000, 20, 60, seed=7)
+    seqs = [seq[off[i]:off[i + 1]].tobytes() for i in range(2000)]
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    fq = str(tmp_path / "reads.fastq")
+    _fastq(fq, seqs)
+    out_dir = tmp_path / "out"
+    calls = [0]
+
+    class Failing:
+        def __init__(self, cfg):
+            self.inner = H.oracle_factory(cfg)
+            self.counts = self.inner.counts
+
+        def classify(self, s, o):
+            calls[0] += 1
+            if calls[0] == 2:
+                if where == "classify":
+                    raise RuntimeError("classifier failed on batch 2")
+                shutil.rmtree(out_dir)  # the writer's next open fails
+            return self.inner.classify(s, o)
+
+        def close(self):
+            pass
+
+    result = {}
+
+    def run():
+        try:
+            H.bdx.execute_demultiplexing(fq, str(bc), str(out_dir), max_error_rate=0.2, _classifier_factory=Failing, _io="native",
+                                         _batch_reads=100)  # 20 batches
+            result["ok"] = True
+        except BaseException as e:  # noqa: BLE001
+            result["err"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "the pipeline hangs on an error"
+    assert "err" in result, result
+    if where == "classify":
+        assert "batch 2" in str(result["err"])

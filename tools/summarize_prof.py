@@ -16,7 +16,10 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
-summary = {"tag": tag, "reads_per_launch": reads, "kernels": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha16: the identity of the kernels these counters were collected on — run this
+              # script on the tree the profile was taken from, before touching csrc/ again)
+summary = {"tag": tag, "reads_per_launch": reads, "kernel_source_sha16": bench.kernel_source_sha16(), "kernels": {}}
 for d in pmc_dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
