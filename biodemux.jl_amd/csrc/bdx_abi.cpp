@@ -921,6 +921,39 @@ int build_pair_tables(bdx_ctx *ctx) {
     int kmax = 0, track = 1 << 20, mmin = 1 << 20, g = 0;
     struct Bc { int g, m, kb; const uint8_t *bc; };
     std::vector<Bc> bcs;
+    // SAME-DIAGONAL variants (split configs whose indels cost more than their mismatches — the reference's demo2 options:
+    // mismatch 1, indel 2, budget 6 of 24): an alignment with g indels lies on at most g + 1 diagonals and has at most
+    // e(g) = g + floor((ae - g indel) / mismatch) operations; with P disjoint pieces, P - e(g) >= g + 2 for every possible g
+    // puts two intact pieces on ONE diagonal (an intact piece cannot span an indel) — far more selective than "two pieces
+    // within kb diagonals", and valid beyond the classic variant's 4 (kb + 2) <= m.  Tried per piece length: 4 bases
+    // (six pieces), then 3 (eight).  The alignment then lies within g_max columns of that diagonal (`spread`).
+    int sd_pl = 0, sd_spread = 0;
+    if (split && sgm && c.mismatch >= 1 && c.indel >= 1 && groups == 1) {
+        for (int pl = 4; pl >= 3 && !sd_pl; --pl) {
+            bool ok = true;
+            int spread = 0;
+            for (int k = 0; k < npass && ok; ++k) {
+                const bdx_pass_t &p = c.pass[k];
+                for (int b = 0; b < p.n_barcodes && ok; ++b) {
+                    const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
+                    const long long ae = (long long)std::floor(c.max_error_rate * (double)m);
+                    if (ae < 0) continue;
+                    const int P = std::min(pl == 4 ? 6 : 8, m / pl);
+                    const long long gmax = ae / c.indel;
+                    for (long long gg = 0; gg <= gmax && ok; ++gg) {
+                        const long long e = gg + (ae - gg * c.indel) / c.mismatch;
+                        ok = (long long)P - e >= gg + 2;
+                    }
+                    if (gmax > spread) spread = (int)gmax;
+                    if (ae / cmin > 15 || m - (int)(ae / cmin) - 1 < 12) ok = false;  // (sweep budget field / score tracking from column 12)
+                }
+            }
+            if (ok && spread <= 8) {
+                sd_pl = pl;
+                sd_spread = spread;
+            }
+        }
+    }
     for (int k = 0; k < npass; ++k) {
         const bdx_pass_t &p = c.pass[k];
         for (int b = 0; b < p.n_barcodes; ++b, ++g) {
@@ -948,11 +981,11 @@ int build_pair_tables(bdx_ctx *ctx) {
                 continue;
             }
             const long long kb = ae / cmin;
-            if (kb > 4 || 4 * (kb + 2) > m) return BDX_OK;
+            if (!sd_pl && (kb > 4 || 4 * (kb + 2) > m)) return BDX_OK;
             int dmax = 255;
             for (long long d = 0; d <= kb; ++d)  // lone-survivor accept threshold of the replay, as in build_wave_tables
                 if (d <= ae && (double)d / (double)m <= c.max_error_rate) dmax = (int)d;
-            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8) | ((uint32_t)dmax << 16);
+            meta[(size_t)g] = (uint32_t)m | ((uint32_t)kb << 8) | ((uint32_t)dmax << 16) | ((uint32_t)sd_spread << 24);
             if ((int)kb > kmax) kmax = (int)kb;
             if (m - (int)kb - 1 < track) track = m - (int)kb - 1;
             if (m < mmin) mmin = m;
@@ -960,15 +993,18 @@ int build_pair_tables(bdx_ctx *ctx) {
         }
     }
     if (bcs.empty() || track < 12) return BDX_OK;
-    const int KB = kmax <= 3 ? 3 : 4, P = KB + 2;
-    std::vector<uint32_t> tab((size_t)groups * P * 256 * (size_t)(estride / 4), 0u);
-    for (const Bc &x : bcs)
-        for (int t = 0; t < x.kb + 2; ++t) {
+    const int KB = sd_pl == 4 ? 8 : sd_pl == 3 ? 9 : kmax <= 3 ? 3 : 4;  // (the kernel's variant number)
+    const int PL = sd_pl ? sd_pl : 4, P = sd_pl == 4 ? 6 : sd_pl == 3 ? 8 : KB + 2, NK = 1 << (2 * PL);
+    std::vector<uint32_t> tab((size_t)groups * P * NK * (size_t)(estride / 4), 0u);
+    for (const Bc &x : bcs) {
+        const int np = sd_pl ? std::min(P, x.m / PL) : x.kb + 2;  // pieces of this barcode
+        for (int t = 0; t < np; ++t) {
             uint32_t key = 0;
-            for (int i = 0; i < 4; ++i) key |= (uint32_t)((x.bc[4 * t + i] >> 1) & 3) << (2 * i);
+            for (int i = 0; i < PL; ++i) key |= (uint32_t)((x.bc[PL * t + i] >> 1) & 3) << (2 * i);
             const int grp = x.g >> 7, gl = x.g & 127;
-            tab[(((size_t)grp * P + (size_t)t) * 256 + key) * (size_t)(estride / 4) + (size_t)(gl >> 5)] |= 1u << (gl & 31);
+            tab[(((size_t)grp * P + (size_t)t) * NK + key) * (size_t)(estride / 4) + (size_t)(gl >> 5)] |= 1u << (gl & 31);
         }
+    }
     wp.q = 4;
     wp.n_barcodes = Btot;
     wp.b0 = c.pass[0].n_barcodes;
@@ -977,6 +1013,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp.n_ent = 0;
     wp.track_from = track > 28 ? 28 : track;
     wp.pairs_kb = KB;
+    wp.pairs_spread = sd_pl ? sd_spread : KB;
     wp.nw = nw;
     wp.groups = groups;
     wp.ranged = ranged ? 1 : 0;
@@ -1030,14 +1067,15 @@ bool size_pairs(bdx_ctx *ctx, BdxWavePlan &wp, int read_len) {
     const int rw = 16;
     const int span = rw * slot + 16;
     if (span > 6 * 1024) return false;  // (instantiated: three and six 16-byte vectors per lane)
-    int cpr = ((read_len - ctx->pair_mmin + wp.pairs_kb + 8) >> 4) + 1;
+    int cpr = ((read_len - ctx->pair_mmin + wp.pairs_spread + 8) >> 4) + 1;
     if (read_len < ctx->pair_mmin) cpr = 1;
     if (cpr > slot / 16) cpr = slot / 16;
     if (cpr < 1) cpr = 1;
     const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
     // (31 chance flags per read at 96 barcodes and kb = 4: the queue holds a 16-read tile's worth; with more barcodes it is
     // drained several times per tile; a tile whose queue runs over between two drains is handed on / swept whole)
-    wp.hq_cap = wp.groups > 1 ? 1024 : 56 * rw;
+    // (same-diagonal variants: ~80 chance flags per read at 96 barcodes of eight 3-base pieces — the queue is drained inside the scan)
+    wp.hq_cap = wp.groups > 1 ? 1024 : wp.pairs_kb >= 8 ? 1280 : 56 * rw;
     wp.sq_cap = 0;
     const size_t area = bdx_wave_area_bytes(rw, span, true, wp.hq_cap, 0, wp.cand_words + (wp.ranged ? 4 : 0));
     int best = 0;
@@ -2332,11 +2370,32 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 HIP_TRY(ctx, poison_check(list2, count2, true, false));
             }
         }
+        // Same-diagonal pairs mode as the ONLY filter of a split config without tiers (weighted costs whose full budget is beyond
+        // every seeded variant — the reference's demo2 options): every read of the batch is laid out in slots and scanned;
+        // masks + windows of all reads go to the exact kernel's dense launch.
+        bool pairs_all = false;
+        if (!tiered && split && windows && !dense_w && !wsplit0 && !wave0k && !ctx->dev.vlen && ctx->fs[0].pplan.enabled &&
+            ctx->fs[0].pplan.pairs_kb >= 8 && ctx->fs[0].pplan.split && size_pairs(ctx, batch_len)) {
+            const BdxWavePlan &pp = ctx->fs[0].pplan;
+            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
+            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
+            if (ctx->tune.poison) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
+            }
+            unsigned int *count_all = (unsigned int *)(scratch + 192);
+            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, nullptr, nullptr, n_reads, (uint8_t *)ctx->d_gseq.p,
+                                           (int *)ctx->d_glen.p, pp.slot, batch_len, ctx->n_cu, ctx->stream, count_all));
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, nullptr,
+                                          count_all, o, nullptr, nullptr, nullptr, ctx->stream, ctx->tune.debug >> 8, &wsp_all));
+            ctx->pair_launches += 1;
+            pairs_all = true;
+        }
         ctx->F().bplan.d_tile_counter = (int *)(scratch + 64);
         ctx->F().bplan.dense_w = dense_w;
         ctx->F().bplan.grid_override = ctx->tune.grid;
         ctx->F().bplan.dbg = ctx->tune.debug;
-        if (pairs && split && !pairs_k) {
+        if ((pairs && split && !pairs_k) || pairs_all) {
             // (tier 0's filter already ran: the pairs mode wrote the listed reads' masks and windows)
         } else if (wsplit0) {
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -2374,6 +2433,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         if (wsplit0) ctx->path = "wave+verify";
         if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
+        if (pairs_all) ctx->path = "pairs(diag)+verify";
         if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = "wave > " + ctx->path;
         if (wave0k) ctx->path = "wave(end) > " + ctx->path;

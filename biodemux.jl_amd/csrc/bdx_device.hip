@@ -390,15 +390,19 @@ __global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list
 // only touched when bytes of the read lie in it).
 namespace {
 __global__ __launch_bounds__(256) void bdx_gather_kernel(const uint8_t *seq, const long long *off, const uint32_t *list, const unsigned int *count,
-                                                         long long n_cap, uint8_t *slots, int *lens, const int slot, const int max_len) {
-    long long n = (long long)*count;
+                                                         long long n_cap, uint8_t *slots, int *lens, const int slot, const int max_len,
+                                                         unsigned int *count_out) {
+    // list == NULL: every read of the batch, in order (the pairs mode as the only filter of a config without tiers); the
+    // number of reads then is n_cap, and it is left in *count_out for the kernel that walks the slots
+    long long n = list ? (long long)*count : n_cap;
     if (n > n_cap) n = n_cap;
+    if (!list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = (unsigned int)n;
     // sixteen lanes per read (four reads per wave side by side: the list -> offsets -> bytes chain is latency-bound)
     const int sub = threadIdx.x & 15;
     const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
     const int dw = slot >> 2;
     for (long long k = grp; k < n; k += ngrp) {
-        const uint32_t id = list[k];
+        const uint32_t id = list ? list[k] : (uint32_t)k;
         const long long o0 = off[id];
         long long len = off[id + 1] - o0;
         const bool fits = len >= 0 && len <= (long long)max_len;  // (the scan was planned for reads up to max_len <= slot)
@@ -428,13 +432,15 @@ __global__ __launch_bounds__(256) void bdx_gather_kernel(const uint8_t *seq, con
 }  // namespace
 
 hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const uint32_t *d_list, const unsigned int *d_count,
-                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream) {
-    if (!d_seq || !d_off || !d_list || !d_count || !d_slots || !d_lens || slot < 16 || (slot & 15) || max_len > slot) return hipErrorInvalidValue;
+                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream,
+                             unsigned int *d_count_out) {
+    if (!d_seq || !d_off || (d_list && !d_count) || (!d_list && !d_count_out) || !d_slots || !d_lens || slot < 16 || (slot & 15) || max_len > slot)
+        return hipErrorInvalidValue;
     long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * 8;
     const long long useful = (n_cap + 15) / 16;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bdx_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq, d_off, d_list, d_count, n_cap, d_slots, d_lens, slot, max_len);
+    hipLaunchKernelGGL(bdx_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq, d_off, d_list, d_count, n_cap, d_slots, d_lens, slot, max_len, d_count_out);
     return hipGetLastError();
 }
 

@@ -199,7 +199,9 @@ struct BdxWavePlan {
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
     // tables [kb + 2][256] of barcode masks, there is no hash
-    int pairs_kb;          // 0: single seeds; else the largest budget (3 / 4)
+    int pairs_kb;          // 0: single seeds; 3 / 4: two intact 4-base pieces within that many diagonals (the largest budget); 8 / 9: two intact
+                           // pieces on the SAME diagonal, of six 4-base / eight 3-base pieces (configs whose indels cost more than their mismatches)
+    int pairs_spread;      // pairs mode: columns a flagged alignment can lie off its diagonal (classic: the budget; same-diagonal variants: the largest number of indels)
     int nw;                // words of a barcode mask
     int groups;            // groups of 128 barcodes (more than 128 barcodes: one set of piece tables per group, nw = 4)
     int slot;              // bytes per gathered read
@@ -250,7 +252,8 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
                             uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);
 // Gathers the reads of a list into slots of `slot` bytes (padded with 'N') + their lengths (bdx_device.hip).
 hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const uint32_t *d_list, const unsigned int *d_count,
-                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream);
+                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream,
+                             unsigned int *d_count_out = nullptr);  // d_list == NULL: every read of the batch, their number left in *d_count_out
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
                            double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr,

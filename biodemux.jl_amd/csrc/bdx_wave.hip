@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     };
     const auto load_gid = [&](const int t) -> uint32_t {
         const long long r0 = (long long)t * RW;
-        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? a.idmap[r0 + lane] : 0u;
+        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? (a.idmap ? a.idmap[r0 + lane] : (uint32_t)(r0 + lane)) : 0u;
     };
     const auto rlen = [&](const int t) -> int { return PAIRS ? rl[t] : fb[t + 1] - fb[t]; };
     u32x4 v[NV];
@@ -638,7 +638,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u);
                 valid = valid && kk != 255;
                 const int n = rl[t];
-                int lo = dlo - kk, hi = dlo + wd + mm + kk;
+                const int sp = KB >= 8 ? (int)(mt >> 24) : kk;  // columns an alignment can lie off the flagged diagonal: its indels
+                int lo = dlo - sp, hi = dlo + wd + mm + sp;
                 const int wlo = win_lo(t, b >= a.B0), whi = win_hi(t, b >= a.B0, n);
                 lo = lo < wlo ? wlo : lo;
                 hi = hi > whi ? whi : hi;
@@ -661,12 +662,20 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // `twice` = barcodes with two pieces on this diagonal, `once & near` = one here and one on the KB diagonals
             // before.  Flagged barcodes are swept over that window; every other pair has a distance beyond its budget.
             // Keys of positions outside the read are whatever the image holds there: they can only add sweeps.
-            constexpr int P = KB + 2;
+            // SAME-DIAGONAL variants (KB = 8: six 4-base pieces, KB = 9: eight 3-base pieces; ND = 0): configs whose indels cost
+            // more than their mismatches (the reference's own demo2 options: mismatch 1, indel 2, budget 6 of 24).  An alignment
+            // with g indels lies on at most g + 1 diagonals and has at most e(g) = g + floor((budget - g indel) / mismatch)
+            // operations; when P - e(g) >= g + 2 for every g, two of its intact pieces share a diagonal (build_pair_tables checks
+            // it per barcode), and it lies within the columns [d - g_max, d + m + g_max) of that diagonal d (`spread` in meta).
+            constexpr int PL = KB == 9 ? 3 : 4;         // bases per piece
+            constexpr int P = KB == 8 ? 6 : KB == 9 ? 8 : KB + 2;
+            constexpr int ND = KB >= 8 ? 0 : KB;        // the second piece may sit on one of the ND diagonals before
             constexpr int ESTRIDE = NW <= 2 ? 8 : 16;   // bytes per table entry
-            constexpr int TSTRIDE = 256 * ESTRIDE;      // bytes per piece table (the tables start at LDS address 0)
-            constexpr int XLO = -8 - KB;                // first position, relative to the chunk, whose key is needed
-            constexpr int NX = 16 + KB + 4 * (P - 1);   // positions
-            uint32_t amask = 0xFFu * ESTRIDE;
+            constexpr int TSTRIDE = (1 << (2 * PL)) * ESTRIDE;  // bytes per piece table (the tables start at LDS address 0)
+            constexpr int XLO = -8 - ND;                // first position, relative to the chunk, whose key is needed
+            constexpr int NX = 16 + ND + PL * (P - 1);  // positions
+            static_assert(7 + PL * (P - 1) + PL - 1 <= 31, "the keys of a chunk come out of three words of the 2-bit image");
+            uint32_t amask = ((1u << (2 * PL)) - 1u) * ESTRIDE;
             asm volatile("" : "+v"(amask));
             const int s16 = a.slot >> 4;
             const int items = BDX_DBG(8) ? 0 : nr * a.cpr;
@@ -689,21 +698,22 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 };
                 const auto key_addr = [&](const int xi) __attribute__((always_inline)) -> uint32_t {
                     const int bit = 2 * (XLO + xi + 16) - (ESTRIDE == 16 ? 4 : 3);  // the key lands at bit 4 (3): times 16 (8)
+                    static_assert(2 * (XLO + 16) - 4 >= 0, "the first key's bits start inside the first word");
                     const int wi = bit >> 5, sh = bit & 31;
                     const uint32_t lo = wi == 0 ? wm1 : (wi == 1 ? w0 : w1);
                     const uint32_t hi = wi == 0 ? w0 : (wi == 1 ? w1 : 0u);
                     return __builtin_amdgcn_alignbit(hi, lo, sh) & amask;
                 };
                 const auto diagonals = [&](const uint32_t gbase) __attribute__((always_inline)) {
-                    uint32_t Ah[KB][NW];  // barcodes with any piece on each of the previous KB diagonals
+                    uint32_t Ah[ND > 0 ? ND : 1][NW];  // barcodes with any piece on each of the previous ND diagonals
 #pragma unroll
-                    for (int j = -KB; j < 16; ++j) {
+                    for (int j = -ND; j < 16; ++j) {
 #pragma unroll
-                        for (int xi = (j == -KB ? 0 : j + KB + 4 * (P - 1)); xi <= j + KB + 4 * (P - 1); ++xi) ad[xi] = key_addr(xi);
+                        for (int xi = (j == -ND ? 0 : j + ND + PL * (P - 1)); xi <= j + ND + PL * (P - 1); ++xi) ad[xi] = key_addr(xi);
                         uint32_t H[P][NW];
 #pragma unroll
                         for (int tt = 0; tt < P; ++tt) {
-                            const uint32_t ea = ad[j - 8 + 4 * tt - XLO] + gbase + (uint32_t)(tt * TSTRIDE);
+                            const uint32_t ea = ad[j - 8 + PL * tt - XLO] + gbase + (uint32_t)(tt * TSTRIDE);
                             if constexpr (NW == 1) {
                                 H[tt][0] = *(const LDS uint32_t *)(bm + ea);
                             } else if constexpr (NW == 2) {
@@ -728,14 +738,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                                 once |= H[tt][w];
                             }
                             if (j >= 0) {
-                                uint32_t near = Ah[0][w];
+                                uint32_t F = twice;
+                                if constexpr (ND > 0) {
+                                    uint32_t near = Ah[0][w];
 #pragma unroll
-                                for (int u = 1; u < KB; ++u) near |= Ah[u][w];
-                                const uint32_t F = twice | (once & near);
+                                    for (int u = 1; u < ND; ++u) near |= Ah[u][w];
+                                    F |= once & near;
+                                }
                                 Fl[w] |= F;
                                 dmw[w] = (dmw[w] << 1) | (F != 0u ? 1u : 0u);  // bit 15 - j
                             }
-                            Ah[(j + KB) % KB][w] = once;  // (replaces the oldest)
+                            if constexpr (ND > 0) Ah[(j + ND) % ND][w] = once;  // (replaces the oldest)
                         }
                     }
                 };
@@ -760,7 +773,73 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         }
                     }
                 };
-                if constexpr (!MG) {
+                if constexpr (KB >= 8) {
+                    // Same-diagonal variants: ~90 chance flags per read at 96 barcodes of eight 3-base pieces, i.e. several per lane
+                    // and mask word — one run of diagonals per lane would span most of its sixteen and make every sweep 40-odd
+                    // columns.  The flags are appended per group of THREE diagonals: a sweep's window is m + 2 spread + 2 <= 32
+                    // columns (one block), and the append loops take as many trips in total as one append of all sixteen.
+                    // (all lanes walk the diagonals — the appends are wave-wide; lanes without a chunk look at read 0 and drop their flags)
+                    keys();
+                    const uint32_t onm = on ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                    for (int j0 = 0; j0 < 16; j0 += 3) {
+                        const int j1 = j0 + 2 < 15 ? j0 + 2 : 15;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
+#pragma unroll
+                        for (int j = j0; j <= j1; ++j) {
+#pragma unroll
+                            for (int xi = (j == 0 ? 0 : j + PL * (P - 1)); xi <= j + PL * (P - 1); ++xi) ad[xi] = key_addr(xi);
+                            uint32_t H[P][NW];
+#pragma unroll
+                            for (int tt = 0; tt < P; ++tt) {
+                                const uint32_t ea = ad[j - 8 + PL * tt - XLO] + (uint32_t)(tt * TSTRIDE);
+                                if constexpr (NW <= 2) {
+                                    const u32x2 x = *(const LDS u32x2 *)(bm + ea);
+                                    H[tt][0] = x[0];
+                                    if constexpr (NW == 2) H[tt][1] = x[1];
+                                } else {
+                                    const u32x4 x = *(const LDS u32x4 *)(bm + ea);
+                                    H[tt][0] = x[0];
+                                    H[tt][1] = x[1];
+                                    H[tt][2] = x[2];
+                                    if constexpr (NW == 4) H[tt][3] = x[3];
+                                }
+                            }
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                uint32_t once = H[0][w] | H[1][w];
+                                uint32_t twice = H[0][w] & H[1][w];
+#pragma unroll
+                                for (int tt = 2; tt < P; ++tt) {
+                                    twice |= once & H[tt][w];
+                                    once |= H[tt][w];
+                                }
+                                const uint32_t F = twice & onm;
+                                Fl[w] |= F;
+                                dmw[w] = (dmw[w] << 1) | (F != 0u ? 1u : 0u);  // bit j1 - j
+                            }
+                        }
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            uint32_t bits = Fl[w];
+                            const int jlo = j1 - (31 - (int)__builtin_clz(dmw[w] | 1u)), jhi = j1 - (int)__builtin_ctz(dmw[w] | 0x8u);
+                            const uint32_t common = ((uint32_t)t << 9) | ((uint32_t)(jhi - jlo) << 13) | ((uint32_t)(16 * c - 8 + jlo + 64) << 17) | (uint32_t)(32 * w);
+                            unsigned long long mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                            while (mk) {
+                                const int k = nhq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                if (bits) {
+                                    const int bi = __builtin_ctz(bits);
+                                    bits &= bits - 1u;
+                                    if (k < HQ) hq[k] = common | (uint32_t)bi;
+                                }
+                                nhq += (int)__builtin_popcountll(mk);
+                                mk = __builtin_amdgcn_ballot_w64(bits != 0u);
+                            }
+                        }
+                    }
+                    if (nhq > HQ - 768) drain();  // (the queue is swept whenever a round of flags might not fit any more)
+                } else if constexpr (!MG) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w) Fl[w] = dmw[w] = 0u;
                     if (on) {
@@ -1401,7 +1480,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
                             const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,
                             uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
-    if (wp.pairs_kb <= 0 || !d_slots || !d_lens || !d_idmap || !d_count) return hipErrorInvalidValue;
+    if (wp.pairs_kb <= 0 || !d_slots || !d_lens || !d_count) return hipErrorInvalidValue;  // (d_idmap == NULL: slot k holds read k of the batch)
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, sp);
     a.seq = d_slots;
@@ -1427,10 +1506,13 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
      : wp.kend ? launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV, false, 1>(a, lds, wp.waves, blocks, stream)                    \
                : launch_wave<RWV, TFV, NVV, 4, false, KBV, NWV>(a, lds, wp.waves, blocks, stream))
 #define BDX_PAIRS_NW(RWV, TFV, NVV, KBV) (wp.groups > 1 ? launch_wave<RWV, TFV, NVV, 4, false, KBV, 4, true>(a, lds, wp.waves, blocks, stream) : wp.nw <= 2 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, TFV, NVV, KBV, 4))
-#define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
+// (same-diagonal variants 8 / 9: weighted costs, i.e. always split mode)
+#define BDX_PAIRS_SD(RWV, TFV, NVV, KBV) (wp.nw <= 2 ? launch_wave<RWV, TFV, NVV, 4, true, KBV, 2>(a, lds, wp.waves, blocks, stream) : wp.nw == 3 ? launch_wave<RWV, TFV, NVV, 4, true, KBV, 3>(a, lds, wp.waves, blocks, stream) : launch_wave<RWV, TFV, NVV, 4, true, KBV, 4>(a, lds, wp.waves, blocks, stream))
+#define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb == 8 ? BDX_PAIRS_SD(RWV, TFV, NVV, 8) : wp.pairs_kb == 9 ? BDX_PAIRS_SD(RWV, TFV, NVV, 9) : wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
 #define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
-    if (wp.pairs_kb > 4 || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
+    if ((wp.pairs_kb > 4 && wp.pairs_kb != 8 && wp.pairs_kb != 9) || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
+    if (wp.pairs_kb >= 8 && (!wp.split || wp.groups > 1)) return hipErrorInvalidValue;
     if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return hipErrorInvalidValue;
     if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
     if ((wp.kend == 2) != (wp.kend && (a.trim0 == 3 || a.trim1 == 3))) return hipErrorInvalidValue;
@@ -1440,6 +1522,7 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     return hipErrorInvalidValue;
 #undef BDX_PAIRS_TF
 #undef BDX_PAIRS_KB
+#undef BDX_PAIRS_SD
 #undef BDX_PAIRS_NW
 #undef BDX_PAIRS_SP
 }

@@ -340,3 +340,52 @@ def test_pairs_dual_known_score(monkeypatch):
     cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 100, ids=[f"x{i}" for i in range(100)], is_dual=True, bc_seqs2=b2,
                             bc_lengths_no_N2=[24] * 60, ids2=[f"y{i}" for i in range(60)], max_error_rate=0.2)
     _with_and_without(cfg, seq, off, monkeypatch, want_pass=False)
+
+
+# ---- same-diagonal variants: configs whose indels cost more than their mismatches (round 4) ----
+@pytest.mark.parametrize("kw,path", [
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), "pairs(diag)+verify"),   # the reference's demo2 options: budget 6 of 24, eight 3-base pieces
+    (dict(max_error_rate=0.25, mismatch=1, indel=2), None),    # (without min_delta: tier 1 in front, the variant is tier 0's filter)
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, trim_side=3), None),
+    (dict(max_error_rate=0.25, mismatch=1, indel=3, min_delta=0.1, trim_side=5), None),
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, summary=True, min_delta=0.15), "pairs(diag)+verify"),
+    (dict(max_error_rate=0.2, mismatch=1, indel=2), None),     # budget 4: six 4-base pieces (as tier 0 behind tier 1)
+    (dict(max_error_rate=0.34, mismatch=2, indel=4, min_delta=0.1), None),  # budget 8 = 4 mismatches
+    (dict(max_error_rate=0.3, mismatch=1, indel=2), None),     # budget 7: no variant qualifies -> plain sweep
+], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else "")
+def test_pairs_same_diagonal_variants(kw, path, monkeypatch):
+    bcs = synth.make_barcodes(96, 24, seed=71)
+    seq, off, _ = synth.make_reads(bcs, 40000, 150, seed=72, sub=0.06, ins=0.015, dele=0.015, repeat=dict(frac=0.1))
+    cfg = _cfg(bcs, **kw)
+    exp = _with_and_without(cfg, seq, off, monkeypatch, expect_pairs=None if path is None else True)
+    assert (exp["bc1"] > 0).mean() > 0.3
+    if path is not None:
+        with H.bdx.HipClassifier(cfg) as hc:
+            hc.classify(seq, off)
+            assert hc.kernel_path == path, hc.kernel_path
+
+
+def test_pairs_same_diagonal_dual_and_other_lengths(monkeypatch):
+    b1 = synth.make_barcodes(24, 24, seed=73)
+    b2 = synth.make_barcodes(16, 24, seed=74)
+    seq, off, _ = synth.make_reads(b1, 30000, 150, seed=75, plant_lo=0, plant_hi=40, second=(b2, 100, 126), sub=0.06, ins=0.015, dele=0.015)
+    cfg = H.bdx.DemuxConfig(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+                            bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.25, mismatch=1, indel=2,
+                            min_delta=0.1, trim_side=5, trim_side2=3)
+    _with_and_without(cfg, seq, off, monkeypatch, expect_pairs=None)
+    for m, rate in ((20, 0.25), (28, 0.25), (32, 0.2), (30, 0.2)):
+        bcs = synth.make_barcodes(64, m, seed=76 + m, min_hamming=max(4, m // 4))
+        seq, off, _ = synth.make_ragged_reads(bcs, 20000, 30, 150, seed=77 + m, sub=0.06, ins=0.015, dele=0.015)
+        _with_and_without(_cfg(bcs, max_error_rate=rate, mismatch=1, indel=2, min_delta=0.1), seq, off, monkeypatch, expect_pairs=None)
+
+
+def test_pairs_same_diagonal_low_complexity_overflow(monkeypatch):
+    """Reads that flag nearly every (barcode, diagonal): the queue runs over, the tile is swept whole."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    bcs = synth.make_barcodes(96, 24, seed=79)
+    seq, off, _ = synth.make_reads(bcs, 12000, 150, seed=80, sub=0.05, ins=0.01, dele=0.01)
+    seq = seq.copy()
+    for i in range(0, 12000, 3):  # two-letter reads around the planted barcode
+        r = seq[off[i]:off[i + 1]]
+        r[:] = np.where(rng.random(150) < 0.85, np.frombuffer(b"ACAC" * 38, dtype=np.uint8)[:150], r)
+    _with_and_without(_cfg(bcs, max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), seq, off, monkeypatch)
