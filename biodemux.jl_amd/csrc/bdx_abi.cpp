@@ -927,9 +927,19 @@ int build_pair_tables(bdx_ctx *ctx) {
     // puts two intact pieces on ONE diagonal (an intact piece cannot span an indel) — far more selective than "two pieces
     // within kb diagonals", and valid beyond the classic variant's 4 (kb + 2) <= m.  Tried per piece length: 4 bases
     // (six pieces), then 3 (eight).  The alignment then lies within g_max columns of that diagonal (`spread`).
+    // Order of preference: six 4-base pieces on one diagonal (strictly more selective than the classic variant), the classic
+    // variant (two 4-base pieces within kb diagonals) where its conditions hold, eight 3-base pieces on one diagonal.
+    bool classic_ok = true;
+    for (int k = 0; k < npass; ++k)
+        for (int b = 0; b < c.pass[k].n_barcodes; ++b) {
+            const int m = (int)(c.pass[k].bc_off[b + 1] - c.pass[k].bc_off[b]);
+            const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);
+            if (ae >= 0 && (ae / cmin > 4 || 4 * (ae / cmin + 2) > m)) classic_ok = false;
+        }
     int sd_pl = 0, sd_spread = 0;
     if (split && sgm && c.mismatch >= 1 && c.indel >= 1 && groups == 1) {
         for (int pl = 4; pl >= 3 && !sd_pl; --pl) {
+            if (pl == 3 && classic_ok) break;
             bool ok = true;
             int spread = 0;
             for (int k = 0; k < npass && ok; ++k) {
@@ -1046,7 +1056,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     bool trims_ok = true;
     for (int k = 0; k < npass; ++k) trims_ok = trims_ok && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE;
     if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !c.need_traceback &&
-        !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1) {
+        !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1 && wp.pairs_kb <= 4) {  // (the same-diagonal variants only exist in split mode)
         F.pplan_k = wp;
         F.pplan_k.split = 0;
         F.pplan_k.cand_words = c.is_dual ? 4 : 0;
@@ -1063,11 +1073,12 @@ bool size_pairs(bdx_ctx *ctx, int read_len) { return size_pairs(ctx, ctx->fs[0].
 bool size_pairs(bdx_ctx *ctx, BdxWavePlan &wp, int read_len) {
     if (!wp.enabled || ctx->dev.vlen) return false;
     if (read_len < 1) read_len = 1;
-    const int slot = (read_len + 15) & ~15;
+    // a read's slot in the tile's images: its bytes are fetched as aligned 16-byte vectors, so it starts up to 15 positions in
+    const int slot = (read_len + 15 + 15) & ~15;
     const int rw = 16;
     const int span = rw * slot + 16;
-    if (span > 6 * 1024) return false;  // (instantiated: three and six 16-byte vectors per lane)
-    int cpr = ((read_len - ctx->pair_mmin + wp.pairs_spread + 8) >> 4) + 1;
+    if (span > 6 * 1024 + 16) return false;  // (instantiated: three and six 16-byte vectors per lane)
+    int cpr = ((15 + read_len - ctx->pair_mmin + wp.pairs_spread + 8) >> 4) + 1;  // (diagonals are counted from the slot's start)
     if (read_len < ctx->pair_mmin) cpr = 1;
     if (cpr > slot / 16) cpr = slot / 16;
     if (cpr < 1) cpr = 1;
@@ -1097,6 +1108,7 @@ bool size_pairs(bdx_ctx *ctx, BdxWavePlan &wp, int read_len) {
     wp.span_cap = span;
     wp.slot = slot;
     wp.cpr = cpr;
+    wp.read_len_hint = read_len;
     return true;
 }
 
@@ -1995,8 +2007,6 @@ void bdx_destroy(bdx_ctx *ctx) {
         f.pair_tables.release();
     }
     ctx->d_wlist.release();
-    ctx->d_gseq.release();
-    ctx->d_glen.release();
     ctx->d_tier.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
@@ -2326,19 +2336,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             // known-end class: the pairs mode answers the listed reads itself (verdict + trimmed keep range); what it cannot
             // answer goes on to the split path in list mode
             const BdxWavePlan &pp = ctx->fs[0].pplan_k;
-            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
-            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
-            if (ctx->tune.poison) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
-            }
-            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, t0.in_list, t0.in_count, n_reads, (uint8_t *)ctx->d_gseq.p,
-                                           (int *)ctx->d_glen.p, pp.slot, tier_len, ctx->n_cu, ctx->stream));
+            if (ctx->tune.poison) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
             uint32_t *list2 = (uint32_t *)ctx->d_wlist.p;
             unsigned int *count2 = (unsigned int *)(scratch + 320);
-            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, t0.in_list,
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, t0.in_list,
                                           t0.in_count, o, ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, nullptr));
             ctx->pair_launches += 1;
             pairs = pairs_k = true;
@@ -2348,19 +2350,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         } else
         if (tiered && (!split || windows) && !dense_w && size_pairs(ctx, tier_len)) {
             const BdxWavePlan &pp = ctx->fs[0].pplan;
-            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
-            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
             if (!split) HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
-            if (ctx->tune.poison) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
-                if (!split) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
-            }
-            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, t0.in_list, t0.in_count, n_reads, (uint8_t *)ctx->d_gseq.p,
-                                           (int *)ctx->d_glen.p, pp.slot, tier_len, ctx->n_cu, ctx->stream));
+            if (ctx->tune.poison && !split) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
             uint32_t *list2 = split ? nullptr : (uint32_t *)ctx->d_wlist.p;
             unsigned int *count2 = split ? nullptr : (unsigned int *)(scratch + 320);
-            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, t0.in_list,
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, t0.in_list,
                                           t0.in_count, o, split ? nullptr : ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, split ? &wsp_all : nullptr));
             ctx->pair_launches += 1;
             pairs = true;
@@ -2377,17 +2371,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (!tiered && split && windows && !dense_w && !wsplit0 && !wave0k && !ctx->dev.vlen && ctx->fs[0].pplan.enabled &&
             ctx->fs[0].pplan.pairs_kb >= 8 && ctx->fs[0].pplan.split && size_pairs(ctx, batch_len)) {
             const BdxWavePlan &pp = ctx->fs[0].pplan;
-            HIP_TRY(ctx, ctx->d_gseq.ensure((size_t)n_reads * (size_t)pp.slot + 64));
-            HIP_TRY(ctx, ctx->d_glen.ensure((size_t)n_reads * 4 + 64));
-            if (ctx->tune.poison) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_gseq.p, 0xA5, ctx->d_gseq.cap, ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_glen.p, 0xA5, ctx->d_glen.cap, ctx->stream));
-            }
-            unsigned int *count_all = (unsigned int *)(scratch + 192);
-            HIP_TRY(ctx, bdx_launch_gather(d_seq_bytes, (const long long *)d_seq_off, nullptr, nullptr, n_reads, (uint8_t *)ctx->d_gseq.p,
-                                           (int *)ctx->d_glen.p, pp.slot, batch_len, ctx->n_cu, ctx->stream, count_all));
-            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, (const uint8_t *)ctx->d_gseq.p, (const int *)ctx->d_glen.p, nullptr,
-                                          count_all, o, nullptr, nullptr, nullptr, ctx->stream, ctx->tune.debug >> 8, &wsp_all));
+            HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, nullptr,
+                                          nullptr, o, nullptr, nullptr, nullptr, ctx->stream, ctx->tune.debug >> 8, &wsp_all));
             ctx->pair_launches += 1;
             pairs_all = true;
         }

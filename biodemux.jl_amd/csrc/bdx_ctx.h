@@ -98,7 +98,6 @@ struct bdx_ctx {
     int64_t wave_launches = 0;  // launches of the wave-autonomous kernel
     int64_t pair_launches = 0;  // launches of its pairs mode
     int pair_mmin = 0;          // shortest barcode of the pairs plan
-    DevBuf d_gseq, d_glen;      // the listed reads gathered into slots + their lengths (input of the pairs mode)
     DevBuf d_dbg;            // [0] hand-over windows the exact kernel refused (not a window: defence in depth; must stay 0)
     DevBuf d_wlist;          // reads the wave kernel hands to the general kernel (plain configs; tiered ones use d_tier)
     hipStream_t own_stream = nullptr;

@@ -381,69 +381,6 @@ __global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list
 }
 }  // namespace
 
-// ---- gather: the reads of a list -> slots (input of the wave kernel's pairs mode, bdx_pairs.hip) ----
-// (HBM-bound: 1.4 M scattered 150-byte reads fetch 435 MB of cache lines and write 216 MB of slots in 0.16 ms; four reads
-// per trip side by side took the same time and moved 40 % more bytes.)
-// Read list[k] of the batch is copied to slots[k * slot .. ) and padded with 'N' up to the slot size; lens[k] is its
-// length, or -1 when it is longer than the planned length (the consumer hands such a read on).  Sixteen lanes per read, one lane per dword:
-// the source is unaligned, so every dword is funnelled out of the two aligned dwords it straddles (the second one is
-// only touched when bytes of the read lie in it).
-namespace {
-__global__ __launch_bounds__(256) void bdx_gather_kernel(const uint8_t *seq, const long long *off, const uint32_t *list, const unsigned int *count,
-                                                         long long n_cap, uint8_t *slots, int *lens, const int slot, const int max_len,
-                                                         unsigned int *count_out) {
-    // list == NULL: every read of the batch, in order (the pairs mode as the only filter of a config without tiers); the
-    // number of reads then is n_cap, and it is left in *count_out for the kernel that walks the slots
-    long long n = list ? (long long)*count : n_cap;
-    if (n > n_cap) n = n_cap;
-    if (!list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = (unsigned int)n;
-    // sixteen lanes per read (four reads per wave side by side: the list -> offsets -> bytes chain is latency-bound)
-    const int sub = threadIdx.x & 15;
-    const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((long long)gridDim.x * blockDim.x) >> 4;
-    const int dw = slot >> 2;
-    for (long long k = grp; k < n; k += ngrp) {
-        const uint32_t id = list ? list[k] : (uint32_t)k;
-        const long long o0 = off[id];
-        long long len = off[id + 1] - o0;
-        const bool fits = len >= 0 && len <= (long long)max_len;  // (the scan was planned for reads up to max_len <= slot)
-        if (!fits) len = 0;
-        if (sub == 0) lens[k] = fits ? (int)len : -1;
-        uint32_t *dst = (uint32_t *)(slots + (size_t)k * (size_t)slot);
-        for (int w = sub; w < dw; w += 16) {
-            const int b0 = 4 * w;
-            uint32_t v = 0x4E4E4E4Eu;
-            if (b0 < len) {
-                const uintptr_t A = (uintptr_t)(seq + o0 + b0);
-                const uint32_t *al = (const uint32_t *)(A & ~(uintptr_t)3);
-                const int mis = (int)(A & 3);
-                const int valid = (int)(len - b0);  // bytes of this dword that belong to the read
-                const uint32_t lo = al[0];
-                const uint32_t hi = (mis != 0 && 4 - mis < valid) ? al[1] : 0u;
-                v = mis ? __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)mis) : lo;
-                if (valid < 4) {
-                    const uint32_t keep = (1u << (8 * valid)) - 1u;
-                    v = (v & keep) | (0x4E4E4E4Eu & ~keep);
-                }
-            }
-            dst[w] = v;
-        }
-    }
-}
-}  // namespace
-
-hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const uint32_t *d_list, const unsigned int *d_count,
-                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream,
-                             unsigned int *d_count_out) {
-    if (!d_seq || !d_off || (d_list && !d_count) || (!d_list && !d_count_out) || !d_slots || !d_lens || slot < 16 || (slot & 15) || max_len > slot)
-        return hipErrorInvalidValue;
-    long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * 8;
-    const long long useful = (n_cap + 15) / 16;
-    if (blocks > useful) blocks = useful;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bdx_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq, d_off, d_list, d_count, n_cap, d_slots, d_lens, slot, max_len, d_count_out);
-    return hipGetLastError();
-}
-
 hipError_t bdx_launch_poison_check(uint32_t *list, const unsigned int *list_count, long long n_reads, const uint32_t *wins, uint8_t *wcnt,
                                    const uint32_t *cand, int cand_words, int n_barcodes, int check_list, unsigned int *dbg, hipStream_t stream) {
     if (n_reads <= 0 || !dbg) return hipSuccess;

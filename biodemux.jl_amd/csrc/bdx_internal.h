@@ -204,7 +204,7 @@ struct BdxWavePlan {
     int pairs_spread;      // pairs mode: columns a flagged alignment can lie off its diagonal (classic: the budget; same-diagonal variants: the largest number of indels)
     int nw;                // words of a barcode mask
     int groups;            // groups of 128 barcodes (more than 128 barcodes: one set of piece tables per group, nw = 4)
-    int slot;              // bytes per gathered read
+    int slot;              // pairs mode: flat positions per read of a (scattered) tile: the read length + 15 (its address mod 16), rounded up to 16
     int cpr;               // 16-diagonal chunks scanned per read
 };
 
@@ -247,13 +247,11 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
                                unsigned int *list_count, hipStream_t stream, int dbg = 0, double tier_slo1 = 0.0);
 // Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
-hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
-                            const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,
-                            uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr);
-// Gathers the reads of a list into slots of `slot` bytes (padded with 'N') + their lengths (bdx_device.hip).
-hipError_t bdx_launch_gather(const uint8_t *d_seq, const long long *d_off, const uint32_t *d_list, const unsigned int *d_count,
-                             long long n_cap, uint8_t *d_slots, int *d_lens, int slot, int max_len, int n_cu, hipStream_t stream,
-                             unsigned int *d_count_out = nullptr);  // d_list == NULL: every read of the batch, their number left in *d_count_out
+// (the listed reads d_idmap[0 .. *d_count) are fetched straight from the batch; d_idmap == NULL: every read of the batch)
+hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                            long long n_reads, const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out,
+                            unsigned long long *d_counts, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0,
+                            const BdxWaveSplit *sp = nullptr);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
                            double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr,

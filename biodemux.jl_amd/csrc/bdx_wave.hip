@@ -30,7 +30,13 @@
 // own Float64 code.
 #include <atomic>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "bdx_core.h"
+
+// a launcher that refuses its plan says where (stderr, only with BDX_TRACE_LAUNCH set: developer aid)
+#define BDX_BAD_PLAN() (getenv("BDX_TRACE_LAUNCH") ? (void)fprintf(stderr, "[bdx] launch refused at %s:%d\n", __FILE__, __LINE__) : (void)0, hipErrorInvalidValue)
 
 namespace {
 
@@ -72,9 +78,13 @@ struct WaveArgs {
     uint8_t *wcnt_out[2];    // [n_reads] entries valid (255: none -> whole window)
     int short_lb[2];         // lookback m + kb instead of 2 (m + kb) + 1
     int sg;                  // :semiglobal (else :hamming / :exact: a window entry's first field is the first START position)
-    // pairs mode (KB > 0; two-intact-pieces filter over the reads an earlier tier listed): the reads were gathered into
-    // slots of `slot` bytes (16-byte multiple, padded with 'N'); read k of the gathered buffer is read idmap[k] of the batch
-    int slot;                // bytes per slot
+    // pairs mode (KB > 0; two-intact-pieces filter over the reads an earlier tier listed) reads SCATTERED tiles: read k of the
+    // launch is read idmap[k] of the batch (NULL: read k), its bytes are fetched straight from the batch into a slot of
+    // `slot` flat positions of the tile's images (16-byte multiple; the read starts `head` = its address mod 16 positions into
+    // its slot, so that every load is an aligned 16-byte vector)
+    int slot;                // flat positions per slot
+    int vps, vps_inv;        // slot / 16 and ceil(2^16 / vps)
+    int max_len;             // the read length the scan was planned for: longer reads are handed on
     int cpr;                 // 16-diagonal chunks scanned per read
     int cpr_inv;             // ceil(2^16 / cpr)
     int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
@@ -83,9 +93,8 @@ struct WaveArgs {
     int cand_area;           // words per read of the area behind the sweep list (candidate masks / survivors of pass 1)
     int ranged;              // some pass has a ref_search_range: per read the column window [first, last] of each pass (classification.jl:795-807)
     BdxDevPass dpass[2];     // the passes' ranges (ranged only)
-    const int *lens;         // [count] read lengths
-    const uint32_t *idmap;   // [count] batch read numbers (= the list the reads were gathered from)
-    const unsigned int *n_dev;  // the number of gathered reads lives on the device
+    const uint32_t *idmap;   // [count] batch read numbers (= the list an earlier tier wrote; NULL: every read of the batch)
+    const unsigned int *n_dev;  // the number of listed reads lives on the device (NULL: n_reads)
     int dbg;  // timing experiments (env BDX_DEBUG), compiled in ONLY with -DBDX_TUNING — results are wrong when a skip bit
               // is set: 1 skip verdicts, 2 skip sweeps, 4 skip resolve + emit, 8 skip seed scan, 32 skip transcode, 64 skip loads
 };
@@ -264,7 +273,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int q = Q;  // seed length
     // (pairs mode: the number of gathered reads is only known on the device)
     const bool ranged = GEN && a.ranged != 0, dual = GEN && a.dual != 0;
-    const long long n_reads = PAIRS ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
+    constexpr bool SCAT = PAIRS;  // scattered tiles: every read of a tile is fetched on its own (by list index) into a slot of the images
+    const long long n_reads = (SCAT && a.n_dev) ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
     size_t o = 0;
@@ -366,25 +376,60 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         g.nvec = (g.total + 15) >> 4;
         return g;
     };
+    // Scattered tiles (SCAT): lane t < RW owns read t of the tile: its batch number (from the list, three tiles ahead), its
+    // offset and length (two tiles ahead), and from those the 16-byte aligned address its slot is filled from; the bytes are
+    // requested one tile ahead like those of a contiguous tile, every lane fetching vector j of read t (k = t * vps + j).
+    typedef long long ll2a __attribute__((ext_vector_type(2), aligned(8)));
+    struct ScatOff {
+        long long o0;
+        int len;
+    };
+    const auto load_scat = [&](const int t, const uint32_t id) -> ScatOff {
+        const long long r0 = (long long)t * RW;
+        ScatOff so{0, -1};
+        if (SCAT && t < ntiles && r0 + lane < n_reads && lane < RW) {
+            const ll2a o = *(const ll2a __attribute__((address_space(1))) *)(a.off + id);
+            so.o0 = o[0];
+            const long long l = o[1] - o[0];
+            so.len = (l >= 0 && l < (1LL << 30)) ? (int)l : -1;
+        }
+        return so;
+    };
+    // per-lane slot geometry of read `lane` of a scattered tile: aligned base address, head, vectors to fetch (0: none — the
+    // read is longer than its slot, or there is no such read)
+    struct ScatGeo {
+        uintptr_t abase;
+        int head, nv, len;
+    };
+    const auto scat_geo = [&](const ScatOff &so) -> ScatGeo {
+        ScatGeo g{0, 0, 0, -1};
+        if (so.len >= 0) {
+            const uintptr_t ad = (uintptr_t)a.seq + (uintptr_t)so.o0;
+            g.head = (int)(ad & 15);
+            g.abase = ad - (uintptr_t)g.head;
+            const int nv = (g.head + so.len + 15) >> 4;
+            if (nv <= a.vps && so.len <= a.max_len) {  // (the scan covers the diagonals of reads up to max_len)
+                g.nv = nv;
+                g.len = so.len;
+            }
+        }
+        return g;
+    };
     const auto load_offsets = [&](const int t) -> long long {  // (t < 2^30 also when it runs past the last tile)
         const long long r0 = (long long)t * RW;
         const long long left = n_reads - r0;
         const int cnt = t < ntiles ? (int)(left < RW ? left : RW) : -1;  // lanes 0 .. cnt load
-        if (PAIRS) return lane <= cnt ? (r0 + lane) * (long long)a.slot : 0;  // slots: no offsets to load
+        if (SCAT) return 0;  // (scattered tiles: load_scat)
         // wave-uniform base in scalar registers + a 32-bit lane offset
         const uintptr_t bp = (uintptr_t)(a.off + r0);
         const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bp), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
         const long long *base = (const long long *)(((uintptr_t)bhi << 32) | blo);
         return lane <= cnt ? base[lane] : 0;
     };
-    // pairs mode: length and batch read number of the tile's reads (lanes 0 .. cnt - 1), requested with the offsets
-    const auto load_len = [&](const int t) -> int {
-        const long long r0 = (long long)t * RW;
-        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? a.lens[r0 + lane] : 0;
-    };
+    // scattered tiles: batch read number of the tile's reads (lanes 0 .. cnt - 1)
     const auto load_gid = [&](const int t) -> uint32_t {
         const long long r0 = (long long)t * RW;
-        return (PAIRS && t < ntiles && r0 + lane < n_reads && lane < RW) ? (a.idmap ? a.idmap[r0 + lane] : (uint32_t)(r0 + lane)) : 0u;
+        return (SCAT && t < ntiles && r0 + lane < n_reads && lane < RW) ? (a.idmap ? a.idmap[r0 + lane] : (uint32_t)(r0 + lane)) : 0u;
     };
     const auto rlen = [&](const int t) -> int { return PAIRS ? rl[t] : fb[t + 1] - fb[t]; };
     u32x4 v[NV];
@@ -396,6 +441,23 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         for (int u = 0; u < NV; ++u) {
             const int k = 64 * u + lane;
             if (k < g.nvec && !BDX_DBG(64)) v[u] = __builtin_nontemporal_load(src + k);
+        }
+    };
+    // scattered tile: vector k of the images is vector j = k - t vps of read t = k / vps; its address comes from lane t
+    // (ds_bpermute); vectors a read does not reach are filled with 'N' (no barcode symbol, no seed of interest)
+    const auto load_bytes_scat = [&](const ScatGeo &sg, const int nr_t) {
+        const uint32_t alo = (uint32_t)sg.abase, ahi = (uint32_t)((unsigned long long)sg.abase >> 32);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int k = 64 * u + lane;
+            const int t = (int)(((uint32_t)k * (uint32_t)a.vps_inv) >> 16);
+            const int j = k - t * a.vps;
+            const int src4 = (t < RW ? t : 0) * 4;
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)alo), bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)ahi);
+            const int nvt = __builtin_amdgcn_ds_bpermute(src4, sg.nv);
+            u32x4 x = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+            if (t < nr_t && j < nvt && !BDX_DBG(64)) x = __builtin_nontemporal_load((GlobalVec16)((((unsigned long long)bhi << 32) | blo) + 16ull * (unsigned)j));
+            v[u] = x;
         }
     };
     for (int i = lane; i < RW * RCAP; i += 64) {  // (a sweep clears its record: the tables are empty at the top of every tile)
@@ -416,13 +478,28 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     };
     long long ov = load_offsets(tile);
     Geo geo{};
+    // scattered tiles: read numbers of this tile and the next three, offsets of this tile and the next two
+    uint32_t iv = load_gid(tile), iv_next = load_gid(tile + nwaves), iv_after = load_gid(tile + 2 * nwaves);
+    ScatOff so = load_scat(tile, iv), so_next = load_scat(tile + nwaves, iv_next);
+    const auto scat_tile = [&](const int t) -> Geo {  // the wave-uniform part of a scattered tile's geometry
+        Geo g{};
+        const long long r0 = (long long)t * RW;
+        g.nr = (int)(n_reads - r0 < RW ? n_reads - r0 : RW);
+        g.ok = true;
+        g.nvec = g.nr * a.vps;
+        g.total = g.nvec << 4;
+        return g;
+    };
     if (tile < ntiles) {
-        geo = geometry(tile, ov);
-        load_bytes(geo);
+        if (SCAT) {
+            geo = scat_tile(tile);
+            load_bytes_scat(scat_geo(so), geo.nr);
+        } else {
+            geo = geometry(tile, ov);
+            load_bytes(geo);
+        }
     }
     long long ov_next = load_offsets(tile + nwaves);
-    int lv = load_len(tile), lv_next = load_len(tile + nwaves);
-    uint32_t iv = load_gid(tile), iv_next = load_gid(tile + nwaves);
 
     while (tile < ntiles) {
         const long long r0 = (long long)tile * RW;
@@ -431,12 +508,14 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         const int total = geo.total, nvec = geo.nvec;
 
         // ---- per-tile tables ----
-        if (lane <= nr) fb[lane] = tile_ok ? geo.head + (int)(ov - geo.span0) : 0;
+        if (!SCAT && lane <= nr) fb[lane] = tile_ok ? geo.head + (int)(ov - geo.span0) : 0;
         if (lane < RW) {
             scnt[lane] = 0;
             flag[lane] = 0;
-            if (PAIRS) {
-                rl[lane] = lv;
+            if (SCAT) {
+                const ScatGeo sg = scat_geo(so);
+                fb[lane] = lane * a.slot + sg.head;  // the read's first base within the tile's flat images
+                rl[lane] = lane < nr ? sg.len : 0;   // (-1: longer than its slot — handed on)
                 gid[lane] = iv;
             }
             wcl1[lane] = 0;  // (split mode: window entries of pass 1; known-score dual configs: survivors of pass 1)
@@ -464,12 +543,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         const int tile_next = tile + nwaves;
         Geo geo_next{};
         if (tile_next < ntiles) {
-            geo_next = geometry(tile_next, ov_next);
-            load_bytes(geo_next);
+            if (SCAT) {
+                geo_next = scat_tile(tile_next);
+                load_bytes_scat(scat_geo(so_next), geo_next.nr);
+            } else {
+                geo_next = geometry(tile_next, ov_next);
+                load_bytes(geo_next);
+            }
         }
         const long long ov_after = load_offsets(tile_next + nwaves);
-        const int lv_after = load_len(tile_next + nwaves);
-        const uint32_t iv_after = load_gid(tile_next + nwaves);
+        const ScatOff so_after = load_scat(tile_next + nwaves, iv_after);
+        const uint32_t iv_after2 = load_gid(tile_next + 2 * nwaves);
         WAVE_SYNC();
 
         if (ranged && lane < RW) {
@@ -639,7 +723,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 valid = valid && kk != 255;
                 const int n = rl[t];
                 const int sp = KB >= 8 ? (int)(mt >> 24) : kk;  // columns an alignment can lie off the flagged diagonal: its indels
-                int lo = dlo - sp, hi = dlo + wd + mm + sp;
+                const int dr = dlo - (fb[t] - t * a.slot);      // (the scan's diagonals are relative to the slot: the read starts `head` positions in)
+                int lo = dr - sp, hi = dr + wd + mm + sp;
                 const int wlo = win_lo(t, b >= a.B0), whi = win_hi(t, b >= a.B0, n);
                 lo = lo < wlo ? wlo : lo;
                 hi = hi > whi ? whi : hi;
@@ -677,7 +762,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             static_assert(7 + PL * (P - 1) + PL - 1 <= 31, "the keys of a chunk come out of three words of the 2-bit image");
             uint32_t amask = ((1u << (2 * PL)) - 1u) * ESTRIDE;
             asm volatile("" : "+v"(amask));
-            const int s16 = a.slot >> 4;
+            const int s16 = a.vps;
             const int items = BDX_DBG(8) ? 0 : nr * a.cpr;
             for (int i0 = 0; i0 < items; i0 += 64) {
                 const int i = i0 + lane;
@@ -1139,10 +1224,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             geo = geo_next;
             ov = ov_next;
             ov_next = ov_after;
-            lv = lv_next;
-            lv_next = lv_after;
+            so = so_next;
+            so_next = so_after;
             iv = iv_next;
             iv_next = iv_after;
+            iv_after = iv_after2;
             continue;
         }
 
@@ -1311,10 +1397,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         geo = geo_next;
         ov = ov_next;
         ov_next = ov_after;
-        lv = lv_next;
-        lv_next = lv_after;
+        so = so_next;
+        so_next = so_after;
         iv = iv_next;
         iv_next = iv_after;
+        iv_after = iv_after2;
     }
 
     flush_list();
@@ -1388,9 +1475,11 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.tier_slo1 = 0.0;
     a.dual = 0;
     a.slot = 0;
+    a.vps = 1;
+    a.vps_inv = 65536;
+    a.max_len = 0;
     a.cpr = 1;
     a.cpr_inv = 65536;
-    a.lens = nullptr;
     a.idmap = nullptr;
     a.n_dev = nullptr;
 }
@@ -1436,9 +1525,9 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
     a.tier_slo = tier_slo;
     a.tier_slo1 = tier_slo1;
     a.dual = (!wp.split && cfg.is_dual) ? 1 : 0;
-    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;  // (the survivors of pass 1 live in the candidate-word area: four per read)
-    if (wp.pairs_kb > 0) return hipErrorInvalidValue;
-    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
+    if (a.dual && wp.cand_words != 4) return BDX_BAD_PLAN();  // (the survivors of pass 1 live in the candidate-word area: four per read)
+    if (wp.pairs_kb > 0) return BDX_BAD_PLAN();
+    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return BDX_BAD_PLAN();
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
     long long blocks = (long long)wp.blocks;
@@ -1466,7 +1555,7 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
         case 8:
             BDX_WAVE_TF(8);
         default:
-            return hipErrorInvalidValue;
+            return BDX_BAD_PLAN();
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
@@ -1475,29 +1564,33 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
 
 #elif defined(BDX_WAVE_TU_PAIRS)  // the pairs-mode instantiations live in a translation unit of their own (bdx_pairs.hip)
 
-// Pairs mode over the reads of a list (gathered into slots by bdx_launch_gather): final verdicts at the full budgets for
-// the known-score class (what it cannot answer goes to `list`), candidate masks + windows in split mode.
-hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_slots, const int *d_lens,
-                            const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out, unsigned long long *d_counts,
-                            uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg, const BdxWaveSplit *sp) {
-    if (wp.pairs_kb <= 0 || !d_slots || !d_lens || !d_count) return hipErrorInvalidValue;  // (d_idmap == NULL: slot k holds read k of the batch)
+// Pairs mode over the reads of a list (d_idmap[0 .. *d_count), fetched straight from the batch; d_idmap == NULL: every read of
+// the batch): final verdicts at the full budgets for the known-score class (what it cannot answer goes to `list`), candidate
+// masks + windows in split mode.
+hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                            long long n_reads, const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out,
+                            unsigned long long *d_counts, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg,
+                            const BdxWaveSplit *sp) {
+    if (wp.pairs_kb <= 0 || !d_seq || !d_off || n_reads <= 0 || (d_idmap && !d_count)) return BDX_BAD_PLAN();
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, sp);
-    a.seq = d_slots;
-    a.off = nullptr;
-    a.n_reads = 0;
+    a.seq = d_seq;
+    a.off = d_off;
+    a.n_reads = n_reads;
     a.tier = 0;
     a.tier_slo = 0.0;
     a.slot = wp.slot;
+    a.vps = wp.slot >> 4;
+    a.vps_inv = (65536 + a.vps - 1) / a.vps;
+    a.max_len = wp.read_len_hint;
     a.cpr = wp.cpr;
     a.cpr_inv = (65536 + wp.cpr - 1) / wp.cpr;
-    a.lens = d_lens;
     a.idmap = d_idmap;
-    a.n_dev = d_count;
+    a.n_dev = d_idmap ? d_count : nullptr;
     a.dual = (!wp.split && cfg.is_dual) ? 1 : 0;
-    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;
-    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return hipErrorInvalidValue;
-    if (wp.rw * wp.cpr > 32 * 40 || (wp.slot & 15) || wp.rw * wp.slot + 16 > wp.span_cap) return hipErrorInvalidValue;
+    if (a.dual && wp.cand_words != 4) return BDX_BAD_PLAN();
+    if (wp.split && (!sp || !a.cand_out[0] || !a.wins_out[0] || !a.wcnt_out[0])) return BDX_BAD_PLAN();
+    if (wp.rw * wp.cpr > 32 * 40 || (wp.slot & 15) || wp.slot < 16 || wp.rw * wp.slot + 16 > wp.span_cap) return BDX_BAD_PLAN();
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long blocks = wp.blocks < 1 ? 1 : wp.blocks;
     const int tf = wp.track_from;
@@ -1511,15 +1604,15 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
 #define BDX_PAIRS_KB(RWV, TFV, NVV) (wp.pairs_kb == 8 ? BDX_PAIRS_SD(RWV, TFV, NVV, 8) : wp.pairs_kb == 9 ? BDX_PAIRS_SD(RWV, TFV, NVV, 9) : wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, TFV, NVV, 3) : BDX_PAIRS_NW(RWV, TFV, NVV, 4))
 #define BDX_PAIRS_TF(RWV, NVV) return BDX_PAIRS_KB(RWV, 12, NVV)
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
-    if ((wp.pairs_kb > 4 && wp.pairs_kb != 8 && wp.pairs_kb != 9) || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return hipErrorInvalidValue;
-    if (wp.pairs_kb >= 8 && (!wp.split || wp.groups > 1)) return hipErrorInvalidValue;
-    if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return hipErrorInvalidValue;
-    if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
-    if ((wp.kend == 2) != (wp.kend && (a.trim0 == 3 || a.trim1 == 3))) return hipErrorInvalidValue;
+    if ((wp.pairs_kb > 4 && wp.pairs_kb != 8 && wp.pairs_kb != 9) || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return BDX_BAD_PLAN();
+    if (wp.pairs_kb >= 8 && (!wp.split || wp.groups > 1)) return BDX_BAD_PLAN();
+    if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return BDX_BAD_PLAN();
+    if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();
+    if ((wp.kend == 2) != (wp.kend && (a.trim0 == 3 || a.trim1 == 3))) return BDX_BAD_PLAN();
     if (wp.kend == 2) return bdx_launch_pairs_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)
-    if (wp.rw == 16 && wp.span_cap <= 3 * 1024) BDX_PAIRS_TF(16, 3);
-    if (wp.rw == 16 && wp.span_cap <= 6 * 1024) BDX_PAIRS_TF(16, 6);
-    return hipErrorInvalidValue;
+    if (wp.rw == 16 && wp.span_cap <= 3 * 1024 + 16) BDX_PAIRS_TF(16, 3);
+    if (wp.rw == 16 && wp.span_cap <= 6 * 1024 + 16) BDX_PAIRS_TF(16, 6);
+    return BDX_BAD_PLAN();
 #undef BDX_PAIRS_TF
 #undef BDX_PAIRS_KB
 #undef BDX_PAIRS_SD
@@ -1545,7 +1638,7 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
         case 8:
             BDX_WAVE_TF(8);
         default:
-            return hipErrorInvalidValue;
+            return BDX_BAD_PLAN();
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
@@ -1560,10 +1653,10 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
                                unsigned int *list_count, hipStream_t stream, int dbg, double tier_slo1) {
     if (n_reads <= 0) return hipSuccess;
-    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr || !wp.d_peq8r) return hipErrorInvalidValue;
+    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr || !wp.d_peq8r) return BDX_BAD_PLAN();
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, nullptr);
-    if (out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;  // (a trim_side = 3 pass knows its start only)
+    if (out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();  // (a trim_side = 3 pass knows its start only)
     a.seq = d_seq;
     a.off = d_off;
     a.n_reads = n_reads;
@@ -1571,14 +1664,14 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
     a.tier_slo = tier_slo;
     a.tier_slo1 = tier_slo1;
     a.dual = cfg.is_dual ? 1 : 0;
-    if (a.dual && wp.cand_words != 4) return hipErrorInvalidValue;  // (the survivors of pass 1 live in the candidate-word area: four per read)
+    if (a.dual && wp.cand_words != 4) return BDX_BAD_PLAN();  // (the survivors of pass 1 live in the candidate-word area: four per read)
     const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
     const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
     long long blocks = (long long)wp.blocks;
     const long long useful = (tiles + wp.waves - 1) / wp.waves;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
-    if ((wp.kend == 2) != (a.trim0 == 3 || a.trim1 == 3)) return hipErrorInvalidValue;
+    if ((wp.kend == 2) != (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();
     if (wp.kend == 2) return bdx_launch_wave_end_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)
     const int tf = wp.track_from;
 #define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 1>(a, lds, wp.waves, blocks, stream)
@@ -1595,7 +1688,7 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
         case 8:
             BDX_WAVE_TF(8);
         default:
-            return hipErrorInvalidValue;
+            return BDX_BAD_PLAN();
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
@@ -1620,7 +1713,7 @@ hipError_t bdx_launch_wave_gen(const void *wave_args, const BdxWavePlan &wp, siz
         case 8:
             BDX_WAVE_TF(8);
         default:
-            return hipErrorInvalidValue;
+            return BDX_BAD_PLAN();
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
@@ -1646,7 +1739,7 @@ hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp,
         case 8:
             BDX_WAVE_TF(8);
         default:
-            return hipErrorInvalidValue;
+            return BDX_BAD_PLAN();
     }
 #undef BDX_WAVE_TF
 #undef BDX_WAVE_NV
@@ -1655,13 +1748,13 @@ hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp,
 
 hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
     const WaveArgs &a = *(const WaveArgs *)wave_args;
-    if (wp.pairs_kb > 4 || wp.nw > 4 || wp.track_from < 12 || wp.groups > 1 || wp.split || wp.kend != 2) return hipErrorInvalidValue;
+    if (wp.pairs_kb > 4 || wp.nw > 4 || wp.track_from < 12 || wp.groups > 1 || wp.split || wp.kend != 2) return BDX_BAD_PLAN();
 #define BDX_PAIRS_SP(RWV, NVV, KBV, NWV) launch_wave<RWV, 12, NVV, 4, false, KBV, NWV, false, 2>(a, lds, wp.waves, blocks, stream)
 #define BDX_PAIRS_NW(RWV, NVV, KBV) (wp.nw <= 2 ? BDX_PAIRS_SP(RWV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, NVV, KBV, 4))
 #define BDX_PAIRS_KB(RWV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, NVV, 3) : BDX_PAIRS_NW(RWV, NVV, 4))
-    if (wp.rw == 16 && wp.span_cap <= 3 * 1024) return BDX_PAIRS_KB(16, 3);
-    if (wp.rw == 16 && wp.span_cap <= 6 * 1024) return BDX_PAIRS_KB(16, 6);
-    return hipErrorInvalidValue;
+    if (wp.rw == 16 && wp.span_cap <= 3 * 1024 + 16) return BDX_PAIRS_KB(16, 3);
+    if (wp.rw == 16 && wp.span_cap <= 6 * 1024 + 16) return BDX_PAIRS_KB(16, 6);
+    return BDX_BAD_PLAN();
 #undef BDX_PAIRS_KB
 #undef BDX_PAIRS_NW
 #undef BDX_PAIRS_SP
