@@ -47,6 +47,7 @@ BdxTuning read_tuning() {
     t.lds_dp = getenv("BDX_LDS_DP") != nullptr;
     t.no_tier = getenv("BDX_NO_TIER") != nullptr;
     t.no_wave = getenv("BDX_NO_WAVE") != nullptr;
+    t.no_win = getenv("BDX_NO_WIN") != nullptr;
     t.no_pairs = getenv("BDX_NO_PAIRS") != nullptr;
     t.no_kend = getenv("BDX_NO_KEND") != nullptr;
     if (const char *e = getenv("BDX_TIER0_DIV")) t.tier0_div = atoi(e);
@@ -589,6 +590,8 @@ int build_diag_tables(bdx_ctx *ctx) {
 // for every read (then final_search_range = 1:n, max_start_pos = n, min_end_pos = 1: neither binds, DESIGN.md
 // §3.1).  Same pieces, keys and budgets as build_seed_tables / build_bitpar_tables of the set — only the symbol
 // coding differs: the kernel transcodes arithmetically, code = (byte >> 1) & 3 (A 0, C 1, T 2, G 3).
+// (developer aid: with BDX_TRACE_LAUNCH set, build_wave_tables says where it turned a filter set away)
+#define WAVE_NO() (getenv("BDX_TRACE_LAUNCH") ? (void)fprintf(stderr, "[bdx] no wave tables for set %d: bdx_abi.cpp:%d\n", ctx->cur, __LINE__) : (void)0, BDX_OK)
 int build_wave_tables(bdx_ctx *ctx) {
     const bdx_config_t &c = ctx->cfg;
     BdxFilterSet &F = ctx->F();
@@ -599,7 +602,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     const int npass = c.is_dual ? 2 : 1;
     if (ctx->tune.no_wave || !bp.enabled || !sp.enabled || sp.diag || bp.word_bytes != 4 || sp.n_always[0] != 0 || sp.n_always[1] != 0 ||
         sp.q < 6 || sp.q > 8 || (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel))
-        return BDX_OK;
+        return WAVE_NO();
     // known-score configs: the kernel replays the reducer itself (single pass); everything else in the filters' domain:
     // "split" — it only filters, candidate masks and column windows go to the exact kernel (either pass count)
     bool split = false;
@@ -608,7 +611,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     // budget is floor(rate * m) substitutions / 0, one operation costs 1
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
     int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
-    if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
+    if (cmin < 1 || (sgm && c.match < 0)) return WAVE_NO();
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     int Btot = 0, cwt = 0;
     bool ranged = false;
@@ -616,20 +619,20 @@ int build_wave_tables(bdx_ctx *ctx) {
         const bdx_pass_t &p = c.pass[k];
         // (a ref_search_range is allowed for :semiglobal: the kernel resolves every read's column window itself, classification.jl:795-807;
         // start / end ranges that could bind stay on the general kernel)
-        if (p.explicit_window != 0 || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return BDX_OK;
+        if (p.explicit_window != 0 || !whole(p.barcode_start_range) || !whole(p.barcode_end_range)) return WAVE_NO();
         if (!whole(p.ref_search_range)) {
-            if (c.algorithm != BDX_ALG_SEMIGLOBAL) return BDX_OK;
+            if (c.algorithm != BDX_ALG_SEMIGLOBAL) return WAVE_NO();
             ranged = true;
         }
-        if (p.n_barcodes < 1) return BDX_OK;
+        if (p.n_barcodes < 1) return WAVE_NO();
         for (uint32_t i = 0; i < p.bc_off[p.n_barcodes]; ++i) {
             const uint8_t ch = p.bc_bytes[i];
-            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return BDX_OK;
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') return WAVE_NO();
         }
         Btot += p.n_barcodes;
         cwt += (p.n_barcodes + 31) / 32;
     }
-    if (Btot > 1024 || (split && cwt > 16)) return BDX_OK;  // (split mode keeps the candidate words of a read in LDS: up to 512 barcodes)
+    if (Btot > 1024 || (split && cwt > 16)) return WAVE_NO();  // (split mode keeps the candidate words of a read in LDS: up to 512 barcodes)
     const int q = sp.q;
     struct Piece { int g, start; const uint8_t *bc; };
     std::vector<Piece> pieces;
@@ -640,7 +643,7 @@ int build_wave_tables(bdx_ctx *ctx) {
         const bdx_pass_t &p = c.pass[k];
         for (int b = 0; b < p.n_barcodes; ++b, ++g) {
             const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
-            if (m < 1 || m > 32) return BDX_OK;
+            if (m < 1 || m > 32) return WAVE_NO();
             const uint8_t *bc = p.bc_bytes + p.bc_off[b];
             const int shift = 32 - m;
             const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift);
@@ -664,9 +667,9 @@ int build_wave_tables(bdx_ctx *ctx) {
             }
             long long kb = ae / cmin;
             if (kb > tier_cap(ctx, m)) kb = tier_cap(ctx, m);
-            if (kb > 15) return BDX_OK;  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
+            if (kb > 15) return WAVE_NO();  // (a record keeps the diagonals of its hits as 2 kb + 1 bits)
             const long long L = m / (kb + 1);
-            if (L < q) return BDX_OK;  // (cannot happen: the set's q is the shortest piece)
+            if (L < q) return WAVE_NO();  // (cannot happen: the set's q is the shortest piece)
             // lone-survivor tables of the replay (bdx_wave.hip): the reference accepts a survivor with distance d iff
             // d <= floor(max_error_rate * m) (:254) and score = d / m <= max_error_rate (:658 / :696) — both Float64, both
             // evaluated here exactly as the device would; tier 1 settles it iff score < slo (and, with_delta, the bound
@@ -688,7 +691,7 @@ int build_wave_tables(bdx_ctx *ctx) {
             for (long long t = 0; t <= kb; ++t) pieces.push_back(Piece{g, (int)(t * L), bc});
         }
     }
-    if (pieces.empty() || pieces.size() > 8192) return BDX_OK;
+    if (pieces.empty() || pieces.size() > 8192) return WAVE_NO();
     // the per-read record table holds eight (barcode, diagonal cluster) records: the planted one(s) plus the chance pairs must nearly always fit
     {
         // chance seed hits per 150-base read: the hit queue and the sweep list of a tile are sized from it (size_wave)
@@ -698,7 +701,7 @@ int build_wave_tables(bdx_ctx *ctx) {
         double limit = ctx->cur == 1 ? 3.0 : 6.0;
         if (const char *e = getenv("BDX_WAVE_CHANCE")) limit = atof(e);  // (tuning experiment)
         wp.chance = 150.0 * (double)pieces.size() / std::pow(4.0, (double)q);
-        if (wp.chance > limit) return BDX_OK;
+        if (wp.chance > limit) return WAVE_NO();
     }
     wp.q = q;
     wp.n_barcodes = Btot;
@@ -730,7 +733,7 @@ int build_wave_tables(bdx_ctx *ctx) {
         for (size_t i = 0; i < ents.size(); ++i)
             if (i == 0 || ents[i].key != ents[i - 1].key) head_of.push_back(i);
         const size_t D = head_of.size();
-        if (ents.size() >= 65536) return BDX_OK;
+        if (ents.size() >= 65536) return WAVE_NO();
         ent.assign(ents.size(), 0u);
         size_t next_free = D;
         for (size_t h = 0; h < D; ++h) {
@@ -755,7 +758,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     }
     wp.n_ent = (int)ent.size();
     // the tables must leave room for at least eight waves' work areas at the smallest tile
-    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return BDX_OK;
+    if (bdx_wave_table_bytes(wp, ctx->plan.hist_entries) > 64 * 1024) return WAVE_NO();
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_bm = 0, o_rank = al(bitmap.size()), o_ent = o_rank + al(rank.size() * 2), o_peq = o_ent + al(ent.size() * 4),
                  o_meta = o_peq + al(peq8.size() * 4), o_settle = o_meta + al(meta.size() * 4), o_peqr = o_settle + al(settle.size() * 4),
@@ -805,12 +808,14 @@ int build_wave_tables(bdx_ctx *ctx) {
     return BDX_OK;
 }
 
+#undef WAVE_NO
 // Geometry of the wave kernel for a batch: the tile size and workgroup shape that keep the most waves resident
 // per compute unit (tables once per workgroup + one work area per wave within 160 KiB, at most 16 waves: the
 // kernel is compiled for four waves per SIMD).  false: this batch runs the general kernel.
 bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads);
 bool size_wave(bdx_ctx *ctx, int set, int read_len, long long n_reads) { return size_wave(ctx, ctx->fs[set].wplan, read_len, n_reads); }
 bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
+    wp.winm = 0;
     if (!wp.enabled || ctx->dev.vlen) return false;  // (window uploads stage per-read slots: general kernel)
     if (read_len < 1) read_len = 1;
     const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
@@ -866,6 +871,67 @@ bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
         }
         if (gpr * npw * 16 * 10 <= (long long)read_len * 7 && (long long)wp.rw * npw * gpr < 2048) wp.scan_gpr = (int)gpr;
     }
+    return true;
+}
+
+// Window mode of the wave kernel (bdx_wave_win.hip) for a batch: single-pass known-score configs whose ref_search_range
+// window — resolved at the planned read length (classification.jl:795-800) — is at most half the read: the tiles are
+// scattered, every read's slot holds just its window (+ up to 15 positions in front: the loads are aligned 16-byte vectors).
+// This is what lets 10 kbp reads with a 200-column window (BASELINE config 5) take the wave kernel at all: a tile's bytes
+// wait in registers, which bounds a contiguous tile at 10 KB.
+bool size_wave_win(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
+    wp.winm = 0;
+    if (!wp.enabled || ctx->dev.vlen || !wp.ranged || wp.split || wp.kend || ctx->dev.is_dual || ctx->tune.no_wave || ctx->tune.no_win) return false;
+    if (read_len < 1) read_len = 1;
+    const BdxDevRange &dr = ctx->dev.pass[0].ref_search;
+    {
+        const long long LIM = 1LL << 28;  // (the kernel resolves the windows in 32-bit arithmetic)
+        if (dr.start_offset < -LIM || dr.start_offset > LIM || dr.end_offset < -LIM || dr.end_offset > LIM) return false;
+    }
+    long long f = dr.start_from_end ? read_len + dr.start_offset : dr.start_offset;
+    long long l = dr.end_from_end ? read_len + dr.end_offset : dr.end_offset;
+    if (f < 1) f = 1;
+    if (l > read_len) l = read_len;
+    const long long wlen = l >= f ? l - f + 1 : 0;
+    if (wlen < 1 || wlen * 2 > read_len) return false;
+    const int slot = (int)((wlen + 15 + 15) & ~15LL);
+    const size_t tables = bdx_wave_table_bytes(wp, ctx->plan.hist_entries);
+    const double chance = wp.chance * (double)wlen / 150.0;
+    int best_waves = 0;
+    const int rws[2] = {32, 16};
+    for (int rw : rws) {
+        if (ctx->tune.wave_rw && rw != ctx->tune.wave_rw) continue;
+        if (!ctx->tune.wave_rw && rw > 16 && n_reads / rw < (long long)ctx->n_cu * 16) continue;  // small batches: a tile per resident wave first
+        const int vecs = rw * (slot >> 4);
+        if (!((rw == 32 && vecs <= 64 * 7) || (rw == 16 && vecs <= 64 * 4))) continue;  // (instantiated register budgets)
+        const int span = rw * slot + 16;
+        const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * chance));
+        const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * chance));
+        const size_t area = bdx_wave_area_bytes(rw, span, false, hq_cap, sq_cap, 0, true);
+        const int shapes[3] = {16, 8, 4};
+        for (int w : shapes) {
+            if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
+            const size_t lds = tables + (size_t)w * area;
+            if (lds > LDS_MAX) continue;
+            int per_cu = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));
+            if (per_cu * w > 16) per_cu = 16 / w;
+            if (per_cu * w > best_waves) {
+                best_waves = per_cu * w;
+                wp.rw = rw;
+                wp.waves = w;
+                wp.blocks = per_cu * ctx->n_cu;
+                wp.span_cap = span;
+                wp.hq_cap = hq_cap;
+                wp.sq_cap = sq_cap;
+            }
+        }
+        if (best_waves >= 12) break;
+    }
+    if (best_waves < 4) return false;
+    wp.slot = slot;
+    wp.read_len_hint = read_len;
+    wp.scan_gpr = 0;
+    wp.winm = 1;
     return true;
 }
 
@@ -2230,9 +2296,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // in list mode.  The list-mode plan is made first: if it cannot be made, the general kernel runs alone.
         bool wave1 = false, wave0 = false;
         if (!split && !ctx->dev.vlen) {
+            // (window mode first: reads much longer than their column window — only the windows are fetched)
             if (tiered)
-                wave1 = size_wave(ctx, 1, batch_len, n_reads);
-            else if (size_wave(ctx, 0, batch_len, n_reads))
+                wave1 = size_wave_win(ctx, ctx->fs[1].wplan, batch_len, n_reads) || size_wave(ctx, 1, batch_len, n_reads);
+            else if (size_wave_win(ctx, ctx->fs[0].wplan, batch_len, n_reads) || size_wave(ctx, 0, batch_len, n_reads))
                 wave0 = size_bitpar(ctx, batch_len, n_reads, true);
             if (!tiered && !wave0) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
         }
@@ -2272,6 +2339,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         }
         if (wave0) {
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
+            if (ctx->fs[0].wplan.winm)
+                HIP_TRY(ctx, bdx_launch_wave_win(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                                 ctx->counts, 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192), ctx->stream, ctx->tune.debug));
+            else
             HIP_TRY(ctx, bdx_launch_wave(ctx->dev, ctx->fs[0].wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                          ctx->counts, (int *)(scratch + 256), 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192),
                                          ctx->stream, ctx->tune.debug));
@@ -2302,6 +2373,10 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             } else if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                              nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
+                ctx->wave_launches += 1;
+            } else if (wave1 && f1.wplan.winm) {  // ... in window mode
+                HIP_TRY(ctx, bdx_launch_wave_win(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug));
                 ctx->wave_launches += 1;
             } else if (wave1) {  // tier 1 as the wave-autonomous kernel: same budgets, same settle rule, same list
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
@@ -2419,8 +2494,8 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (wsplit0) ctx->path = "wave+verify";
         if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
         if (pairs_all) ctx->path = "pairs(diag)+verify";
-        if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
-        if (wave0) ctx->path = "wave > " + ctx->path;
+        if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (wave0) ctx->path = (ctx->fs[0].wplan.winm ? "wave(win) > " : "wave > ") + ctx->path;
         if (wave0k) ctx->path = "wave(end) > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {

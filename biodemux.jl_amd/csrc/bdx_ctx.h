@@ -51,6 +51,7 @@ struct BdxTuning {
     int tier0_div = 0;    // BDX_TIER0_DIV: tier 0's list is planned for n_reads / this many reads (default 16; 1: the whole batch)
     int no_kend = 0;      // BDX_NO_KEND: trim_side = 5 configs never take the known-end form of the wave kernel (filter + exact kernel instead)
     int no_pairs = 0;     // BDX_NO_PAIRS: never the pairs-mode kernel (bdx_pairs.hip) between tier 1 and the general kernel
+    int no_win = 0;       // BDX_NO_WIN: never the window mode of the wave kernel (bdx_wave_win.hip): reads with a short column window stage whole tiles or stay on the general kernel
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;

@@ -195,6 +195,7 @@ struct BdxWavePlan {
     int cand_words;        // split mode: candidate mask words per read (both passes)
     int scan_gpr;          // ranged single-pass configs (per batch): groups of sixteen positions scanned per read, 0: the whole flat image
     int ranged;            // some pass has a ref_search_range other than the whole read: per-read column windows in the kernel
+    int winm;              // per batch: window mode (bdx_wave_win.hip): scattered tiles that hold only each read's ref_search_range window (`slot` positions per read)
     int kend;              // known-trim class (any trim side per pass, no per-pass start positions wanted): the non-split kernel with position keys (bdx_wave_end.hip)
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
@@ -241,11 +242,16 @@ struct BdxWaveSplit {
 
 // Implemented in bdx_wave.hip.
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries);
-size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words);
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words, bool winm = false);
 // Implemented in bdx_wave_end.hip (the known-end instantiations of the same kernel).
 hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
                                unsigned int *list_count, hipStream_t stream, int dbg = 0, double tier_slo1 = 0.0);
+// Implemented in bdx_wave_win.hip (the window-mode instantiations: single-pass known-score configs whose column window is much
+// shorter than their reads — only the windows are fetched).
+hipError_t bdx_launch_wave_win(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                               long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
+                               unsigned int *list_count, hipStream_t stream, int dbg = 0);
 // Implemented in bdx_pairs.hip (the pairs-mode instantiations of the same kernel).
 // (the listed reads d_idmap[0 .. *d_count) are fetched straight from the batch; d_idmap == NULL: every read of the batch)
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,

@@ -85,6 +85,7 @@ struct WaveArgs {
     int slot;                // flat positions per slot
     int vps, vps_inv;        // slot / 16 and ceil(2^16 / vps)
     int max_len;             // the read length the scan was planned for: longer reads are handed on
+    int win_sfe, win_so, win_efe, win_eo;  // window mode: the pass's ref_search_range (start / end: from the read's end?, offset)
     int cpr;                 // 16-diagonal chunks scanned per read
     int cpr_inv;             // ceil(2^16 / cpr)
     int hq_cap, sq_cap;      // entries of the hit queue / the sweep list of a wave's tile
@@ -255,7 +256,11 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 // (sweep_lane) — and the replay trims with them.
 // GEN: the general form — dual configs and ref_search_range windows; false: single pass over whole reads (the headline
 // configuration: those checks are compiled out).
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true>
+// WINM: WINDOW mode of the seeded kernel — a single-pass config whose ref_search_range window is much shorter than its reads
+// (BASELINE config 5: 10 kbp reads, window 1:200): the tile is scattered like a pairs-mode tile, only each read's resolved
+// column window (classification.jl:795-807) is fetched into its slot, and everything downstream sees the window as the read
+// (what the verdict needs of the real read — its length, its number — rides along).
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true, bool WINM = false>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr bool KREV = KEND == 2;  // known-trim class with a trim_side = 3 pass: reversed sweeps (1: trim sides 5 / none only — the sweeps of round 3's known-end class)
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int q = Q;  // seed length
     // (pairs mode: the number of gathered reads is only known on the device)
     const bool ranged = GEN && a.ranged != 0, dual = GEN && a.dual != 0;
-    constexpr bool SCAT = PAIRS;  // scattered tiles: every read of a tile is fetched on its own (by list index) into a slot of the images
+    static_assert(!WINM || (!PAIRS && !SPLIT && KEND == 0 && GEN), "window mode: the non-split single-seed kernel");
+    constexpr bool SCAT = PAIRS || WINM;  // scattered tiles: every read of a tile is fetched on its own (by list index) into a slot of the images
     const long long n_reads = (SCAT && a.n_dev) ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
@@ -302,9 +308,15 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr int O_FLAG = O_SCNT + RW * 4;                  // int[RW]: read goes to the list
     constexpr int O_WCL1 = O_FLAG + RW * 4;                  // int[RW]: split mode: window entries written for pass 1 (pass 0: scnt)
     constexpr int O_LBUF = O_WCL1 + RW * 4;                  // u32[64]: reads for the list, flushed in batches
-    constexpr int O_RL = O_LBUF + 64 * 4;                    // int[RW]: pairs mode: read lengths (the slots are longer)
-    constexpr int O_GID = O_RL + (PAIRS ? RW * 4 : 0);       // u32[RW]: pairs mode: batch read numbers of the gathered reads
-    constexpr int O_IMG2 = O_GID + (PAIRS ? RW * 4 + 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (pairs mode: four guard words in front)
+    constexpr int O_RL = O_LBUF + 64 * 4;                    // int[RW]: scattered tiles: read (window) lengths (the slots are longer)
+    constexpr int O_GID = O_RL + (SCAT ? RW * 4 : 0);        // u32[RW]: scattered tiles: batch read numbers of the tile's reads
+    constexpr int O_TN = O_GID + (SCAT ? RW * 4 : 0);        // int[RW]: window mode: the reads' true lengths
+    // scattered tiles: slot geometry of this tile and the next (double-buffered: written when a tile's bytes are requested, one
+    // tile ahead) — u32x4 {aligned address lo, hi, vectors to fetch | head << 8, length (-1: handed on)}, read number, true length
+    constexpr int O_SG4 = O_TN + (WINM ? RW * 4 : 0);        // u32x4[2][RW]
+    constexpr int O_SGID = O_SG4 + (SCAT ? 2 * RW * 16 : 0); // u32[2][RW]
+    constexpr int O_STN = O_SGID + (SCAT ? 2 * RW * 4 : 0);  // int[2][RW] (window mode)
+    constexpr int O_IMG2 = O_STN + (WINM ? 2 * RW * 4 : 0) + (SCAT ? 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (scattered tiles: four guard words in front)
     const int nvec_cap = a.span_cap >> 4;
     LDS int *fb = (LDS int *)(wbase + O_FB);
     LDS uint32_t *rid = (LDS uint32_t *)(wbase + O_RID);
@@ -316,6 +328,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     LDS uint32_t *lbuf = (LDS uint32_t *)(wbase + O_LBUF);
     LDS int *rl = (LDS int *)(wbase + O_RL);
     LDS uint32_t *gid = (LDS uint32_t *)(wbase + O_GID);
+    LDS int *tn = (LDS int *)(wbase + O_TN);
+    LDS u32x4 *sg4 = (LDS u32x4 *)(wbase + O_SG4);
+    LDS uint32_t *sgid = (LDS uint32_t *)(wbase + O_SGID);
+    LDS int *stn = (LDS int *)(wbase + O_STN);
     LDS uint32_t *img2 = (LDS uint32_t *)(wbase + O_IMG2);
     LDS uint32_t *img4 = img2 + ((nvec_cap + 2 + 3) & ~3);  // u32[2 nvec_cap + 6]: 4-bit image (16-byte aligned)
     LDS uint32_t *hq = img4 + ((2 * nvec_cap + 6 + 3) & ~3);  // u32[HQ]: seed hits: flat position << 16 | key (pairs mode: sweep entries)
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         for (int i = tid; i < a.bm_bytes / 8; i += blockDim.x) ((LDS uint32_t *)rnk)[i] = ((const uint32_t *)a.rank)[i];
         for (int i = tid; i < a.n_ent; i += blockDim.x) ent[i] = a.ent[i];
     }
-    if (PAIRS && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
+    if (SCAT && lane < 4) img2[lane - 4] = 0u;  // guard words in front of the first slot
     for (int i = tid; i < B * 9; i += blockDim.x) peq[i] = a.peq8[i];
     if (KREV)
         for (int i = tid; i < B * 9; i += blockDim.x) peqr[i] = a.peq8r[i];
@@ -399,18 +415,35 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     // read is longer than its slot, or there is no such read)
     struct ScatGeo {
         uintptr_t abase;
-        int head, nv, len;
+        int head, nv, len;  // len: bases of the slot's read (window mode: of its column window); -1: not answered by this kernel
     };
     const auto scat_geo = [&](const ScatOff &so) -> ScatGeo {
         ScatGeo g{0, 0, 0, -1};
         if (so.len >= 0) {
-            const uintptr_t ad = (uintptr_t)a.seq + (uintptr_t)so.o0;
+            int wlo = 0, wlen = so.len;
+            bool ok = true;
+            if (WINM) {
+                // the read's column window (classification.jl:795-807) in 32-bit arithmetic: this kernel only runs for configs whose
+                // barcode_start / barcode_end ranges are the whole read (build_wave_tables) and whose ref_search_range offsets are
+                // small (the launcher checks), so  first = max(s, 1), last = min(e, n) (empty: last = first - 1, Julia's
+                // normalisation, resolve :96-100), max_start_pos = n, min_end_pos = 1, and the :805 sanity check is
+                // first <= last (first <= n and last >= 1 follow).  An empty read is not in the known-score class.
+                const int n = so.len;
+                const int sx = a.win_sfe ? n + a.win_so : a.win_so, ex = a.win_efe ? n + a.win_eo : a.win_eo;
+                const int first = sx > 1 ? sx : 1;
+                int last = ex < n ? ex : n;
+                if (last < first) last = first - 1;
+                ok = n > 0 && first <= last;
+                wlo = ok ? first - 1 : 0;
+                wlen = ok ? last - first + 1 : 0;
+            }
+            const uintptr_t ad = (uintptr_t)a.seq + (uintptr_t)so.o0 + (uintptr_t)wlo;
             g.head = (int)(ad & 15);
             g.abase = ad - (uintptr_t)g.head;
-            const int nv = (g.head + so.len + 15) >> 4;
-            if (nv <= a.vps && so.len <= a.max_len) {  // (the scan covers the diagonals of reads up to max_len)
+            const int nv = (g.head + wlen + 15) >> 4;
+            if (ok && nv <= a.vps && (WINM || so.len <= a.max_len)) {  // (pairs mode: the scan covers the diagonals of reads up to max_len)
                 g.nv = nv;
-                g.len = so.len;
+                g.len = wlen;
             }
         }
         return g;
@@ -431,7 +464,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         const long long r0 = (long long)t * RW;
         return (SCAT && t < ntiles && r0 + lane < n_reads && lane < RW) ? (a.idmap ? a.idmap[r0 + lane] : (uint32_t)(r0 + lane)) : 0u;
     };
-    const auto rlen = [&](const int t) -> int { return PAIRS ? rl[t] : fb[t + 1] - fb[t]; };
+    const auto rlen = [&](const int t) -> int { return SCAT ? rl[t] : fb[t + 1] - fb[t]; };
     u32x4 v[NV];
     LDS uint32_t *const img2_lane = img2 + lane;      // (one base register each: the unrolled stores differ by immediates)
     LDS uint32_t *const img4_lane = img4 + 2 * lane;
@@ -445,18 +478,26 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     };
     // scattered tile: vector k of the images is vector j = k - t vps of read t = k / vps; its address comes from lane t
     // (ds_bpermute); vectors a read does not reach are filled with 'N' (no barcode symbol, no seed of interest)
-    const auto load_bytes_scat = [&](const ScatGeo &sg, const int nr_t) {
-        const uint32_t alo = (uint32_t)sg.abase, ahi = (uint32_t)((unsigned long long)sg.abase >> 32);
+    // The slot geometry of a tile is worked out ONCE, by lane t for read t, when the tile's bytes are requested, and left in LDS
+    // (buffer `par`): the loads below read it from there (every lane its own read's entry), the tile itself one stage later.
+    const auto stash_scat = [&](const int par, const ScatOff &so, const uint32_t id) {
+        if (lane < RW) {
+            const ScatGeo sg = scat_geo(so);
+            sg4[par * RW + lane] = u32x4{(uint32_t)sg.abase, (uint32_t)((unsigned long long)sg.abase >> 32), (uint32_t)sg.nv | ((uint32_t)sg.head << 8), (uint32_t)sg.len};
+            sgid[par * RW + lane] = id;
+            if (WINM) stn[par * RW + lane] = so.len;
+        }
+        WAVE_SYNC();
+    };
+    const auto load_bytes_scat = [&](const int par, const int nr_t) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int k = 64 * u + lane;
             const int t = (int)(((uint32_t)k * (uint32_t)a.vps_inv) >> 16);
             const int j = k - t * a.vps;
-            const int src4 = (t < RW ? t : 0) * 4;
-            const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)alo), bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)ahi);
-            const int nvt = __builtin_amdgcn_ds_bpermute(src4, sg.nv);
+            const u32x4 e = sg4[par * RW + (t < RW ? t : 0)];
             u32x4 x = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
-            if (t < nr_t && j < nvt && !BDX_DBG(64)) x = __builtin_nontemporal_load((GlobalVec16)((((unsigned long long)bhi << 32) | blo) + 16ull * (unsigned)j));
+            if (t < nr_t && j < (int)(e[2] & 255u) && !BDX_DBG(64)) x = __builtin_nontemporal_load((GlobalVec16)((((unsigned long long)e[1] << 32) | e[0]) + 16ull * (unsigned)j));
             v[u] = x;
         }
     };
@@ -479,8 +520,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     long long ov = load_offsets(tile);
     Geo geo{};
     // scattered tiles: read numbers of this tile and the next three, offsets of this tile and the next two
-    uint32_t iv = load_gid(tile), iv_next = load_gid(tile + nwaves), iv_after = load_gid(tile + 2 * nwaves);
-    ScatOff so = load_scat(tile, iv), so_next = load_scat(tile + nwaves, iv_next);
+    uint32_t iv_next = load_gid(tile + nwaves), iv_after = load_gid(tile + 2 * nwaves);
+    ScatOff so_next = load_scat(tile + nwaves, iv_next);
+    int par = 0;  // the stash buffer of the current tile (wave-uniform)
     const auto scat_tile = [&](const int t) -> Geo {  // the wave-uniform part of a scattered tile's geometry
         Geo g{};
         const long long r0 = (long long)t * RW;
@@ -493,7 +535,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     if (tile < ntiles) {
         if (SCAT) {
             geo = scat_tile(tile);
-            load_bytes_scat(scat_geo(so), geo.nr);
+            const uint32_t iv0 = load_gid(tile);
+            stash_scat(0, load_scat(tile, iv0), iv0);
+            load_bytes_scat(0, geo.nr);
         } else {
             geo = geometry(tile, ov);
             load_bytes(geo);
@@ -513,10 +557,15 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             scnt[lane] = 0;
             flag[lane] = 0;
             if (SCAT) {
-                const ScatGeo sg = scat_geo(so);
-                fb[lane] = lane * a.slot + sg.head;  // the read's first base within the tile's flat images
-                rl[lane] = lane < nr ? sg.len : 0;   // (-1: longer than its slot — handed on)
-                gid[lane] = iv;
+                const u32x4 e = sg4[par * RW + lane];
+                const int slen = (int)e[3];
+                fb[lane] = lane * a.slot + (int)(e[2] >> 8);  // the read's first base within the tile's flat images
+                rl[lane] = lane < nr ? slen : 0;              // (-1: longer than its slot — handed on)
+                gid[lane] = sgid[par * RW + lane];
+                if (WINM) {
+                    tn[lane] = stn[par * RW + lane];
+                    if (lane < nr && slen < 0) flag[lane] = 1;  // (not in the known-score class, or a window longer than planned: listed)
+                }
             }
             wcl1[lane] = 0;  // (split mode: window entries of pass 1; known-score dual configs: survivors of pass 1)
             if (SPLIT)
@@ -545,7 +594,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         if (tile_next < ntiles) {
             if (SCAT) {
                 geo_next = scat_tile(tile_next);
-                load_bytes_scat(scat_geo(so_next), geo_next.nr);
+                stash_scat(par ^ 1, so_next, iv_next);
+                load_bytes_scat(par ^ 1, geo_next.nr);
             } else {
                 geo_next = geometry(tile_next, ov_next);
                 load_bytes(geo_next);
@@ -577,7 +627,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         // uniform read length of the tile (0: mixed) for the hit -> read mapping
         int ulen = 0;
         {
-            const int my = lane < nr ? fb[lane + 1] - fb[lane] : 0;
+            const int my = (!SCAT && lane < nr) ? fb[lane + 1] - fb[lane] : 0;
             const int l0 = __builtin_amdgcn_readfirstlane(my);
             ulen = (l0 > 0 && !__builtin_amdgcn_ballot_w64(lane < nr && my != l0)) ? l0 : 0;
         }
@@ -1052,7 +1102,11 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     const uint32_t key = h & 0xFFFFu;
                     int t;
                     bool ok = true;
-                    if (ulen > 0) {
+                    if (SCAT) {  // (slots of equal size)
+                        t = (int)(((uint32_t)(pos >> 4) * (uint32_t)a.vps_inv) >> 16);
+                        ok = t < nr;
+                        t = ok ? t : 0;
+                    } else if (ulen > 0) {
                         const int x = pos - fb0;
                         t = (int)((float)x * rinv);
                         t = t * ulen > x ? t - 1 : t;
@@ -1065,8 +1119,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         while (t > 0 && pos < fb[t]) --t;
                         while (t < nr - 1 && pos >= fb[t + 1]) ++t;
                     }
-                    const int f0 = fb[t], f1 = fb[t + 1];
-                    const int p = pos - f0, n = f1 - f0;
+                    const int f0 = fb[t];
+                    const int p = pos - f0, n = SCAT ? rl[t] : fb[t + 1] - f0;
                     // a seed lies inside its read (final_search_range = 1:n for this kernel's configs, classification.jl:795-800)
                     if (ok && p >= 0 && p + q <= n) {
                         // the key is in the bitmap (the bitmap is exact): its entry is the one with the key's rank among the
@@ -1224,22 +1278,21 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             geo = geo_next;
             ov = ov_next;
             ov_next = ov_after;
-            so = so_next;
             so_next = so_after;
-            iv = iv_next;
             iv_next = iv_after;
             iv_after = iv_after2;
+            par ^= 1;
             continue;
         }
 
         // ---- verdicts: lane = read; reducer replay on the survivors' unit distances ----
         const bool active = lane < nr;
-        const long long ridx = PAIRS ? (long long)gid[lane < RW ? lane : 0] : r0 + lane;
+        const long long ridx = SCAT ? (long long)gid[lane < RW ? lane : 0] : r0 + lane;
         Verdict vd{0, 0, -1, -1};
         PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
         bool done = false;
         if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
-            const int n = rlen(lane);
+            const int n = WINM ? tn[lane] : rlen(lane);  // (window mode: the keep range is the whole READ, :907-908)
             const int cnt = scnt[lane], cnt1 = dual ? wcl1[lane] : 0;
             // known-score class per read: this kernel only runs for configs whose ranges resolve to
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
@@ -1397,11 +1450,10 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
         geo = geo_next;
         ov = ov_next;
         ov_next = ov_after;
-        so = so_next;
         so_next = so_after;
-        iv = iv_next;
         iv_next = iv_after;
         iv_after = iv_after2;
+        par ^= 1;
     }
 
     flush_list();
@@ -1414,17 +1466,17 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     }
 }
 
-template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true>
+template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true, bool WINM = false>
 hipError_t launch_wave(const WaveArgs &a, size_t lds, int waves, long long blocks, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN, WINM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL((bdx_wave_kernel<RW, TF, NV, Q, SPLIT, KB, NW, MG, KEND, GEN, WINM>), dim3((unsigned)blocks), dim3(64 * waves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1450,7 +1502,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.B = wp.n_barcodes;
     a.q = wp.q;
     a.span_cap = wp.span_cap;
-    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.cand_words + (wp.ranged ? 4 : 0));
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, wp.pairs_kb > 0, wp.hq_cap, wp.sq_cap, wp.cand_words + (wp.ranged ? 4 : 0), wp.winm != 0);
     a.hq_cap = wp.hq_cap;
     a.sq_cap = wp.sq_cap;
     a.list = list;
@@ -1478,6 +1530,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.vps = 1;
     a.vps_inv = 65536;
     a.max_len = 0;
+    a.win_sfe = a.win_efe = a.win_so = a.win_eo = 0;
     a.cpr = 1;
     a.cpr_inv = 65536;
     a.idmap = nullptr;
@@ -1493,7 +1546,62 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 
-#if !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND) && !defined(BDX_WAVE_TU_KREV)
+#if defined(BDX_WAVE_TU_WIN)  // the window-mode instantiations (bdx_wave_win.hip)
+
+// Window mode: a single-pass known-score config whose column window is much shorter than its reads; tier 1 or the only
+// wave launch of the config, same outputs and the same list as bdx_launch_wave.
+hipError_t bdx_launch_wave_win(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
+                               long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
+                               unsigned int *list_count, hipStream_t stream, int dbg) {
+    if (n_reads <= 0) return hipSuccess;
+    if (!wp.winm || wp.pairs_kb > 0 || wp.split || wp.kend || cfg.is_dual || !wp.ranged || wp.slot < 16 || (wp.slot & 15)) return BDX_BAD_PLAN();
+    WaveArgs a;
+    fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, nullptr);
+    a.seq = d_seq;
+    a.off = d_off;
+    a.n_reads = n_reads;
+    a.tier = tier1;
+    a.tier_slo = tier_slo;
+    a.ranged = 0;     // (the window is resolved by the tile loader: downstream the window IS the read)
+    {
+        const BdxDevRange &dr = cfg.pass[0].ref_search;
+        const long long LIM = 1LL << 28;
+        if (dr.start_offset < -LIM || dr.start_offset > LIM || dr.end_offset < -LIM || dr.end_offset > LIM) return BDX_BAD_PLAN();
+        a.win_sfe = dr.start_from_end ? 1 : 0;
+        a.win_so = (int)dr.start_offset;
+        a.win_efe = dr.end_from_end ? 1 : 0;
+        a.win_eo = (int)dr.end_offset;
+    }
+    a.scan_gpr = 0;
+    a.slot = wp.slot;
+    a.vps = wp.slot >> 4;
+    a.vps_inv = (65536 + a.vps - 1) / a.vps;
+    a.idmap = nullptr;
+    a.n_dev = nullptr;
+    a.per_wave = (int)bdx_wave_area_bytes(wp.rw, wp.span_cap, false, wp.hq_cap, wp.sq_cap, 0, true);
+    const size_t lds = bdx_wave_table_bytes(wp, hist_entries) + (size_t)wp.waves * (size_t)a.per_wave;
+    const long long tiles = (n_reads + wp.rw - 1) / wp.rw;
+    long long blocks = (long long)wp.blocks;
+    const long long useful = (tiles + wp.waves - 1) / wp.waves;
+    if (blocks > useful) blocks = useful;
+    if (blocks < 1) blocks = 1;
+    const int tf = wp.track_from;
+    const int vecs = wp.rw * a.vps;  // 16-byte vectors of a tile
+    if (wp.rw * wp.slot + 16 > wp.span_cap) return BDX_BAD_PLAN();
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 0, true, true>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_TF(RWV, NVV)                                                                              \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_SP(RWV, 20, NVV, 8) : tf >= 12 ? BDX_WAVE_SP(RWV, 12, NVV, 8) : BDX_WAVE_SP(RWV, 0, NVV, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_SP(RWV, 12, NVV, 7) : BDX_WAVE_SP(RWV, 0, NVV, 7))                      \
+                       : BDX_WAVE_SP(RWV, 0, NVV, 6)
+    if (wp.rw == 32 && vecs <= 64 * 3) BDX_WAVE_TF(32, 3);
+    if (wp.rw == 32 && vecs <= 64 * 7) BDX_WAVE_TF(32, 7);
+    if (wp.rw == 16 && vecs <= 64 * 4) BDX_WAVE_TF(16, 4);
+    return BDX_BAD_PLAN();
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_SP
+}
+
+#elif !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND) && !defined(BDX_WAVE_TU_KREV)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
@@ -1501,11 +1609,11 @@ size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
            al(wp.kend == 2 ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
-size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words) {
+size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words, bool winm) {
     const size_t nvec = (size_t)span_cap >> 4;
     const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4;  // record tables
     const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
-                         (pairs ? 2 * (size_t)rw * 4 + 16 : 0);
+                         ((pairs || winm) ? 2 * (size_t)rw * 4 + 16 + 2 * (size_t)rw * 20 : 0) + (winm ? (size_t)rw * 4 + 2 * (size_t)rw * 4 : 0);
     const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + ((2 * nvec + 6 + 3) & ~(size_t)3) * 4 + ((size_t)hq_cap + (pairs ? 0 : (size_t)sq_cap) + (size_t)rw * (size_t)cand_words) * 4;
     return (o + 31) & ~(size_t)31;
 }

@@ -548,3 +548,95 @@ def test_tier0_planned_for_a_fraction_of_the_batch(div, monkeypatch):
         monkeypatch.delenv("BDX_TIER0_DIV")
         fuzz.assert_same(hc.classify(seq, off), exp, f"div {div} [{hc.kernel_path}]")
         assert hc.kernel_path.startswith("tier1:") and hc.pair_launches == 0, hc.kernel_path
+
+
+# ---- window mode (round 4): reads much longer than their column window — scattered tiles that hold only the windows ----
+def _win_three_ways(cfg, seq, off, monkeypatch, expect_win=True, hint=None):
+    """window mode, BDX_NO_WIN (whole tiles / general kernel), BDX_NO_WAVE: all equal the oracle, counters included."""
+    oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False)
+    exp = oc.classify(seq, off)
+    for env in (None, "BDX_NO_WIN", "BDX_NO_WAVE"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+            if env:
+                monkeypatch.delenv(env)
+            if hint is not None:
+                hc.set_read_length_hint(hint)
+            got = hc.classify(seq, off)
+            fuzz.assert_same(got, exp, f"{env} [{hc.kernel_path}]")
+            assert np.array_equal(hc.counts, oc.counts), (env, hc.kernel_path)
+            assert ("wave(win)" in hc.kernel_path) == (env is None and expect_win), (env, hc.kernel_path)
+            fuzz.assert_same(hc.classify(seq, off), exp, f"{env}, second call [{hc.kernel_path}]")
+    return exp
+
+
+@pytest.mark.parametrize("rng_str,kw", [
+    ("1:60", dict()), ("1:60", dict(max_error_rate=0.2)), ("1:60", dict(min_delta=0.05)), ("20:70", dict()), ("end-59:end", dict()),
+    ("end-70:end-10", dict(max_error_rate=0.2, min_delta=0.08)), ("5:40", dict(max_error_rate=0.13)),
+], ids=lambda v: str(v))
+def test_window_mode_c2_shape(rng_str, kw, monkeypatch):
+    bcs = synth.make_barcodes(96, 24, seed=301)
+    lo, hi = {"1:60": (0, 36), "20:70": (19, 46), "end-59:end": (90, 126), "end-70:end-10": (80, 116), "5:40": (4, 16)}[rng_str]
+    seq, off, _ = synth.make_reads(bcs, 50000, 150, seed=302, plant_lo=lo, plant_hi=hi, sub=0.03, ins=0.01, dele=0.01)
+    cfg = _cfg(bcs, ref_search_range=H.bdx.parse_dynamic_range(rng_str), **kw)
+    exp = _win_three_ways(cfg, seq, off, monkeypatch)
+    assert (exp["bc1"] > 0).mean() > 0.2
+
+
+def test_window_mode_ragged_reads_wrong_hints_and_unaligned_offsets(monkeypatch):
+    """Reads of 0..400 bases with a 1:80 window and an end-anchored one: reads shorter than the window, shorter than a barcode,
+    empty; the planned length (hint) too small and too large; odd offsets (every slot starts at another address mod 16)."""
+    bcs = synth.make_barcodes(64, 24, seed=311)
+    seq, off, _ = synth.make_ragged_reads(bcs, 30000, 0, 400, seed=312, plant_hi=50, sub=0.03, ins=0.01, dele=0.01)
+    for rng_str in ("1:80", "end-99:end-20"):
+        cfg = _cfg(bcs, ref_search_range=H.bdx.parse_dynamic_range(rng_str))
+        for hint in (None, 400, 170):
+            _win_three_ways(cfg, seq, off, monkeypatch, hint=hint)
+        _win_three_ways(cfg, seq, off, monkeypatch, hint=100, expect_win=False)  # (window 80 of 100 planned bases: whole tiles)
+
+
+def _win_device_three_ways(cfg, seq, off, monkeypatch, hint=None, expect_win=True):
+    """The same through the DEVICE entry point (the host entry point uploads only the windows of such batches and classifies
+    them as virtual reads on the general kernel: bdx_window_uploads)."""
+    import torch
+
+    n = len(off) - 1
+    oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False)
+    exp = oc.classify(seq, off)
+    dev = torch.device("cuda:0")
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    for env in (None, "BDX_NO_WIN", "BDX_NO_WAVE"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        out = {k: torch.empty(n, dtype=torch.int32, device=dev) for k in ("bc1", "bc2", "keep_start", "keep_end")}
+        with H.bdx.HipClassifier(cfg) as hc:
+            if env:
+                monkeypatch.delenv(env)
+            if hint is not None:
+                hc.set_read_length_hint(hint)
+            for _ in range(2):
+                hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n, **{k: v.data_ptr() for k, v in out.items()})
+                hc.sync()
+                for k, v in out.items():
+                    got = v.cpu().numpy()
+                    assert np.array_equal(got, exp[k]), (env, k, hc.kernel_path, np.flatnonzero(got != exp[k])[:5])
+            assert np.array_equal(hc.counts, 2 * oc.counts), (env, hc.kernel_path)
+            assert ("wave(win)" in hc.kernel_path) == (env is None and expect_win), (env, hc.kernel_path)
+    return exp
+
+
+def test_window_mode_c5_shape_long_reads_mixed_barcode_lengths(monkeypatch):
+    """BASELINE config 5's shape: 10 kbp reads, 24 barcodes of 16..32 nt, window 1:200, rate 0.2 (tier 1 in window mode,
+    tier 0 the general kernel), and rate 0.1."""
+    lens = np.random.Generator(np.random.PCG64(5)).integers(16, 33, size=24)
+    bcs = synth.make_barcodes(24, 24, seed=5, lengths=lens)
+    seq, off, _ = synth.make_reads(bcs, 6000, 10000, seed=321, plant_lo=0, plant_hi=150, sub=0.03, ins=0.01, dele=0.01)
+    for rate in (0.2, 0.1):
+        cfg = _cfg(bcs, max_error_rate=rate, ref_search_range=H.bdx.parse_dynamic_range("1:200"))
+        exp = _win_device_three_ways(cfg, seq, off, monkeypatch, hint=10000)
+        assert (exp["bc1"] > 0).mean() > 0.5
+    # ragged long reads (2..12 kbp), no hint
+    seq, off, _ = synth.make_ragged_reads(bcs, 3000, 2000, 12000, seed=322, plant_hi=150, sub=0.03, ins=0.01, dele=0.01)
+    _win_device_three_ways(_cfg(bcs, max_error_rate=0.2, ref_search_range=H.bdx.parse_dynamic_range("1:200")), seq, off, monkeypatch)
