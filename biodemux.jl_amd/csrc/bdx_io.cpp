@@ -29,10 +29,110 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
 #include <vector>
+
+// ---- persistent worker pool --------------------------------------------------------------------------------------
+// The parallel sections of the reader (line index, packer) and of the writer (sizes, gather / iovecs, files) run on a
+// pool that belongs to the CALLING thread (the pipeline's reader and writer threads each keep their own for the whole
+// run) instead of starting and joining a set of std::threads per section: a 10 M-read run has ~140 sections per stage,
+// i.e. ~2 200 thread starts at a few tens of microseconds each on the coordinating thread.  Tasks are claimed with an
+// atomic counter; the caller works too.
+class WorkPool {
+  public:
+    ~WorkPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_start_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    template <class F>
+    void run(int n, F &&f) {
+        if (n <= 1) {
+            if (n == 1) f(0);
+            return;
+        }
+        while ((int)th_.size() < n - 1) th_.emplace_back([this]() { worker(); });
+        std::function<void(int)> job = std::ref(f);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &job;
+            njobs_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = n;
+            ++gen_;
+        }
+        cv_start_.notify_all();
+        work(job, n);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this]() { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void work(const std::function<void(int)> &job, int n) {
+        int finished = 0;
+        for (;;) {
+            const int i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) break;
+            job(i);
+            ++finished;
+        }
+        if (finished) {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_ -= finished;
+            if (pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job = nullptr;
+            int n = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_start_.wait(lk, [&]() { return stop_ || (gen_ != seen && job_ != nullptr); });
+                if (stop_) return;
+                seen = gen_;
+                job = job_;
+                n = njobs_;
+            }
+            // (the job object lives until pending_ reaches 0: a worker that arrives after the last task was claimed only
+            // reads the counter)
+            int finished = 0;
+            for (;;) {
+                const int i = next_.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n) break;
+                (*job)(i);
+                ++finished;
+            }
+            if (finished) {
+                std::lock_guard<std::mutex> lk(mu_);
+                pending_ -= finished;
+                if (pending_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int njobs_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+template <class F>
+static void parallel_for(int n, F &&f) {
+    static thread_local WorkPool pool;
+    pool.run(n, std::forward<F>(f));
+}
 
 extern "C" {
 
@@ -109,9 +209,8 @@ static int64_t inflate_tagged_chain(bdx_fq_file *f, const uint8_t *comp, size_t 
         std::mutex pub;
         size_t published = 0;
         const int T = std::max(1, std::min<int>(nthreads, (int)ms.size()));
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&]() {
+                parallel_for(T, [&](const int t) {
+            (void)t;
                 for (;;) {
                     const size_t i = next.fetch_add(1);
                     if (i >= ms.size() || bad.load() || f->cancel.load(std::memory_order_relaxed)) break;
@@ -143,7 +242,6 @@ static int64_t inflate_tagged_chain(bdx_fq_file *f, const uint8_t *comp, size_t 
                     }
                 }
             });
-        for (auto &t : th) t.join();
         if (bad.load()) return -1;
         result = (int64_t)uoff;
     }
@@ -363,9 +461,8 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
         std::vector<std::unique_ptr<uint32_t[]>> pos((size_t)T);
         std::vector<int64_t> cnt((size_t)T, 0);
         {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t)
-                th.emplace_back([&, t]() {
+                        parallel_for(T, [&](const int t) {
+                (void)t;
                     const int64_t a = std::min(hi, scanned_to + span * t), b = std::min(hi, a + span);
                     // (a slice has at most one newline per byte; FASTQ lines are long, so a bound that is usually
                     // generous is tried first and the slice is rescanned with the exact count if it does not hold)
@@ -391,7 +488,6 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
                         cap = n;
                     }
                 });
-            for (auto &t : th) t.join();
         }
         // prefix over the slices: first line index and the end of the last line before every slice
         std::vector<int64_t> first((size_t)T + 1, 0), prev_end((size_t)T, 0);
@@ -407,9 +503,8 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
         const int64_t room = want - nlines;
         const int64_t take = std::min<int64_t>(first[(size_t)T], room);
         {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t)
-                th.emplace_back([&, t]() {
+                        parallel_for(T, [&](const int t) {
+                (void)t;
                     const int64_t a = std::min(hi, scanned_to + span * t);
                     int64_t lcur = prev_end[(size_t)t];
                     const int64_t k0 = first[(size_t)t], k1 = std::min<int64_t>(first[(size_t)t + 1], take);
@@ -422,7 +517,6 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
                         lcur = e + 1;
                     }
                 });
-            for (auto &t : th) t.join();
         }
         if (take > 0) {
             // the cursor after the last line taken
@@ -488,15 +582,13 @@ void bdx_fq_pack(const bdx_fq_file *f, const int64_t *line_off, const int32_t *l
     seq_off[0] = 0;
     for (int64_t i = 0; i < nrec; ++i) seq_off[i + 1] = seq_off[i] + line_len[4 * i + 1];
     const int T = std::max(1, std::min<int>(nthreads, (int)(nrec >> 14) + 1));
-    std::vector<std::thread> th;
-    const int64_t per = (nrec + T - 1) / T;
-    for (int t = 0; t < T; ++t)
-        th.emplace_back([=]() {
+        const int64_t per = (nrec + T - 1) / T;
+    parallel_for(T, [=](const int t) {
+        (void)t;
             const int64_t a = per * t, b = std::min(nrec, a + per);
             for (int64_t i = a; i < b; ++i)
                 memcpy(seq_bytes + seq_off[i], f->data + line_off[4 * i + 1], (size_t)line_len[4 * i + 1]);
         });
-    for (auto &t : th) t.join();
 }
 
 int64_t bdx_fq_seq_bytes(const int32_t *line_len, int64_t nrec) {
@@ -592,9 +684,8 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
     std::vector<std::vector<char>> tplain((size_t)T, std::vector<char>((size_t)n_classes, 1));
     std::atomic<int> bad_class{0};
     {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
+                parallel_for(T, [&](const int t) {
+            (void)t;
                 const int64_t a0 = per * t, b0 = std::min(nrec, a0 + per);
                 auto &h = tbytes[(size_t)t];
                 auto &r = trecs[(size_t)t];
@@ -615,7 +706,6 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                     }
                 }
             });
-        for (auto &t : th) t.join();
     }
     if (bad_class.load()) {
         g_io_err = "class index out of range";
@@ -661,9 +751,8 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
     tm2 = now();
     // pass 2: the gather (heap classes) / the iovecs (the others)
     {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
+                parallel_for(T, [&](const int t) {
+            (void)t;
                 const int64_t a0 = per * t, b0 = std::min(nrec, a0 + per);
                 auto &pos = tbytes[(size_t)t];
                 auto &rpos = trecs[(size_t)t];
@@ -711,7 +800,6 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                     pos[(size_t)c] += hl + sl + pl + ql + 4;
                 }
             });
-        for (auto &t : th) t.join();
     }
     tm3 = now();
     // pass 3: gzip output — every 4 MiB piece of every class is deflated as a gzip member of its own by whichever thread
@@ -739,9 +827,7 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
     if (!members.empty()) {
         std::atomic<size_t> nextm{0};
         const int TM = std::max(1, std::min<int>(nthreads, (int)members.size()));
-        std::vector<std::thread> th;
-        for (int t = 0; t < TM; ++t)
-            th.emplace_back([&]() {
+        parallel_for(TM, [&](const int) {
                 for (;;) {
                     const size_t i = nextm.fetch_add(1);
                     if (i >= members.size()) break;
@@ -779,7 +865,6 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                     }
                 }
             });
-        for (auto &t : th) t.join();
     }
     // finish: the plain files (largest first: the unmatched reads' buffer is one long write) and the members of the
     // gzip files (consecutive in `members`), each file appended by one thread
@@ -788,9 +873,7 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
         std::sort(order.begin(), order.end(), [&](int x, int y) { return csize[(size_t)x] > csize[(size_t)y]; });
         std::atomic<size_t> nextc{0};
         const int TW = std::max(1, std::min<int>(nthreads, (int)order.size()));
-        std::vector<std::thread> th;
-        for (int t = 0; t < TW; ++t)
-            th.emplace_back([&]() {
+        parallel_for(TW, [&](const int) {
                 for (;;) {
                     const size_t k = nextc.fetch_add(1);
                     if (k >= order.size()) break;
@@ -852,7 +935,6 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                     if (close(fd) != 0) ds.fail = 1;
                 }
             });
-        for (auto &t : th) t.join();
     }
     if (timing)
         fprintf(stderr, "[bdx_io] writer: sizes %.1f ms, buffers %.1f ms, gather / iovecs %.1f ms, deflate + files %.1f ms (%lld records)\n",
