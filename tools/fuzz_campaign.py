@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
+import torch
+assert torch.cuda.is_available()  # (torch's HIP runtime has to come up before the library's first bdx_create: INTEGRATION.md)
 import fuzz
 import helpers as H
 from biodemux_jl_amd import synth
@@ -136,6 +138,63 @@ for seed in range(lo6, hi6):
             bad += 1
             print("MISMATCH", e, flush=True)
 print(f"wide seeds {lo6}..{hi6 - 1}: paths {paths6}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
+# round-4 domains: the known-trim class (unit costs, any mix of trim sides, no per-pass outputs), the same-diagonal pairs
+# variants (indels dearer than mismatches) and the window mode (device entry point: reads much longer than their window)
+lo7, hi7 = int(os.environ.get("SEED7_LO", "85000")), int(os.environ.get("SEED7_HI", "85300"))
+paths7 = {}
+t0 = time.time()
+for seed in range(lo7, hi7):
+    cfg, seq, off = fuzz.random_case_band(seed)
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x7A1))
+    kind = seed % 3
+    if kind == 0:    # known-trim
+        cfg.mismatch, cfg.indel, cfg.summary = 1, 1, False
+        if cfg.trim_side is None and (not cfg.is_dual or cfg.trim_side2 is None):
+            cfg.trim_side = [3, 5][int(rng.integers(0, 2))]
+    elif kind == 1:  # indels dearer than mismatches: budgets 4 .. 8 in mismatches
+        cfg.mismatch = int([1, 1, 2][int(rng.integers(0, 3))])
+        cfg.indel = cfg.mismatch * int(rng.integers(2, 4))
+        cfg.max_error_rate = float([0.2, 0.25, 0.25, 0.3, 0.34][int(rng.integers(0, 5))]) * cfg.mismatch
+        cfg.min_delta = float([0.0, 0.1, 0.15][int(rng.integers(0, 3))]) * cfg.mismatch
+    for want in (False, True) if kind != 2 else (False,):
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want).classify(seq, off)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                got = hc.classify(seq, off)
+                paths7[hc.kernel_path] = paths7.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"round-4 seed {seed} kind {kind} want_pass {want} [{hc.kernel_path}]")
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+    if kind == 2:    # window mode: single pass, ScoreOnly, a short window of long reads, through bdx_classify_device
+        import torch
+        m = len(cfg.bc_seqs[0])
+        L = int([400, 1000, 3000][int(rng.integers(0, 3))])
+        wl = int(rng.integers(m + 8, 180))
+        rs = ["1:%d" % wl, "%d:%d" % (int(rng.integers(2, 60)), int(rng.integers(61, 200))), "end-%d:end" % (wl - 1), "end-%d:end-%d" % (wl + 20, 21)][int(rng.integers(0, 4))]
+        c2 = H.bdx.DemuxConfig(bc_seqs=cfg.bc_seqs, bc_lengths_no_N=cfg.bc_lengths_no_N, ids=cfg.ids, max_error_rate=float([0.1, 0.13, 0.2][int(rng.integers(0, 3))]),
+                               min_delta=cfg.min_delta, ref_search_range=H.bdx.parse_dynamic_range(rs))
+        lo_p = 0 if not rs.startswith("end") else max(0, L - wl - 25)
+        seq2, off2, _ = synth.make_ragged_reads(cfg.bc_seqs, 1200, L // 2, L, seed=seed, plant_lo=lo_p, plant_hi=lo_p + max(1, wl - m), sub=0.03, ins=0.01, dele=0.01)
+        exp = H.orc.OracleClassifier(c2, nthreads=16, want_pass=False).classify(seq2, off2)
+        n2 = len(off2) - 1
+        dev = torch.device("cuda:0")
+        d_seq, d_off = torch.from_numpy(seq2).to(dev), torch.from_numpy(off2).to(dev)
+        out = {k: torch.empty(n2, dtype=torch.int32, device=dev) for k in ("bc1", "bc2", "keep_start", "keep_end")}
+        try:
+            with H.bdx.HipClassifier(c2) as hc:
+                hc.classify_device(d_seq.data_ptr(), d_off.data_ptr(), n2, **{k: v.data_ptr() for k, v in out.items()})
+                hc.sync()
+                paths7[hc.kernel_path] = paths7.get(hc.kernel_path, 0) + 1
+                for k, v in out.items():
+                    got = v.cpu().numpy()
+                    assert np.array_equal(got, exp[k]), f"round-4 seed {seed} window mode {rs} L {L}: {k} differs at {np.flatnonzero(got != exp[k])[:5].tolist()} [{hc.kernel_path}]"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"round-4 seeds {lo7}..{hi7 - 1}: paths {paths7}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
 def stress(name, bcs, seq, off, **kw):
