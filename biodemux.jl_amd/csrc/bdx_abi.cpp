@@ -161,6 +161,7 @@ int plan_generic(bdx_ctx *ctx) {
 // barcode, or with one beyond kb1 — are filtered again at the full budget (tier 0, in list mode).
 long long tier_cap(const bdx_ctx *ctx, int m) {
     if (ctx->cur == 0) return (1LL << 40);
+    if (ctx->tier_cap_fixed >= 0) return ctx->tier_cap_fixed;  // (the pairs tier)
     const int q = ctx->tier_q >= 5 && ctx->tier_q <= 8 ? ctx->tier_q : 8;
     const int c = m / q - 1;
     return c > 0 ? c : 0;
@@ -947,7 +948,8 @@ int build_pair_tables(bdx_ctx *ctx) {
     wp = BdxWavePlan{};
     const BdxBitparPlan &bp = F.bplan;
     const int npass = c.is_dual ? 2 : 1;
-    if (ctx->tune.no_wave || ctx->tune.no_pairs || !bp.enabled || bp.word_bytes != 4 || bp.tier_capped || c.filter != BDX_FILTER_AUTO ||
+    // (a capped set gets pair tables only as the pairs tier: budgets capped at tier_cap_fixed operations)
+    if (ctx->tune.no_wave || ctx->tune.no_pairs || !bp.enabled || bp.word_bytes != 4 || (bp.tier_capped && ctx->tier_cap_fixed < 0) || c.filter != BDX_FILTER_AUTO ||
         (c.algorithm == BDX_ALG_SEMIGLOBAL && c.has_nindel))
         return BDX_OK;
     bool split = false;
@@ -955,6 +957,9 @@ int build_pair_tables(bdx_ctx *ctx) {
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
     const int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
     if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
+    // the pairs tier (capped set): the filter only has to be lossless for alignments of COST <= cap x cmin — a barcode it does not
+    // flag costs more, i.e. at least (cap + 1) cmin = the tier's slo (costs are integers; the tier exists for mismatch = cmin = 1)
+    const long long cost_cap = (ctx->cur == 1 && ctx->tier_cap_fixed >= 0) ? (long long)ctx->tier_cap_fixed * cmin : (1LL << 40);
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     int Btot = 0, cwt = 0;
     bool ranged = false;
@@ -999,7 +1004,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     for (int k = 0; k < npass; ++k)
         for (int b = 0; b < c.pass[k].n_barcodes; ++b) {
             const int m = (int)(c.pass[k].bc_off[b + 1] - c.pass[k].bc_off[b]);
-            const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);
+            const long long ae = std::min(cost_cap, c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m));
             if (ae >= 0 && (ae / cmin > 4 || 4 * (ae / cmin + 2) > m)) classic_ok = false;
         }
     int sd_pl = 0, sd_spread = 0;
@@ -1012,7 +1017,7 @@ int build_pair_tables(bdx_ctx *ctx) {
                 const bdx_pass_t &p = c.pass[k];
                 for (int b = 0; b < p.n_barcodes && ok; ++b) {
                     const int m = (int)(p.bc_off[b + 1] - p.bc_off[b]);
-                    const long long ae = (long long)std::floor(c.max_error_rate * (double)m);
+                    const long long ae = std::min(cost_cap, (long long)std::floor(c.max_error_rate * (double)m));
                     if (ae < 0) continue;
                     const int P = std::min(pl == 4 ? 6 : 8, m / pl);
                     const long long gmax = ae / c.indel;
@@ -1051,7 +1056,7 @@ int build_pair_tables(bdx_ctx *ctx) {
                         if (((bc[m - 1 - i] >> 1) & 3) == code) maskr |= 1u << (shift + i);
                 peq8r[(size_t)g * 9 + code] = maskr;
             }
-            const long long ae = c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m);
+            const long long ae = std::min(cost_cap, c.algorithm == BDX_ALG_EXACT ? 0 : (long long)std::floor(c.max_error_rate * (double)m));
             if (ae < 0) {  // can never be recorded: in no table entry, never swept
                 meta[(size_t)g] = (uint32_t)m | (255u << 8) | (255u << 16);
                 continue;
@@ -2015,6 +2020,37 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
                     if (!(ctx->fs[1].bplan.tier_slo[k] >= config->min_delta)) ctx->tiered = 0;
         }
     }
+    // The PAIRS TIER: a split config with min_delta whose seed tier proves nothing (above), mismatch = cmin = 1 and indels dearer —
+    // the reference's demo2 options (mismatch 1, indel 2, rate 0.25, min_delta 0.15): tier 1 = the same-diagonal pairs mode with
+    // six 4-base pieces over the WHOLE batch at budgets capped at 4 (3) operations — ~3 chance flags per read instead of the ~90 of
+    // the full-budget variant — followed by the exact kernel, which settles every read whose winner leaves min_delta of room below
+    // slo = (cap + 1) / m (a perfect match or one mismatch under demo2's options: ~75 % of the reads) and lists the rest for tier 0.
+    if (!ctx->tiered && ctx->fs[0].bplan.enabled && ctx->fs[0].pplan.enabled && ctx->fs[0].pplan.split && !ctx->tune.no_tier && !ctx->tune.no_pairs &&
+        config->filter == BDX_FILTER_AUTO && config->algorithm == BDX_ALG_SEMIGLOBAL && !config->has_nindel && config->mismatch == 1 &&
+        config->indel >= 2 && config->match == 0 && config->min_delta != 0.0) {
+        bool plain = true;
+        for (int k = 0; k < (config->is_dual ? 2 : 1); ++k) plain = plain && config->pass[k].explicit_window == 0;
+        for (int cap = 4; cap >= 3 && plain && !ctx->tiered; --cap) {
+            ctx->tier_cap_fixed = cap;
+            ctx->cur = 1;
+            ctx->fs[1].splan = BdxSeedPlan{};
+            ctx->fs[1].wplan = BdxWavePlan{};
+            rc = build_bitpar_tables(ctx);
+            bool ok = rc == BDX_OK && ctx->fs[1].bplan.enabled && ctx->fs[1].bplan.tier_capped;
+            for (int k = 0; ok && k < (config->is_dual ? 2 : 1); ++k) ok = ctx->fs[1].bplan.tier_slo[k] >= config->min_delta;
+            if (ok) rc = build_pair_tables(ctx);
+            ok = ok && rc == BDX_OK && ctx->fs[1].pplan.enabled && ctx->fs[1].pplan.pairs_kb == 8 && ctx->fs[1].pplan.split;
+            ctx->cur = 0;
+            if (rc != BDX_OK) return bail(rc);
+            if (ok) {
+                ctx->tiered = 1;
+                ctx->pairs_tier = 1;
+            } else {
+                ctx->tier_cap_fixed = -1;
+                ctx->fs[1].bplan.enabled = 0;
+            }
+        }
+    }
     ctx->path = ctx->F().bplan.enabled ? (ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify") : "generic";
     if (ctx->tiered) ctx->path = "tier1:qgram+bitpar > " + ctx->path;
     ctx->filter_used = ctx->F().bplan.enabled ? (ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR) : BDX_FILTER_OFF;
@@ -2321,7 +2357,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // split configs (trimming, summary, weighted costs): the wave kernel as the FILTER of a dense launch — candidate
         // masks and column windows in the formats of the general kernel's split mode, every verdict from the exact
         // kernel as before.  Tiered: tier 1 (all reads); plain: the only filter launch.
-        bool wsplit1 = false, wsplit0 = false;
+        bool wsplit1 = false, wsplit0 = false, pairs_t1 = false;
         BdxWaveSplit wsp{};
         for (int k = 0; k < 2; ++k) {
             wsp.cw[k] = k < npass ? ctx->dev.pass[k].cand_words : 0;
@@ -2370,6 +2406,12 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
                 HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, f1.wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                                  ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug, f1.bplan.tier_slo[1]));
                 ctx->wave_launches += 1;
+            } else if (ctx->pairs_tier && split && windows && !dense_w && !ctx->dev.vlen && size_pairs(ctx, f1.pplan, batch_len)) {
+                // the pairs tier: tier 1's filter is the same-diagonal pairs mode over every read of the batch
+                HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, f1.pplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, nullptr,
+                                              nullptr, o, nullptr, nullptr, nullptr, ctx->stream, ctx->tune.debug >> 8, &wsp));
+                ctx->pair_launches += 1;
+                pairs_t1 = true;
             } else if (wsplit1) {  // tier 1's filter as the wave-autonomous kernel (split mode: the exact kernel settles and lists)
                 HIP_TRY(ctx, bdx_launch_wave(ctx->dev, f1.wplan, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                              nullptr, (int *)(scratch + 256), 0, 0.0, nullptr, nullptr, ctx->stream, ctx->tune.debug, &wsp));
@@ -2494,7 +2536,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (wsplit0) ctx->path = "wave+verify";
         if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
         if (pairs_all) ctx->path = "pairs(diag)+verify";
-        if (tiered) ctx->path = (wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (tiered) ctx->path = (pairs_t1 ? "tier1:pairs(diag) > " : wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = (ctx->fs[0].wplan.winm ? "wave(win) > " : "wave > ") + ctx->path;
         if (wave0k) ctx->path = "wave(end) > " + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;

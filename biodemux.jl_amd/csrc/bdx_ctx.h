@@ -116,6 +116,9 @@ struct bdx_ctx {
     DevBuf d_vlen, d_vlo;
     int virt_maxlen = 0;     // > 0 while a window-upload batch is being classified: its longest read
     int tier_q = 8;          // piece length behind tier 1's capped budgets: cap(m) = m / tier_q - 1
+    int tier_cap_fixed = -1; // >= 0: the pairs tier — tier 1's budgets are capped at this many operations for every barcode and its
+                             // filter is the same-diagonal pairs mode over the whole batch (configs whose min_delta the seed tier cannot prove)
+    int pairs_tier = 0;
     bool scratch_zeroed = false;  // the small-batch copy kernel has already cleared the filter kernels' scratch words
     int host_maxlen = 0;     // > 0 while bdx_classify_host runs an ordinary batch: its longest read (seen on the host)
     void *h_stage = nullptr;  // page-locked staging for the verdict vectors of small batches

@@ -344,11 +344,15 @@ def test_pairs_dual_known_score(monkeypatch):
 
 # ---- same-diagonal variants: configs whose indels cost more than their mismatches (round 4) ----
 @pytest.mark.parametrize("kw,path", [
-    (dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), "pairs(diag)+verify"),   # the reference's demo2 options: budget 6 of 24, eight 3-base pieces
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), "tier1:pairs(diag) > pairs+verify"),   # the reference's demo2 options: budget 6 of 24 — the pairs tier (six 4-base pieces, cost <= 4) in front of eight 3-base pieces
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.22), "pairs(diag)+verify"),   # min_delta beyond the pairs tier's slo = 5 / 24 too: one filter over the whole batch
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.18), "tier1:pairs(diag) > pairs+verify"),   # only perfect matches settle
     (dict(max_error_rate=0.25, mismatch=1, indel=2), None),    # (without min_delta: tier 1 in front, the variant is tier 0's filter)
     (dict(max_error_rate=0.25, mismatch=1, indel=2, trim_side=3), None),
     (dict(max_error_rate=0.25, mismatch=1, indel=3, min_delta=0.1, trim_side=5), None),
-    (dict(max_error_rate=0.25, mismatch=1, indel=2, summary=True, min_delta=0.15), "pairs(diag)+verify"),
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, summary=True, min_delta=0.15), "tier1:pairs(diag) > pairs+verify"),
+    (dict(max_error_rate=0.25, mismatch=1, indel=2, trim_side=3, min_delta=0.15), "tier1:pairs(diag) > pairs+verify"),
+    (dict(max_error_rate=0.25, mismatch=1, indel=3, min_delta=0.2), None),
     (dict(max_error_rate=0.2, mismatch=1, indel=2), None),     # budget 4: six 4-base pieces (as tier 0 behind tier 1)
     (dict(max_error_rate=0.34, mismatch=2, indel=4, min_delta=0.1), None),  # budget 8 = 4 mismatches
     (dict(max_error_rate=0.3, mismatch=1, indel=2), None),     # budget 7: no variant qualifies -> plain sweep
@@ -389,3 +393,24 @@ def test_pairs_same_diagonal_low_complexity_overflow(monkeypatch):
         r = seq[off[i]:off[i + 1]]
         r[:] = np.where(rng.random(150) < 0.85, np.frombuffer(b"ACAC" * 38, dtype=np.uint8)[:150], r)
     _with_and_without(_cfg(bcs, max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15), seq, off, monkeypatch)
+    _with_and_without(_cfg(bcs, max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.22), seq, off, monkeypatch)
+
+
+def test_pairs_tier_equals_one_tier(monkeypatch):
+    """The pairs tier (tier 1 = same-diagonal pairs mode capped at cost 4 over the whole batch) against BDX_NO_TIER (one
+    full-budget filter) on demo2's options: identical outputs incl. per-pass scores and deltas, counters, statistics-free."""
+    bcs = synth.make_barcodes(96, 24, seed=81)
+    seq, off, _ = synth.make_reads(bcs, 60000, 150, seed=82, sub=0.04, ins=0.01, dele=0.01, repeat=dict(frac=0.15))
+    for kw in (dict(), dict(trim_side=5), dict(trim_side=3, summary=True)):
+        cfg = _cfg(bcs, max_error_rate=0.25, mismatch=1, indel=2, min_delta=0.15, **kw)
+        oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=True)
+        exp = oc.classify(seq, off)
+        for env in (None, "BDX_NO_TIER"):
+            if env:
+                monkeypatch.setenv(env, "1")
+            with H.bdx.HipClassifier(cfg, want_pass=True) as hc:
+                if env:
+                    monkeypatch.delenv(env)
+                fuzz.assert_same(hc.classify(seq, off), exp, f"{kw} {env} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), (env, hc.kernel_path)
+                assert hc.kernel_path.startswith("tier1:pairs(diag)") == (env is None), hc.kernel_path
