@@ -806,6 +806,21 @@ int build_wave_tables(bdx_ctx *ctx) {
                 if (c.pass[k].trim_side == 3) F.wplan_k.kend = 2;  // (reversed sweeps: bdx_wave_rev.hip)
         }
     }
+    // Known-alignment class: the same conditions with `summary` allowed — start AND end of every pass's winner come out of one
+    // more (anchored) sweep per pass and read, so per-pass positions and the DemuxStats histograms need no exact kernel either
+    // (bdx_wave_aln.hip); taken per launch when the caller wants positions the known-trim class does not know, or statistics.
+    F.wplan_a = BdxWavePlan{};
+    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !ctx->tune.no_known &&
+        !ctx->tune.no_kend && !getenv("BDX_NO_KALN")) {
+        bool fits = true;
+        for (uint32_t x : meta) fits = fits && (((x >> 8) & 255u) == 255u || ((x >> 8) & 255u) < 64u);
+        if (fits && c.pass[0].n_barcodes <= 1023 && (!c.is_dual || c.pass[1].n_barcodes <= 1023)) {
+            F.wplan_a = wp;
+            F.wplan_a.split = 0;
+            F.wplan_a.cand_words = c.is_dual ? 4 : 0;
+            F.wplan_a.kend = 3;
+        }
+    }
     return BDX_OK;
 }
 
@@ -2346,10 +2361,13 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         bool trim3 = false;  // (a trim_side = 3 pass of the known-trim class knows its start only)
         for (int k = 0; k < npass; ++k) trim3 |= ctx->dev.pass[k].trim_side == 3;
         const bool kend_ok = split && windows && !ctx->dev.vlen && !dense_w && o.pass_start == nullptr && stp == nullptr && !(trim3 && o.pass_end != nullptr);
-        if (kend_ok) {
+        // known-alignment class: the caller wants positions the known-trim class does not know, or the statistics tables
+        const bool aln_ok = split && windows && !ctx->dev.vlen && !dense_w && !kend_ok && ctx->fs[tiered ? 1 : 0].wplan_a.enabled;
+        BdxWavePlan &wk1 = aln_ok ? ctx->fs[1].wplan_a : ctx->fs[1].wplan_k, &wk0 = aln_ok ? ctx->fs[0].wplan_a : ctx->fs[0].wplan_k;
+        if (kend_ok || aln_ok) {
             if (tiered)
-                wave1k = size_wave(ctx, ctx->fs[1].wplan_k, batch_len, n_reads);
-            else if (size_wave(ctx, ctx->fs[0].wplan_k, batch_len, n_reads)) {
+                wave1k = size_wave(ctx, wk1, batch_len, n_reads);
+            else if (size_wave(ctx, wk0, batch_len, n_reads)) {
                 wave0k = size_bitpar(ctx, batch_len, n_reads, true);
                 if (!wave0k) (void)size_bitpar(ctx, batch_len, n_reads);  // (restore the dense plan)
             }
@@ -2388,8 +2406,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         }
         if (wave0k) {
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
-            HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, ctx->fs[0].wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                             ctx->counts, 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192), ctx->stream, ctx->tune.debug));
+            HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, wk0, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                             ctx->counts, 0, 0.0, (uint32_t *)ctx->d_wlist.p, (unsigned int *)(scratch + 192), ctx->stream, ctx->tune.debug, 0.0,
+                                             aln_ok ? stp : nullptr));
             ctx->wave_launches += 1;
             t0.in_list = (const uint32_t *)ctx->d_wlist.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
@@ -2403,8 +2422,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             f1.bplan.grid_override = ctx->tune.grid;
             f1.bplan.dbg = ctx->tune.debug;
             if (wave1k) {  // tier 1 as the known-end form of the wave kernel: verdicts + trimmed keep range of what it settles, the rest listed
-                HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, f1.wplan_k, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
-                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug, f1.bplan.tier_slo[1]));
+                HIP_TRY(ctx, bdx_launch_wave_end(ctx->dev, wk1, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
+                                                 ctx->counts, 1, f1.bplan.tier_slo[0], t1.out_list, t1.out_count, ctx->stream, ctx->tune.debug, f1.bplan.tier_slo[1],
+                                                 aln_ok ? stp : nullptr));
                 ctx->wave_launches += 1;
             } else if (ctx->pairs_tier && split && windows && !dense_w && !ctx->dev.vlen && size_pairs(ctx, f1.pplan, batch_len)) {
                 // the pairs tier: tier 1's filter is the same-diagonal pairs mode over every read of the batch
@@ -2536,9 +2556,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         if (wsplit0) ctx->path = "wave+verify";
         if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
         if (pairs_all) ctx->path = "pairs(diag)+verify";
-        if (tiered) ctx->path = (pairs_t1 ? "tier1:pairs(diag) > " : wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
+        if (tiered) ctx->path = (pairs_t1 ? "tier1:pairs(diag) > " : (wave1k && aln_ok) ? "tier1:wave(aln) > " : wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = (ctx->fs[0].wplan.winm ? "wave(win) > " : "wave > ") + ctx->path;
-        if (wave0k) ctx->path = "wave(end) > " + ctx->path;
+        if (wave0k) ctx->path = (aln_ok ? "wave(aln) > " : "wave(end) > ") + ctx->path;
         ctx->filter_used = ctx->F().splan.enabled ? BDX_FILTER_QGRAM : BDX_FILTER_BITPAR;
     } else {
         HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,

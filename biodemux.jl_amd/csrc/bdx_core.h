@@ -1250,18 +1250,20 @@ __device__ __forceinline__ void classify_one(const BdxDevCfg &cfg, const Bytes<S
 // have no trim side; the keep range is the whole read as in :907-908, :932-935).
 // KEND: the known-trim class — the passes' entries carry position keys (run_pass_known): the winner's start (trim_side = 3) or end
 // (trim_side = 5) trims the keep range as in :910-929.
-template <bool KEND>
-__device__ __forceinline__ void known_positions(PassOut &po, const int trim_side) {
+// KEND = 2: the known-alignment class — a pass without a trim side keeps its end column too (the kernel then finds the other
+// position of every pass's winner with an anchored sweep).
+template <int KEND>
+__device__ __forceinline__ void known_positions(PassOut &po, const int trim_side, const bool need_tb) {
     if (!KEND) return;
     const int key = po.end;  // (-1: no winner)
     po.start = -1;
     po.end = -1;
     if (key < 0) return;
     if (trim_side == 3) po.start = 0xFFFF - key;
-    if (trim_side == 5) po.end = key;
+    if (trim_side == 5 || (KEND == 2 && trim_side == 0 && need_tb)) po.end = key;
 }
 
-template <bool KEND = false, class MLen0, class MLen1>
+template <int KEND = 0, class MLen0, class MLen1>
 __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0 m0, const MLen1 m1, const int n,
                                                const KnownPass kn0, const KnownPass kn1, Verdict &v, PassOut &p1,
                                                PassOut &p2) {
@@ -1269,8 +1271,8 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
     p2 = PassOut{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
     p1 = kn0.dt ? run_pass_known_dense(cfg, m0, kn0.dt, kn0.cbits, kn0.cwords)
          : kn0.ent ? run_pass_known_ent(cfg, m0, kn0.ent, kn0.count)
-                   : run_pass_known<KEND>(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
-    known_positions<KEND>(p1, cfg.pass[0].trim_side);
+                   : run_pass_known<(KEND != 0)>(cfg, m0, kn0.e0, kn0.e1, kn0.e2, kn0.e3, kn0.count);  // :875
+    known_positions<KEND>(p1, cfg.pass[0].trim_side, cfg.need_traceback != 0);
     if (p1.status != 1) {  // :879-883
         v.bc1 = p1.status;
         return;
@@ -1278,8 +1280,8 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
     if (cfg.is_dual) {  // :887-895
         p2 = kn1.dt ? run_pass_known_dense(cfg, m1, kn1.dt, kn1.cbits, kn1.cwords)
              : kn1.ent ? run_pass_known_ent(cfg, m1, kn1.ent, kn1.count)
-                       : run_pass_known<KEND>(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
-        known_positions<KEND>(p2, cfg.pass[1].trim_side);
+                       : run_pass_known<(KEND != 0)>(cfg, m1, kn1.e0, kn1.e1, kn1.e2, kn1.e3, kn1.count);
+        known_positions<KEND>(p2, cfg.pass[1].trim_side, cfg.need_traceback != 0);
         if (p2.status != 1) {
             v.bc1 = p2.status;
             return;
@@ -1311,6 +1313,22 @@ __device__ __forceinline__ void classify_known(const BdxDevCfg &cfg, const MLen0
         v.keep_start = keep_start;
         v.keep_end = keep_end;
     }
+}
+
+// match_barcode_pass's statistics block (classification.jl:827-865): runs iff the pass returned :match
+__device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p, const int B, const PassOut &po) {
+    if (po.status != 1) return;
+    const long long b = po.bc - 1;
+    const long long prow = (long long)po.start - 1 + st.pos_bias;
+    const long long lrow = (long long)po.end - po.start + 1;
+    const long long rrow = po.raw;
+    if (prow < 0 || prow >= st.rows || lrow < 0 || lrow >= st.len_rows || rrow < 0 || rrow >= st.raw_rows) {
+        atomicOr(st.overflow, 1u);
+        return;
+    }
+    atomicAdd(&st.pos[p][prow * B + b], 1ULL);
+    atomicAdd(&st.len[p][b * st.len_stride + lrow], 1ULL);
+    atomicAdd(&st.raw[p][b * st.raw_stride + rrow], 1ULL);
 }
 
 }  // namespace

@@ -74,7 +74,8 @@ struct BdxFilterSet {
     DevBuf bp_tables, seed_tables, seed_tables_alt;
     BdxWavePlan wplan{};   // wave-autonomous kernel (bdx_wave.hip) for this set, when the config qualifies
     DevBuf wave_tables;
-    BdxWavePlan wplan_k{};  // known-end class (ScoreOnly conditions + trim_side = 5): the same tables, the non-split kernel with end columns
+    BdxWavePlan wplan_k{};  // known-trim class (ScoreOnly conditions + trim sides): the same tables, the non-split kernel with position keys
+    BdxWavePlan wplan_a{};  // known-alignment class (... + summary statistics / per-pass positions wanted): kend = 3
     BdxWavePlan pplan{};   // the same kernel in pairs mode (bdx_pairs.hip) at this set's full budgets, over listed reads
     DevBuf pair_tables;
     BdxWavePlan pplan_k{};  // ... in its known-end form (trim_side = 5 configs)

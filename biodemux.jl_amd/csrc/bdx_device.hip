@@ -71,22 +71,6 @@ __device__ __forceinline__ bool tier_pass_settled(const BdxDevCfg &cfg, const Pa
     return !want_delta && po.status == 1 && (slo - po.score) >= cfg.min_delta;
 }
 
-// match_barcode_pass's statistics block (classification.jl:827-865): runs iff the pass returned :match
-__device__ __forceinline__ void stats_update(const BdxDevStats &st, const int p, const int B, const PassOut &po) {
-    if (po.status != 1) return;
-    const long long b = po.bc - 1;
-    const long long prow = (long long)po.start - 1 + st.pos_bias;
-    const long long lrow = (long long)po.end - po.start + 1;
-    const long long rrow = po.raw;
-    if (prow < 0 || prow >= st.rows || lrow < 0 || lrow >= st.len_rows || rrow < 0 || rrow >= st.raw_rows) {
-        atomicOr(st.overflow, 1u);
-        return;
-    }
-    atomicAdd(&st.pos[p][prow * B + b], 1ULL);
-    atomicAdd(&st.len[p][b * st.len_stride + lrow], 1ULL);
-    atomicAdd(&st.raw[p][b * st.raw_stride + rrow], 1ULL);
-}
-
 // LDS carve-up (all 16-byte aligned):
 //   [DP: dp_rows*BS int][OG: dp_rows*BS int if any_traceback][off0|off1: uint32][nn0|nn1: int]
 //   [barcode bytes pass0|pass1][hist: int[hist_entries]][read bytes: stage_bytes]

@@ -196,7 +196,8 @@ struct BdxWavePlan {
     int scan_gpr;          // ranged single-pass configs (per batch): groups of sixteen positions scanned per read, 0: the whole flat image
     int ranged;            // some pass has a ref_search_range other than the whole read: per-read column windows in the kernel
     int winm;              // per batch: window mode (bdx_wave_win.hip): scattered tiles that hold only each read's ref_search_range window (`slot` positions per read)
-    int kend;              // known-trim class (any trim side per pass, no per-pass start positions wanted): the non-split kernel with position keys (bdx_wave_end.hip)
+    int kend;              // known-trim class (any trim side per pass): the non-split kernel with position keys — 1: trim sides 5 / none (bdx_wave_end.hip), 2: with reversed
+                           // sweeps for trim_side = 3 (bdx_wave_rev.hip), 3: the known-ALIGNMENT class — both positions of every winner by anchored sweeps, statistics (bdx_wave_aln.hip)
     double chance;         // expected chance seed hits per 150-base read (config)
     // pairs mode (two-intact-pieces filter over a gathered list of reads; bdx_pairs.hip): d_bitmap holds the piece
     // tables [kb + 2][256] of barcode masks, there is no hash
@@ -246,7 +247,8 @@ size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_
 // Implemented in bdx_wave_end.hip (the known-end instantiations of the same kernel).
 hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
-                               unsigned int *list_count, hipStream_t stream, int dbg = 0, double tier_slo1 = 0.0);
+                               unsigned int *list_count, hipStream_t stream, int dbg = 0, double tier_slo1 = 0.0,
+                               const BdxDevStats *stats = nullptr);  // (stats / pass_start: the known-alignment class only, kend = 3)
 // Implemented in bdx_wave_win.hip (the window-mode instantiations: single-pass known-score configs whose column window is much
 // shorter than their reads — only the windows are fetched).
 hipError_t bdx_launch_wave_win(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,

@@ -57,6 +57,8 @@ struct WaveArgs {
     const uint32_t *peq8;    // [B][9]: sweep word of barcode b for symbol code c (4..7: "other"; the ninth word pads the stride)
     const uint32_t *peq8r;   // [B][9]: the same for the REVERSED barcode (known-trim class: the sweeps of trim_side = 3 passes run right to left)
     int trim0, trim1;        // known-trim class: the passes' trim sides (0 / 3 / 5)
+    int need_tb;             // known-alignment class: the config collects statistics (summary = true): passes without a trim side report positions too (:812)
+    BdxDevStats stats;       // known-alignment class: the DemuxStats histograms (rows == 0: none), updated for every pass that returns :match
     const uint32_t *meta;    // [B]: m | kb << 8 | (largest distance the reducer accepts for a lone survivor, 255: none) << 16
     const uint32_t *settle;  // [B]: tier 1, lone survivor: bit d = a read whose only survivor has distance d is settled (no_delta: low half, with_delta: high half)
     int B;
@@ -235,12 +237,64 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
                 const uint32_t ep = sweep_step<true>(Eq[h & 1][jj], Pv, Mv, score, best);
                 if (TRACKW == 1) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - kk1), 31);  // (inm << 1) | (score <= budget)
                 if (TRACKW >= 2) inm = __builtin_amdgcn_alignbit(inm, (uint32_t)(score - best_before), 31);  // (inm << 1) | (score < minimum so far)
-                if (TRACKW == 3) inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
+                if (TRACKW >= 3) inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
             }
         }
     }
     if (TRACKW && ngr < 4) inm <<= 32 - 8 * ngr;  // (bit 31 - j stands for column j also when the block stopped early)
-    if (TRACKW == 3 && ngr < 4) inm2 <<= 32 - 8 * ngr;
+    if (TRACKW >= 3 && ngr < 4) inm2 <<= 32 - 8 * ngr;
+}
+
+// 32 columns of an ANCHORED sweep (known-alignment class, KEND = 3): one end of the alignment is fixed, the sweep looks for the
+// first column whose score EQUALS the known distance d: bit 31 - j of `eqm` for column j; `inm2` as in sweep_block.
+// REVA: the sweep runs right to left from the alignment's end column with the reversed barcode and its row 0 is NOT free — the
+// barcode's words are stripped of the "virtual rows below the barcode match everything" bits (rows) and the horizontal delta of
+// row 0 is +1 (lowbit is shifted in): the score of a column is the cost of aligning the whole barcode with exactly the positions
+// from there to the anchor.  !REVA: an ordinary left-to-right sweep from a prepared first column.
+template <bool REVA>
+__device__ __forceinline__ void anchored_block(const uint32_t A0, const uint32_t A1, const uint32_t A2, const uint32_t A3, const uint32_t pbase,
+                                               const uint32_t rows, const uint32_t lowbit, uint32_t &Pv, uint32_t &Mv, int &score, const int d,
+                                               uint32_t &eqm, uint32_t &inm2, const int ngr) {
+    const uint32_t A[4] = {A0, A1, A2, A3};
+    uint32_t Eq[2][8];
+    const auto issue = [&](const int h) __attribute__((always_inline)) {
+        uint32_t addr[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) addr[jj] = pbase + (__builtin_amdgcn_ubfe(A[h], 4 * jj, 3) << 2);
+        lds_read8(Eq[h & 1], addr);
+    };
+    issue(0);
+    eqm = 0u;
+    inm2 = 0u;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (h >= ngr) break;
+        lds_wait8(Eq[h & 1]);
+        if (h < 3 && h + 1 < ngr) issue(h + 1);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const uint32_t E = REVA ? (Eq[h & 1][jj] & rows) : Eq[h & 1][jj];
+            const uint32_t Xv = E | Mv;
+            const uint32_t ep = E & Pv;
+            const uint32_t Xh = ((ep + Pv) ^ Pv) | E;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            uint32_t cp, cm;
+            Ph = __builtin_addc(Ph, Ph, 0u, &cp);
+            Mh = __builtin_addc(Mh, Mh, 0u, &cm);
+            score += (int)cp;
+            score -= (int)cm;
+            if (REVA) Ph |= lowbit;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+            eqm = __builtin_amdgcn_alignbit(eqm, score == d ? 0x80000000u : 0u, 31);
+            inm2 = __builtin_amdgcn_alignbit(inm2, ep, 31);
+        }
+    }
+    if (ngr < 4) {
+        eqm <<= 32 - 8 * ngr;
+        inm2 <<= 32 - 8 * ngr;
+    }
 }
 
 // NV: 16-byte vectors of a tile's span per lane (the next tile's bytes wait in 4 NV registers while this tile is worked
@@ -263,7 +317,8 @@ __device__ __forceinline__ void sweep_block(const uint32_t A0, const uint32_t A1
 template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true, bool WINM = false>
 __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
-    constexpr bool KREV = KEND == 2;  // known-trim class with a trim_side = 3 pass: reversed sweeps (1: trim sides 5 / none only — the sweeps of round 3's known-end class)
+    constexpr bool KREV = KEND >= 2;  // known-trim class with a trim_side = 3 pass: reversed sweeps (1: trim sides 5 / none only — the sweeps of round 3's known-end class)
+    constexpr bool KALN = KEND == 3;  // known-alignment class: start AND end of every pass's winner (anchored sweeps), for per-pass outputs and the statistics tables
     constexpr int RCAP = 8;       // sweep records (seeded barcode x diagonal cluster) per read
     // seed hits per tile (pairs mode: flagged (barcode, run of diagonals)s = sweeps) / sweeps (= records) per tile: sized per
     // config from the expected chance hits (size_wave) — the two queues sit behind the images, at run-time offsets
@@ -745,7 +800,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     // smallest distance first, and of equal ones — trim_side = 5: key = 1-based end column, the leftmost end first;
                     // trim_side = 3: key = 0xFFFF - start, the largest start first (no trim side: 0)
                     uint32_t pkey = 0u;
-                    if (KEND && trim_b == 5) pkey = (uint32_t)(lo + e_hi + 1);
+                    if (KEND && (trim_b == 5 || (KALN && trim_b == 0 && a.need_tb))) pkey = (uint32_t)(lo + e_hi + 1);  // (known-alignment class: a pass without a trim side records like trim_side = 5, :142-153)
                     if (KREV && rev) {
                         const int pstar = hi - 1 - e_hi;  // 0-based read position = node the last lowering column stands for
                         const int origin = (sflag == 0u && pstar <= win_lo(t, second)) ? 0 : pstar + (int)sflag;
@@ -1298,7 +1353,7 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
             // 1:n, so n >= 1 is all that is left to check (n = 0: the :805 sanity check sends the read to :unknown)
             const bool simple = a.out.pass_start == nullptr && a.out.pass_end == nullptr && a.out.pass_raw == nullptr && a.out.pass_bc == nullptr &&
                                 a.out.pass_score == nullptr && a.out.pass_delta == nullptr;  // (kernel-uniform: only the verdict vectors are wanted)
-            if (simple && !flag[lane] && cnt <= 1 && cnt1 <= 1 && n >= 1) {
+            if (simple && !KALN && !flag[lane] && cnt <= 1 && cnt1 <= 1 && n >= 1) {
                 // No or one survivor per pass and nobody asked for scores: the reducers' answer for a lone survivor with distance d
                 // is a per-barcode constant — accepted iff d <= floor(rate * m) and fl(d / m) <= rate (classification.jl:254, :658 /
                 // :696; with_delta: delta = Inf - score is never below min_delta) — precomputed on the host with the same
@@ -1374,7 +1429,8 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 cfg.min_delta = a.min_delta;
                 cfg.pass[0].trim_side = KEND ? a.trim0 : 0;
                 cfg.pass[1].trim_side = KEND ? a.trim1 : 0;
-                classify_known<(KEND != 0)>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
+                cfg.need_traceback = KALN ? a.need_tb : 0;
+                classify_known<(KALN ? 2 : (KEND != 0 ? 1 : 0))>(cfg, m0, m1, n, kn0, kn1, vd, p1, p2);
                 done = true;
                 if (a.tier) {
                     // tier settle rule (same code as bdx_bitpar.hip)
@@ -1389,6 +1445,133 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     if (ok && dual && p1.status == 1) ok = settled(p2, cnt1, a.tier_slo1);
                     done = ok;
                 }
+            }
+        }
+        if constexpr (KALN) {
+            // ---- known-alignment class: the OTHER position of every pass's winner, by an anchored sweep (lane = read) ----
+            // The replay knows, per pass, the winner b, its distance d and the position its trim side makes observable: the END of
+            // the first column at the minimum (trim_side 5 / none; :142-153) or the START = the largest origin (trim_side 3, §3.0c).
+            //  * end known -> start: the reference's start is origin(m, end) = the largest origin among the alignments of cost d that
+            //    end exactly there (same exchange argument as §3.0c) — a right-to-left sweep from the end column whose row 0 is NOT
+            //    free (anchored_block<true>): its score after the column of position p is the cost of aligning the barcode with
+            //    exactly p .. end; the first column (largest p) whose score is d, + 1 iff the diagonal move is optimal there.
+            //  * start known -> end: the reference's end is the first column with an alignment of cost d whose origin is that start
+            //    (:142-153 with trim_side = 3: of equal starts the first column stays) — a left-to-right sweep from the start's
+            //    column, whose first column is prepared as "row 1 entered here" (D[i] = delta(q1, r[start]) + i - 1).
+            // Models + enumeration: oracle orc_known_other_position / orc_selftest_known_alignment.
+            // A start <= 0 (the alignment comes out of the initial column, :278-283) is not representable here: such a read is handed on.
+            const bool want_pos = a.out.pass_start != nullptr || a.out.pass_end != nullptr || a.stats.rows > 0;
+            const int tl = lane < RW ? lane : 0;
+            const int n_t = rlen(tl);
+            bool lost = false;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                if (ps == 1 && !dual) break;
+                PassOut &po = ps ? p2 : p1;
+                const int tr = ps ? a.trim1 : a.trim0;
+                const bool rev = tr != 3;  // (the end is known: sweep back for the start)
+                const bool tb = tr != 0 || a.need_tb != 0;  // (a ScoreOnly pass reports no positions, :812 / :124)
+                bool valid = want_pos && tb && done && lane < nr && po.bc > 0 && po.status != 2;
+                const int b = valid ? (ps ? a.B0 : 0) + po.bc - 1 : 0;
+                const int pos = rev ? po.end : po.start;
+                if (valid && pos <= 0) {  // (trim_side 3: a start <= 0)
+                    lost = true;
+                    valid = false;
+                }
+                const uint32_t mt = meta[b];
+                const int mm = (int)(mt & 255u), kk = (int)((mt >> 8) & 255u), d = valid ? po.raw : 0;
+                const uint32_t rows = mm >= 32 ? 0xFFFFFFFFu : (((1u << mm) - 1u) << (32 - mm)), lowbit = 1u << (32 - mm);
+                const int wlo = win_lo(tl, ps != 0), whi = win_hi(tl, ps != 0, n_t);
+                // positions [lo, hi) of the read: rev: hi = end column (exclusive as a 0-based position), walked downwards; else upwards from the start
+                int lo = rev ? pos - mm - kk : pos, hi = rev ? pos : pos + mm + kk;
+                lo = lo < wlo ? wlo : lo;
+                hi = hi > whi ? whi : hi;
+                valid = valid && hi > lo;
+                const int ncol = valid ? hi - lo : 0;
+                uint32_t Pv = rows, Mv = 0u;
+                int score = mm;
+                const uint32_t pbase = (rev ? peqr_base : peq_base) + (uint32_t)b * 36u;
+                if (!rev) {  // the prepared first column: row 1 is entered at column `pos` (read position pos - 1)
+                    const int fx = fb[tl] + pos - 1;
+                    const uint32_t cw = valid ? img4[fx >> 3] : 0u;
+                    const uint32_t code = (cw >> ((fx & 7) * 4)) & 7u;
+                    const uint32_t e1 = valid ? peq[b * 9 + (int)code] : 0u;
+                    const bool match1 = (e1 & lowbit) != 0u;
+                    if (match1) Pv &= ~lowbit;
+                    score = mm - (match1 ? 1 : 0);
+                }
+                int found = -1;
+                uint32_t sfl = 0u;
+                const int sb0 = fb[tl] + lo, se0 = fb[tl] + hi - 32;
+                for (int blk = 0;; ++blk) {
+                    const int rem = ncol - 32 * blk;
+                    if (!__builtin_amdgcn_ballot_w64(valid && found < 0 && rem > 0)) break;
+                    const int sb = rev ? se0 - 32 * blk : sb0 + 32 * blk;
+                    const int d0 = sb >> 3, shb = (sb & 7) * 4;
+                    uint32_t W[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) W[u] = (valid && rem > 0) ? img4[d0 + u] : 0u;
+                    uint32_t A[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) A[u] = __builtin_amdgcn_alignbit(W[u + 1], W[u], shb);
+                    {
+                        uint32_t R[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t y = __builtin_amdgcn_perm(0u, A[3 - u], 0x00010203u);
+                            R[u] = ((y & 0x0F0F0F0Fu) << 4) | ((y >> 4) & 0x0F0F0F0Fu);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) A[u] = rev ? R[u] : A[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int nv = rem - 8 * u;
+                        A[u] |= nv >= 8 ? 0u : (nv <= 0 ? 0x44444444u : (0x44444444u << (4 * nv)));
+                    }
+                    const int ngr = __builtin_amdgcn_ballot_w64(rem > 24) ? 4 : (__builtin_amdgcn_ballot_w64(rem > 16) ? 3 : (__builtin_amdgcn_ballot_w64(rem > 8) ? 2 : 1));
+                    uint32_t eqm = 0u, inm2 = 0u;
+                    // (a wave runs both forms when its lanes differ: a dual config with trim sides 5 and 3 has one form per pass)
+                    const bool any_rev = __builtin_amdgcn_ballot_w64(valid && rev) != 0ull, any_fwd = __builtin_amdgcn_ballot_w64(valid && !rev) != 0ull;
+                    uint32_t Pv2 = Pv, Mv2 = Mv;
+                    int score2 = score;
+                    uint32_t eqm2 = 0u, inm22 = 0u;
+                    if (any_rev) anchored_block<true>(A[0], A[1], A[2], A[3], pbase, rows, lowbit, Pv, Mv, score, d, eqm, inm2, ngr);
+                    if (any_fwd) anchored_block<false>(A[0], A[1], A[2], A[3], pbase, rows, lowbit, Pv2, Mv2, score2, d, eqm2, inm22, ngr);
+                    if (!rev) {
+                        Pv = Pv2;
+                        Mv = Mv2;
+                        score = score2;
+                        eqm = eqm2;
+                        inm2 = inm22;
+                    }
+                    eqm &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ~((1u << (32 - rem)) - 1u));
+                    if (valid && found < 0 && eqm) {
+                        const int cz = (int)__builtin_clz(eqm);
+                        found = 32 * blk + cz;
+                        sfl = (inm2 >> (31 - cz)) & 1u;
+                    }
+                }
+                if (valid) {
+                    if (found < 0) {
+                        lost = true;  // (cannot happen: the distance d was attained by a sweep of this very window)
+                    } else if (rev) {
+                        const int pstar = hi - 1 - found;
+                        if (sfl == 0u && pstar <= wlo)
+                            lost = true;  // a start <= 0 (out of the reference's initial column)
+                        else
+                            po.start = pstar + (int)sfl;
+                    } else {
+                        po.end = lo + found + 1;
+                    }
+                } else if (want_pos && tb && done && lane < nr && po.bc > 0 && po.status != 2 && !lost) {
+                    lost = true;  // (an empty anchored window: hand the read on rather than guess)
+                }
+            }
+            if (lost) done = false;
+            if (done && a.stats.rows > 0) {
+                stats_update(a.stats, 0, a.B0, p1);
+                if (dual) stats_update(a.stats, 1, B - a.B0, p2);
             }
         }
         {
@@ -1497,6 +1680,8 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.peq8r = wp.d_peq8r;
     a.trim0 = cfg.pass[0].trim_side;
     a.trim1 = cfg.is_dual ? cfg.pass[1].trim_side : 0;
+    a.stats = BdxDevStats{};
+    a.need_tb = cfg.need_traceback;
     a.meta = wp.d_meta;
     a.settle = wp.d_settle;
     a.B = wp.n_barcodes;
@@ -1545,6 +1730,8 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 // (bdx_wave_rev.hip: the known-trim instantiations with reversed sweeps, KEND = 2)
 hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+// (bdx_wave_aln.hip: the known-alignment instantiations, KEND = 3)
+hipError_t bdx_launch_wave_end_aln(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 
 #if defined(BDX_WAVE_TU_WIN)  // the window-mode instantiations (bdx_wave_win.hip)
 
@@ -1601,12 +1788,39 @@ hipError_t bdx_launch_wave_win(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
 #undef BDX_WAVE_SP
 }
 
+#elif defined(BDX_WAVE_TU_ALN)  // the known-alignment instantiations (bdx_wave_aln.hip)
+
+hipError_t bdx_launch_wave_end_aln(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    const int tf = wp.track_from;
+    if (wp.kend != 3) return BDX_BAD_PLAN();
+#define BDX_WAVE_SP(RWV, TFV, NVV, QV) launch_wave<RWV, TFV, NVV, QV, false, 0, 0, false, 3>(a, lds, wp.waves, blocks, stream)
+#define BDX_WAVE_NV(RWV, TFV, QV) (wp.span_cap <= 5 * 1024 ? BDX_WAVE_SP(RWV, TFV, 5, QV) : BDX_WAVE_SP(RWV, TFV, 10, QV))
+#define BDX_WAVE_TF(RWV)                                                                             \
+    return wp.q == 8 ? (tf >= 20 ? BDX_WAVE_NV(RWV, 20, 8) : tf >= 12 ? BDX_WAVE_NV(RWV, 12, 8) : BDX_WAVE_NV(RWV, 0, 8)) \
+           : wp.q == 7 ? (tf >= 12 ? BDX_WAVE_NV(RWV, 12, 7) : BDX_WAVE_NV(RWV, 0, 7))                      \
+                       : BDX_WAVE_NV(RWV, 0, 6)
+    switch (wp.rw) {
+        case 32:
+            BDX_WAVE_TF(32);
+        case 16:
+            BDX_WAVE_TF(16);
+        case 8:
+            BDX_WAVE_TF(8);
+        default:
+            return BDX_BAD_PLAN();
+    }
+#undef BDX_WAVE_TF
+#undef BDX_WAVE_NV
+#undef BDX_WAVE_SP
+}
+
 #elif !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND) && !defined(BDX_WAVE_TU_KREV)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
     return al((size_t)wp.bm_bytes) + al(wp.pairs_kb > 0 ? 0 : (size_t)wp.bm_bytes / 2) + al((size_t)wp.n_ent * 4) + al((size_t)wp.n_barcodes * 36) +
-           al(wp.kend == 2 ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
+           al(wp.kend >= 2 ? (size_t)wp.n_barcodes * 36 : 0) + 2 * al((size_t)wp.n_barcodes * 4) + al((size_t)hist_entries * 4);
 }
 
 size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_cap, int cand_words, bool winm) {
@@ -1759,12 +1973,14 @@ hipError_t bdx_launch_wave_split_gen(const void *wave_args, const BdxWavePlan &w
 // launch as bdx_launch_wave for a known-score config, the verdicts carry the trimmed keep range.
 hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                                long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int tier1, double tier_slo, uint32_t *list,
-                               unsigned int *list_count, hipStream_t stream, int dbg, double tier_slo1) {
+                               unsigned int *list_count, hipStream_t stream, int dbg, double tier_slo1, const BdxDevStats *stats) {
     if (n_reads <= 0) return hipSuccess;
-    if (wp.pairs_kb > 0 || wp.split || !wp.kend || out.pass_start != nullptr || !wp.d_peq8r) return BDX_BAD_PLAN();
+    if (wp.pairs_kb > 0 || wp.split || !wp.kend || !wp.d_peq8r) return BDX_BAD_PLAN();
+    if (wp.kend != 3 && (out.pass_start != nullptr || stats != nullptr)) return BDX_BAD_PLAN();  // (only the known-alignment class knows both positions)
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, nullptr);
-    if (out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();  // (a trim_side = 3 pass knows its start only)
+    if (wp.kend != 3 && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();  // (a trim_side = 3 pass knows its start only)
+    if (stats) a.stats = *stats;
     a.seq = d_seq;
     a.off = d_off;
     a.n_reads = n_reads;
@@ -1779,6 +1995,7 @@ hipError_t bdx_launch_wave_end(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
     const long long useful = (tiles + wp.waves - 1) / wp.waves;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
+    if (wp.kend == 3) return bdx_launch_wave_end_aln(&a, wp, lds, blocks, stream);  // (bdx_wave_aln.hip)
     if ((wp.kend == 2) != (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();
     if (wp.kend == 2) return bdx_launch_wave_end_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)
     const int tf = wp.track_from;

@@ -1026,8 +1026,8 @@ def test_stress_shapes(name):
         assert "bitpar" in path
     if name == "B1500_rate0.2_tiered":
         assert path.startswith(TIER)
-    if name == "min_delta_beyond_an_unseen_barcode":  # tier 1 could prove nothing: it is not built
-        assert not path.startswith(TIER) and "bitpar" in path
+    if name == "min_delta_beyond_an_unseen_barcode":  # the seed tier could prove nothing: the pairs tier (cost <= 4, slo = 5 / 24 >= min_delta) runs instead
+        assert path.startswith("tier1:pairs(diag)"), path
 
 
 def test_concurrent_contexts_on_os_threads():
