@@ -1150,6 +1150,14 @@ int build_pair_tables(bdx_ctx *ctx) {
         for (int k = 0; k < npass; ++k)
             if (c.pass[k].trim_side == 3) F.pplan_k.kend = 2;
     }
+    F.pplan_a = BdxWavePlan{};  // known-alignment class (build_wave_tables): the same with `summary` allowed
+    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !ctx->tune.no_known &&
+        !ctx->tune.no_kend && !getenv("BDX_NO_KALN") && groups == 1 && wp.pairs_kb <= 4) {
+        F.pplan_a = wp;
+        F.pplan_a.split = 0;
+        F.pplan_a.cand_words = c.is_dual ? 4 : 0;
+        F.pplan_a.kend = 3;
+    }
     return BDX_OK;
 }
 
@@ -1539,7 +1547,16 @@ int init_stats(bdx_ctx *ctx) {
     // leading deletions count through the origin: end - start + 1 <= 2 m — a fixed height.  Otherwise (start / end
     // ranges that bind: the band's seeded cells carry origins of their own) only start >= 1 - m and end <= n hold:
     // the table grows with the reads like the position table.
-    ctx->st_len_fixed = ctx->plan.clean || c.algorithm != BDX_ALG_SEMIGLOBAL;
+    // (:semiglobal with a ref_search_range that starts inside the read: an alignment out of the reference's initial column keeps the
+    // origin 1 - i whatever the window's first column is, classification.jl:278-283 — its length end - start + 1 reaches n + m:
+    // found by round 4's known-alignment tests, "a statistics key fell outside its table" on ref_search_range = "end-90:end")
+    bool sg_window = false;
+    if (c.algorithm == BDX_ALG_SEMIGLOBAL)
+        for (int p = 0; p < npass; ++p) {
+            const bdx_range_t &r = c.pass[p].ref_search_range;
+            sg_window = sg_window || r.start_from_end || r.start_offset > 1 || c.pass[p].explicit_window != 0;
+        }
+    ctx->st_len_fixed = (ctx->plan.clean || c.algorithm != BDX_ALG_SEMIGLOBAL) && !sg_window;
     ctx->st_len_rows = ctx->st_len_fixed ? 2 * ctx->dev.max_m + 2 : 0;
     for (int p = 0; p < npass; ++p)
         for (int w = (ctx->st_len_fixed ? 1 : 2); w < 3; ++w) {
@@ -2469,16 +2486,16 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the
         // listed reads for the exact kernel).
         bool pairs = false, pairs_k = false;
-        if (tiered && kend_ok && size_pairs(ctx, ctx->fs[0].pplan_k, tier_len)) {
+        if (tiered && (kend_ok || aln_ok) && size_pairs(ctx, aln_ok ? ctx->fs[0].pplan_a : ctx->fs[0].pplan_k, tier_len)) {
             // known-end class: the pairs mode answers the listed reads itself (verdict + trimmed keep range); what it cannot
             // answer goes on to the split path in list mode
-            const BdxWavePlan &pp = ctx->fs[0].pplan_k;
+            const BdxWavePlan &pp = aln_ok ? ctx->fs[0].pplan_a : ctx->fs[0].pplan_k;
             HIP_TRY(ctx, ctx->d_wlist.ensure((size_t)n_reads * 4 + 64));
             if (ctx->tune.poison) HIP_TRY(ctx, hipMemsetAsync(ctx->d_wlist.p, 0xA5, ctx->d_wlist.cap, ctx->stream));
             uint32_t *list2 = (uint32_t *)ctx->d_wlist.p;
             unsigned int *count2 = (unsigned int *)(scratch + 320);
             HIP_TRY(ctx, bdx_launch_pairs(ctx->dev, pp, ctx->plan.hist_entries, d_seq_bytes, (const long long *)d_seq_off, n_reads, t0.in_list,
-                                          t0.in_count, o, ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, nullptr));
+                                          t0.in_count, o, ctx->counts, list2, count2, ctx->stream, ctx->tune.debug >> 8, nullptr, aln_ok ? stp : nullptr));
             ctx->pair_launches += 1;
             pairs = pairs_k = true;
             t0.in_list = list2;
@@ -2554,7 +2571,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         ctx->last_blocks = (n_reads + ctx->F().bplan.reads_per_block - 1) / ctx->F().bplan.reads_per_block;
         ctx->path = ctx->F().splan.enabled ? (ctx->F().splan.diag ? "qgram2+bitpar+verify" : "qgram+bitpar+verify") : "bitpar+verify";
         if (wsplit0) ctx->path = "wave+verify";
-        if (pairs) ctx->path = pairs_k ? "pairs(end) > " + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
+        if (pairs) ctx->path = pairs_k ? (aln_ok ? "pairs(aln) > " : "pairs(end) > ") + ctx->path : split ? "pairs+verify" : "pairs > " + ctx->path;
         if (pairs_all) ctx->path = "pairs(diag)+verify";
         if (tiered) ctx->path = (pairs_t1 ? "tier1:pairs(diag) > " : (wave1k && aln_ok) ? "tier1:wave(aln) > " : wave1k ? "tier1:wave(end) > " : (wave1 && ctx->fs[1].wplan.winm) ? "tier1:wave(win) > " : (wave1 || wsplit1) ? "tier1:wave > " : "tier1:qgram+bitpar > ") + ctx->path;
         if (wave0) ctx->path = (ctx->fs[0].wplan.winm ? "wave(win) > " : "wave > ") + ctx->path;

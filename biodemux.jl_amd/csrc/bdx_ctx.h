@@ -79,6 +79,7 @@ struct BdxFilterSet {
     BdxWavePlan pplan{};   // the same kernel in pairs mode (bdx_pairs.hip) at this set's full budgets, over listed reads
     DevBuf pair_tables;
     BdxWavePlan pplan_k{};  // ... in its known-end form (trim_side = 5 configs)
+    BdxWavePlan pplan_a{};  // ... in its known-alignment form (kend = 3)
 };
 
 struct bdx_ctx {

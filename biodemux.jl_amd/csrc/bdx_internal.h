@@ -259,7 +259,7 @@ hipError_t bdx_launch_wave_win(const BdxDevCfg &cfg, const BdxWavePlan &wp, int 
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                             long long n_reads, const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out,
                             unsigned long long *d_counts, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0,
-                            const BdxWaveSplit *sp = nullptr);
+                            const BdxWaveSplit *sp = nullptr, const BdxDevStats *stats = nullptr);
 hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                            long long n_reads, const BdxDevOut &out, unsigned long long *d_counts, int *d_tile_counter, int tier1,
                            double tier_slo, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg = 0, const BdxWaveSplit *sp = nullptr,

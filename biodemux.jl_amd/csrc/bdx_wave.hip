@@ -1486,8 +1486,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                 int lo = rev ? pos - mm - kk : pos, hi = rev ? pos : pos + mm + kk;
                 lo = lo < wlo ? wlo : lo;
                 hi = hi > whi ? whi : hi;
-                valid = valid && hi > lo;
-                const int ncol = valid ? hi - lo : 0;
+                const bool has_cols = hi > lo;
+                valid = valid && (has_cols || !rev);  // (a known start at the window's last column: the prepared column may already be the end)
+                const int ncol = (valid && has_cols) ? hi - lo : 0;
                 uint32_t Pv = rows, Mv = 0u;
                 int score = mm;
                 const uint32_t pbase = (rev ? peqr_base : peq_base) + (uint32_t)b * 36u;
@@ -1500,12 +1501,13 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                     if (match1) Pv &= ~lowbit;
                     score = mm - (match1 ? 1 : 0);
                 }
+                const bool ends_at_once = valid && !rev && score == d;  // (the alignment ends in its first column: every later row deleted)
                 int found = -1;
                 uint32_t sfl = 0u;
                 const int sb0 = fb[tl] + lo, se0 = fb[tl] + hi - 32;
                 for (int blk = 0;; ++blk) {
                     const int rem = ncol - 32 * blk;
-                    if (!__builtin_amdgcn_ballot_w64(valid && found < 0 && rem > 0)) break;
+                    if (!__builtin_amdgcn_ballot_w64(valid && !ends_at_once && found < 0 && rem > 0)) break;
                     const int sb = rev ? se0 - 32 * blk : sb0 + 32 * blk;
                     const int d0 = sb >> 3, shb = (sb & 7) * 4;
                     uint32_t W[5];
@@ -1552,7 +1554,9 @@ __global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
                         sfl = (inm2 >> (31 - cz)) & 1u;
                     }
                 }
-                if (valid) {
+                if (ends_at_once) {
+                    po.end = pos;
+                } else if (valid) {
                     if (found < 0) {
                         lost = true;  // (cannot happen: the distance d was attained by a sweep of this very window)
                     } else if (rev) {
@@ -1732,6 +1736,7 @@ hipError_t bdx_launch_wave_end_rev(const void *wave_args, const BdxWavePlan &wp,
 hipError_t bdx_launch_pairs_rev(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 // (bdx_wave_aln.hip: the known-alignment instantiations, KEND = 3)
 hipError_t bdx_launch_wave_end_aln(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
+hipError_t bdx_launch_pairs_aln(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream);
 
 #if defined(BDX_WAVE_TU_WIN)  // the window-mode instantiations (bdx_wave_win.hip)
 
@@ -1815,6 +1820,20 @@ hipError_t bdx_launch_wave_end_aln(const void *wave_args, const BdxWavePlan &wp,
 #undef BDX_WAVE_SP
 }
 
+hipError_t bdx_launch_pairs_aln(const void *wave_args, const BdxWavePlan &wp, size_t lds, long long blocks, hipStream_t stream) {
+    const WaveArgs &a = *(const WaveArgs *)wave_args;
+    if (wp.pairs_kb > 4 || wp.nw > 4 || wp.track_from < 12 || wp.groups > 1 || wp.split || wp.kend != 3) return BDX_BAD_PLAN();
+#define BDX_PAIRS_SP(RWV, NVV, KBV, NWV) launch_wave<RWV, 12, NVV, 4, false, KBV, NWV, false, 3>(a, lds, wp.waves, blocks, stream)
+#define BDX_PAIRS_NW(RWV, NVV, KBV) (wp.nw <= 2 ? BDX_PAIRS_SP(RWV, NVV, KBV, 2) : wp.nw == 3 ? BDX_PAIRS_SP(RWV, NVV, KBV, 3) : BDX_PAIRS_SP(RWV, NVV, KBV, 4))
+#define BDX_PAIRS_KB(RWV, NVV) (wp.pairs_kb <= 3 ? BDX_PAIRS_NW(RWV, NVV, 3) : BDX_PAIRS_NW(RWV, NVV, 4))
+    if (wp.rw == 16 && wp.span_cap <= 3 * 1024 + 16) return BDX_PAIRS_KB(16, 3);
+    if (wp.rw == 16 && wp.span_cap <= 6 * 1024 + 16) return BDX_PAIRS_KB(16, 6);
+    return BDX_BAD_PLAN();
+#undef BDX_PAIRS_KB
+#undef BDX_PAIRS_NW
+#undef BDX_PAIRS_SP
+}
+
 #elif !defined(BDX_WAVE_TU_PAIRS) && !defined(BDX_WAVE_TU_KEND) && !defined(BDX_WAVE_TU_KREV)
 // LDS bytes of the shared tables / of one wave's work area (must mirror the kernel's carve-up)
 size_t bdx_wave_table_bytes(const BdxWavePlan &wp, int hist_entries) {
@@ -1892,10 +1911,14 @@ hipError_t bdx_launch_wave(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist
 hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int hist_entries, const uint8_t *d_seq, const long long *d_off,
                             long long n_reads, const uint32_t *d_idmap, const unsigned int *d_count, const BdxDevOut &out,
                             unsigned long long *d_counts, uint32_t *list, unsigned int *list_count, hipStream_t stream, int dbg,
-                            const BdxWaveSplit *sp) {
+                            const BdxWaveSplit *sp, const BdxDevStats *stats) {
     if (wp.pairs_kb <= 0 || !d_seq || !d_off || n_reads <= 0 || (d_idmap && !d_count)) return BDX_BAD_PLAN();
     WaveArgs a;
     fill_args(a, cfg, wp, hist_entries, out, d_counts, list, list_count, dbg, sp);
+    if (stats) {
+        if (wp.kend != 3) return BDX_BAD_PLAN();
+        a.stats = *stats;
+    }
     a.seq = d_seq;
     a.off = d_off;
     a.n_reads = n_reads;
@@ -1928,7 +1951,12 @@ hipError_t bdx_launch_pairs(const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     // (4 (kb + 2) <= m makes m - kb - 1 >= 16: the first twelve columns of a sweep never need the score)
     if ((wp.pairs_kb > 4 && wp.pairs_kb != 8 && wp.pairs_kb != 9) || wp.nw > 4 || tf < 12 || wp.n_barcodes > 512 || (wp.groups > 1 && (wp.nw != 4 || wp.split || wp.kend))) return BDX_BAD_PLAN();
     if (wp.pairs_kb >= 8 && (!wp.split || wp.groups > 1)) return BDX_BAD_PLAN();
-    if (wp.kend && (out.pass_start != nullptr || !wp.d_peq8r)) return BDX_BAD_PLAN();
+    if (wp.kend && !wp.d_peq8r) return BDX_BAD_PLAN();
+    if (wp.kend == 3) {
+        if (wp.pairs_kb > 4 || wp.groups > 1 || wp.split) return BDX_BAD_PLAN();
+        return bdx_launch_pairs_aln(&a, wp, lds, blocks, stream);  // (bdx_wave_aln.hip)
+    }
+    if (wp.kend && out.pass_start != nullptr) return BDX_BAD_PLAN();
     if (wp.kend && out.pass_end != nullptr && (a.trim0 == 3 || a.trim1 == 3)) return BDX_BAD_PLAN();
     if ((wp.kend == 2) != (wp.kend && (a.trim0 == 3 || a.trim1 == 3))) return BDX_BAD_PLAN();
     if (wp.kend == 2) return bdx_launch_pairs_rev(&a, wp, lds, blocks, stream);  // (bdx_wave_rev.hip)

@@ -1709,3 +1709,126 @@ int64_t orc_selftest_known_start(uint64_t seed, int64_t iters, int64_t *first_ba
     }
     return bad;
 }
+
+/* ---- model of the wave kernel's known-ALIGNMENT class (csrc/bdx_wave.hip, KEND = 3: anchored sweeps), test-only ---------
+ * With one position of the winner known (orc_known_trim_positions), the OTHER one comes out of an anchored sweep:
+ *  * end e known (trim_side 5 / none): the reference's start is origin(m, e) = the largest origin among the alignments of cost d
+ *    that end exactly at column e: a right-to-left sweep from e with the reversed barcode whose row 0 is NOT free (the words lose
+ *    their "virtual rows match everything" bits, the horizontal delta of row 0 is +1): the first column whose score equals d is
+ *    the largest node p* an alignment of cost d ending at e leaves from; start = p* + 1 iff the diagonal move is optimal there
+ *    (top bit of Eq & Pv before the step), else p*; p* at the window's first column without the diagonal move: <= 0 (reported 0);
+ *  * start s known (trim_side 3): the reference's end is the first column at which an alignment of cost d with origin s ends
+ *    (classification.jl:142-153: of equal starts the first column stays): a left-to-right sweep from column s + 1 whose first
+ *    column is prepared as "row 1 entered at column s": D[i] = [q1 != r_s] + i - 1.
+ * Returns 0 when the sweep does not find the distance (the kernel hands such a read on). */
+int64_t orc_known_other_position(const uint8_t *q, int64_t m, const uint8_t *r, int64_t wlo, int64_t whi, int32_t trim_side,
+                                 int64_t d, int64_t pos, int64_t kk) {
+    if (m < 1 || m > 32) return 0;
+    const int shift = (int)(32 - m);
+    const uint32_t rows = m == 32 ? 0xFFFFFFFFu : (((1u << m) - 1u) << shift), lowbit = 1u << shift;
+    const int rev = trim_side != 3;
+    uint32_t peq[256];
+    for (int ch = 0; ch < 256; ch++) peq[ch] = rev ? 0u : ~rows;
+    for (int64_t i = 0; i < m; i++) peq[rev ? q[m - 1 - i] : q[i]] |= 1u << (shift + i);
+    int64_t lo = rev ? pos - m - kk : pos, hi = rev ? pos : pos + m + kk;
+    if (lo < wlo) lo = wlo;
+    if (hi > whi) hi = whi;
+    if (pos <= 0 || (rev && hi <= lo)) return 0;
+    uint32_t Pv = rows, Mv = 0;
+    int64_t score = m;
+    if (!rev) {
+        const int match1 = q[0] == r[pos - 1];
+        if (match1) Pv &= ~lowbit;
+        score = m - match1;
+        if (score == d) return pos;  /* (the alignment ends in its first column: every later row deleted) */
+    }
+    for (int64_t c = 0; c < hi - lo; c++) {
+        const uint32_t Eq = peq[r[rev ? hi - 1 - c : lo + c]];
+        const uint32_t Xv = Eq | Mv;
+        const uint32_t ep = Eq & Pv;
+        const uint32_t Xh = ((ep + Pv) ^ Pv) | Eq;
+        uint32_t Ph = Mv | ~(Xh | Pv);
+        uint32_t Mh = Pv & Xh;
+        score += (int64_t)(Ph >> 31);
+        score -= (int64_t)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        if (rev) Ph |= lowbit;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        if (score == d) {
+            if (!rev) return lo + c + 1;
+            const int64_t pstar = hi - 1 - c;
+            const int sfl = (int)(ep >> 31);
+            return (!sfl && pstar <= wlo) ? 0 : pstar + sfl;
+        }
+    }
+    return 0;
+}
+
+int64_t orc_selftest_known_alignment(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL */) {
+    static const char AL[5] = "ACGTN";
+    static const double RATES[8] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.34, 0.5};
+    uint8_t q[40], r[200];
+    int64_t DP[48], OG[48];
+    int64_t bad = 0, n_start = 0, n_end = 0, n_lost = 0;
+    uint64_t s = seed;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t m = 1 + (int64_t)(st_next(&s) % 32);
+        int64_t n = 1 + (int64_t)(st_next(&s) % 160);
+        const int nal = (st_next(&s) % 5) ? 4 : 2;
+        for (int64_t i = 0; i < m; i++) q[i] = (uint8_t)AL[st_next(&s) % (uint64_t)nal];
+        for (int64_t j = 0; j < n; j++) r[j] = (uint8_t)AL[(st_next(&s) % 50) ? st_next(&s) % (uint64_t)nal : 4];
+        int64_t first = 1, last = n;
+        if (st_next(&s) % 2) {
+            first = 1 + (int64_t)(st_next(&s) % (uint64_t)n);
+            last = first + (int64_t)(st_next(&s) % (uint64_t)(n - first + 1));
+        }
+        int copies = (int)(st_next(&s) % 3);
+        for (int cpy = 0; cpy < copies; cpy++) {
+            int64_t pos = (int64_t)(st_next(&s) % (uint64_t)n);
+            const uint64_t where = st_next(&s) % 6;
+            if (where == 0) pos = first - 1;
+            if (where == 1) pos = first - 2 >= 0 ? first - 2 : 0;
+            if (where == 2) pos = last - m + (int64_t)(st_next(&s) % 3) - 1;
+            if (pos < 0) pos = 0;
+            for (int64_t i = 0; i < m && pos < n; i++) {
+                uint64_t u = st_next(&s) % 100;
+                if (u < 6) r[pos++] = (uint8_t)AL[st_next(&s) % (uint64_t)nal];
+                else if (u < 10) continue;
+                else if (u < 14) { r[pos++] = (uint8_t)AL[st_next(&s) % (uint64_t)nal]; if (pos < n) r[pos++] = q[i]; }
+                else r[pos++] = q[i];
+            }
+        }
+        const double rate = RATES[st_next(&s) % 8];
+        const int32_t trim = (int32_t)((int[]){0, 3, 5}[st_next(&s) % 3]);
+        orc_align_t a = orc_semiglobal_core(DP, OG, q, m, r, n, rate, 0, 1, 1, 0, 0, ORC_OUT_TRACEBACK, trim, first, last, n, 1, m);
+        const int64_t ae = (int64_t)floor(rate * (double)m);
+        if (a.raw >= INF_INT) continue;
+        /* the kernel's first sweep gives (d, position): the end for trim_side 5 / none, the start for trim_side 3 */
+        int64_t d = 0, pos = 0;
+        if (!orc_known_trim_positions(q, m, r, first - 1, last, trim == 3 ? 3 : 5, &d, &pos) || d != a.raw || d > ae) {
+            bad++;
+            continue;
+        }
+        const int64_t other = orc_known_other_position(q, m, r, first - 1, last, trim, d, pos, ae);
+        int ok;
+        if (trim == 3) {
+            if (a.start < 1) { n_lost += pos == 0; ok = pos == 0; }  /* (start <= 0: the kernel hands the read on) */
+            else { ok = pos == a.start && other == a.end; n_end++; }
+        } else {
+            if (pos != a.end) ok = 0;
+            else if (a.start < 1) { ok = other == 0; n_lost++; }
+            else { ok = other == a.start; n_start++; }
+        }
+        if (!ok) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = it; first_bad[1] = m; first_bad[2] = n; first_bad[3] = a.raw;
+                first_bad[4] = a.start; first_bad[5] = a.end; first_bad[6] = pos; first_bad[7] = other * 10 + trim;
+            }
+            bad++;
+        }
+    }
+    if (bad == 0 && first_bad) { first_bad[1] = n_start; first_bad[2] = n_end; first_bad[3] = n_lost; }
+    return bad;
+}

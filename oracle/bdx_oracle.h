@@ -172,6 +172,10 @@ int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad
 int orc_known_trim_positions(const uint8_t *q, int64_t m, const uint8_t *r, int64_t lo, int64_t hi, int32_t trim_side,
                              int64_t *d_out, int64_t *pos_out);
 int64_t orc_selftest_known_start(uint64_t seed, int64_t iters, int64_t *first_bad);
+/* model of the wave kernel's known-alignment class: the other position of a winner (anchored sweep) */
+int64_t orc_known_other_position(const uint8_t *q, int64_t m, const uint8_t *r, int64_t wlo, int64_t whi, int32_t trim_side,
+                                 int64_t d, int64_t pos, int64_t kk);
+int64_t orc_selftest_known_alignment(uint64_t seed, int64_t iters, int64_t *first_bad);
 
 #ifdef __cplusplus
 }

@@ -156,6 +156,8 @@ def lib():
         L.orc_selftest_band_class.argtypes = [C.c_uint64, C.c_int64, i64p]
         L.orc_selftest_known_start.restype = C.c_int64
         L.orc_selftest_known_start.argtypes = [C.c_uint64, C.c_int64, i64p]
+        L.orc_selftest_known_alignment.restype = C.c_int64
+        L.orc_selftest_known_alignment.argtypes = [C.c_uint64, C.c_int64, i64p]
         L.orc_unit_distance.restype = C.c_int64
         L.orc_unit_distance.argtypes = [u8p, C.c_int64, u8p, C.c_int64]
         _lib = L

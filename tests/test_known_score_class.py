@@ -83,3 +83,15 @@ def test_known_trim_class_reversed_sweep_gives_the_reference_start():
     bad = H.orc.lib().orc_selftest_known_start(20260515, 600_000, fb)
     assert bad == 0, f"first disagreement (iter, m, n, core.raw, model d, core.start, model pos | core.end, trim | model pos): {list(fb)}"
     assert fb[1] > 50_000 and fb[2] > 500 and fb[3] > 20_000, list(fb)  # starts inside the read / starts <= 0 / ends compared
+
+
+def test_known_alignment_class_anchored_sweeps_give_the_other_position():
+    """with one position of a pass's winner known (its end for trim_side 5 / none, its start for trim_side 3),
+    the other one comes out of an ANCHORED bit-vector sweep — right to left from the end with row 0 not free (the first column
+    whose score equals the distance; + the diagonal-move bit), or left to right from a prepared "row 1 entered here" column (the
+    first column whose score equals the distance).  The 32-bit model (oracle orc_known_other_position) behind the first sweep's
+    model against the line-faithful core with traceback: every trim side, ties, window edges, starts <= 0 (handed on)."""
+    fb = (C.c_int64 * 8)()
+    bad = H.orc.lib().orc_selftest_known_alignment(20260515, 600_000, fb)
+    assert bad == 0, f"first disagreement (iter, m, n, core.raw, core.start, core.end, known position, other * 10 + trim): {list(fb)}"
+    assert fb[1] > 100_000 and fb[2] > 50_000 and fb[3] > 2_000, list(fb)  # starts from ends / ends from starts / starts <= 0
