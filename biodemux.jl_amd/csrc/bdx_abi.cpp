@@ -319,11 +319,17 @@ int build_bitpar_tables(bdx_ctx *ctx) {
         bp.dense_d = expected >= 1.0 && total_b <= 256 && !ctx->tune.no_dense;  // (used by the kernels without seeds only; they then keep four slots)
     }
     // known-score class (config level): SimpleScoring with unit costs, ScoreOnly output.
+    // (:exact with whole ranges IS the class at a budget of 0: exact_align, classification.jl:485-548, returns (0.0, s, s + m - 1)
+    // for an occurrence — the leftmost, or the rightmost with trim_side = 3 — else Inf: the value, the end of the first column
+    // at distance 0 and the largest origin of a distance-0 alignment; raw bytes are compared, N is a literal: SimpleScoring.
+    // With a ref_search_range its meaning differs — allowed START positions, SURVEY Q11 — so only whole ranges qualify.)
+    const auto whole_rng = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
     for (int k = 0; k < npass; ++k) {
         const bool score_only = c.pass[k].trim_side == 0 && !c.need_traceback;
-        bp.known_ok[k] = c.algorithm == BDX_ALG_SEMIGLOBAL && !c.has_nindel && c.match == 0 && c.mismatch == 1 &&
-                         c.indel == 1 && score_only && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE &&
-                         !ctx->tune.no_known;
+        const bool unit_sg = c.algorithm == BDX_ALG_SEMIGLOBAL && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1;
+        const bool exact_whole = c.algorithm == BDX_ALG_EXACT && c.pass[k].explicit_window == 0 && whole_rng(c.pass[k].ref_search_range) &&
+                                 whole_rng(c.pass[k].barcode_start_range) && whole_rng(c.pass[k].barcode_end_range) && !getenv("BDX_NO_KNOWN_EXACT");
+        bp.known_ok[k] = (unit_sg || exact_whole) && score_only && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE && !ctx->tune.no_known;
     }
     bp.enabled = 1;
     return BDX_OK;
@@ -611,6 +617,8 @@ int build_wave_tables(bdx_ctx *ctx) {
     // :hamming / :exact (always split: their scans run in the exact kernel, restricted to the hand-over windows): the
     // budget is floor(rate * m) substitutions / 0, one operation costs 1
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
+    // the known classes' config condition: unit-cost SimpleScoring, or :exact (whole ranges: checked below / in build_bitpar_tables)
+    const bool kclass = (sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1) || (c.algorithm == BDX_ALG_EXACT && !getenv("BDX_NO_KNOWN_EXACT"));
     int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
     if (cmin < 1 || (sgm && c.match < 0)) return WAVE_NO();
     const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
@@ -793,7 +801,7 @@ int build_wave_tables(bdx_ctx *ctx) {
     F.wplan_k = BdxWavePlan{};
     bool trims_ok = true;
     for (int k = 0; k < npass; ++k) trims_ok = trims_ok && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE;
-    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !c.need_traceback &&
+    if (split && kclass && trims_ok && !c.need_traceback &&
         !ctx->tune.no_known && !ctx->tune.no_kend) {
         bool fits = true;  // entry = barcode << 22 | d << 16 | position key
         for (uint32_t x : meta) fits = fits && (((x >> 8) & 255u) == 255u || ((x >> 8) & 255u) < 64u);
@@ -810,7 +818,9 @@ int build_wave_tables(bdx_ctx *ctx) {
     // more (anchored) sweep per pass and read, so per-pass positions and the DemuxStats histograms need no exact kernel either
     // (bdx_wave_aln.hip); taken per launch when the caller wants positions the known-trim class does not know, or statistics.
     F.wplan_a = BdxWavePlan{};
-    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !ctx->tune.no_known &&
+    // (:exact reports the occurrence's positions whatever the output policy, classification.jl:485-548: its score-only form only
+    // serves callers that do not ask for them — the others take this class per launch, bdx_classify_device)
+    if ((split || c.algorithm == BDX_ALG_EXACT) && kclass && trims_ok && !ctx->tune.no_known &&
         !ctx->tune.no_kend && !getenv("BDX_NO_KALN")) {
         bool fits = true;
         for (uint32_t x : meta) fits = fits && (((x >> 8) & 255u) == 255u || ((x >> 8) & 255u) < 64u);
@@ -970,6 +980,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     bool split = false;
     for (int k = 0; k < npass; ++k) split |= !bp.known_ok[k];
     const bool sgm = c.algorithm == BDX_ALG_SEMIGLOBAL;
+    const bool kclass = (sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1) || (c.algorithm == BDX_ALG_EXACT && !getenv("BDX_NO_KNOWN_EXACT"));
     const int cmin = sgm ? (c.mismatch < c.indel ? c.mismatch : c.indel) : 1;
     if (cmin < 1 || (sgm && c.match < 0)) return BDX_OK;
     // the pairs tier (capped set): the filter only has to be lossless for alignments of COST <= cap x cmin — a barcode it does not
@@ -1141,7 +1152,7 @@ int build_pair_tables(bdx_ctx *ctx) {
     F.pplan_k = BdxWavePlan{};
     bool trims_ok = true;
     for (int k = 0; k < npass; ++k) trims_ok = trims_ok && c.pass[k].explicit_window != BDX_WINDOW_ALIGN_ONE;
-    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !c.need_traceback &&
+    if (split && kclass && trims_ok && !c.need_traceback &&
         !ctx->tune.no_known && !ctx->tune.no_kend && groups == 1 && wp.pairs_kb <= 4) {  // (the same-diagonal variants only exist in split mode)
         F.pplan_k = wp;
         F.pplan_k.split = 0;
@@ -1151,7 +1162,7 @@ int build_pair_tables(bdx_ctx *ctx) {
             if (c.pass[k].trim_side == 3) F.pplan_k.kend = 2;
     }
     F.pplan_a = BdxWavePlan{};  // known-alignment class (build_wave_tables): the same with `summary` allowed
-    if (split && sgm && !c.has_nindel && c.match == 0 && c.mismatch == 1 && c.indel == 1 && trims_ok && !ctx->tune.no_known &&
+    if (split && kclass && trims_ok && !ctx->tune.no_known &&
         !ctx->tune.no_kend && !getenv("BDX_NO_KALN") && groups == 1 && wp.pairs_kb <= 4) {
         F.pplan_a = wp;
         F.pplan_a.split = 0;
@@ -2268,6 +2279,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         const int npass = ctx->dev.is_dual ? 2 : 1;
         bool split = false;
         for (int k = 0; k < npass; ++k) split |= !ctx->F().bplan.known_ok[k];
+        // (:exact returns the occurrence's start and end whatever the output policy: a caller that wants them gets the launch in
+        // its split form — known-alignment class first, exact kernel for what that lists)
+        if (ctx->dev.algorithm == BDX_ALG_EXACT && (o.pass_start != nullptr || o.pass_end != nullptr)) split = true;
         const bool tiered = tier_len > 0;
         if (n_reads > 0xFFFFFFF0LL) return fail(ctx, BDX_E_INVALID, "more than 2^32 reads in one batch");
         uint32_t *c0 = nullptr, *c1 = nullptr, *w0 = nullptr, *w1 = nullptr;

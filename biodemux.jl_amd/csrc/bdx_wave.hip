@@ -1685,7 +1685,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.trim0 = cfg.pass[0].trim_side;
     a.trim1 = cfg.is_dual ? cfg.pass[1].trim_side : 0;
     a.stats = BdxDevStats{};
-    a.need_tb = cfg.need_traceback;
+    a.need_tb = (cfg.need_traceback || cfg.algorithm == BDX_ALG_EXACT) ? 1 : 0;  // (:exact always reports the occurrence's positions)
     a.meta = wp.d_meta;
     a.settle = wp.d_settle;
     a.B = wp.n_barcodes;
