@@ -54,6 +54,7 @@ BdxTuning read_tuning() {
     t.poison = getenv("BDX_POISON") != nullptr;
     if (const char *e = getenv("BDX_WAVE_RW")) t.wave_rw = atoi(e);
     if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
+    if (const char *e = getenv("BDX_WAVE_MAXRES")) t.wave_maxres = atoi(e);
     if (const char *e = getenv("BDX_CU_COUNT")) t.cu_count = atoi(e);
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
@@ -857,13 +858,15 @@ bool size_wave(bdx_ctx *ctx, BdxWavePlan &wp, int read_len, long long n_reads) {
         const int hq_cap = rw * (int)std::ceil(std::max(6.0, 4.0 + 2.5 * wp.chance));
         const int sq_cap = rw * (int)std::ceil(std::max(3.0, 1.8 + 1.6 * wp.chance));
         const size_t area = bdx_wave_area_bytes(rw, (int)span, false, hq_cap, sq_cap, wp.cand_words + (wp.ranged ? 4 : 0));
-        const int shapes[3] = {8, 16, 4};
+        const int maxres = ctx->tune.wave_maxres > 0 ? ctx->tune.wave_maxres : 16;
+        const int shapes[4] = {8, 16, 4, ctx->tune.wave_waves};  // (a forced shape may be any wave count up to 16)
         for (int w : shapes) {
-            if (ctx->tune.wave_waves && w != ctx->tune.wave_waves) continue;
+            if (w < 1 || w > 16 || (ctx->tune.wave_waves && w != ctx->tune.wave_waves)) continue;
             const size_t lds = tables + (size_t)w * area;
             if (lds > LDS_MAX) continue;
             int per_cu = (int)(LDS_MAX / (((lds + 1279) / 1280) * 1280));  // 1280-byte LDS granules
-            if (per_cu * w > 16) per_cu = 16 / w;
+            if (per_cu * w > maxres) per_cu = maxres / w;
+            if (per_cu < 1) continue;
             const int resident = per_cu * w;
             if (resident > best_waves) {
                 best_waves = resident;

@@ -55,6 +55,7 @@ struct BdxTuning {
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;
+    int wave_maxres = 0;  // BDX_WAVE_MAXRES: resident waves per compute unit the wave kernel's geometry may plan for (default 16 = four per SIMD: the kernels need 114-128 VGPRs; tuning: the occupancy experiment of DESIGN §4)
     int cu_count = 0;     // BDX_CU_COUNT: pretend the device has this many compute units (tests of the grid sizing)
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
     int debug = 0;        // BDX_DEBUG: honoured only by builds with -DBDX_TUNING (phase skips: results are wrong)

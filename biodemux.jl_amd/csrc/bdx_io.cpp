@@ -734,7 +734,7 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
         int fail = 0;
     };
     std::vector<Dest> dest((size_t)n_classes);
-    const int64_t IOV_LIMIT = (int64_t)8 << 20;  // classes with more bytes than this in a batch are gathered
+    static const int64_t IOV_LIMIT = getenv("BDX_IO_IOV_LIMIT") ? atoll(getenv("BDX_IO_IOV_LIMIT")) : (int64_t)8 << 20;  // classes with more bytes than this in a batch are gathered
     for (int c : todo) {
         Dest &ds = dest[(size_t)c];
         std::string low(class_paths[c]);

@@ -314,8 +314,11 @@ __device__ __forceinline__ void anchored_block(const uint32_t A0, const uint32_t
 // (BASELINE config 5: 10 kbp reads, window 1:200): the tile is scattered like a pairs-mode tile, only each read's resolved
 // column window (classification.jl:795-807) is fetched into its slot, and everything downstream sees the window as the read
 // (what the verdict needs of the real read — its length, its number — rides along).
+#ifndef BDX_WAVE_BOUNDS  // (tuning: the occupancy experiment of DESIGN §4 compiles the kernels for more waves per SIMD)
+#define BDX_WAVE_BOUNDS __launch_bounds__(1024)
+#endif
 template <int RW, int TF, int NV, int Q, bool SPLIT, int KB, int NW, bool MG = false, int KEND = 0, bool GEN = true, bool WINM = false>
-__global__ __launch_bounds__(1024) void bdx_wave_kernel(const WaveArgs a) {
+__global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
     constexpr bool PAIRS = KB > 0;
     constexpr bool KREV = KEND >= 2;  // known-trim class with a trim_side = 3 pass: reversed sweeps (1: trim sides 5 / none only — the sweeps of round 3's known-end class)
     constexpr bool KALN = KEND == 3;  // known-alignment class: start AND end of every pass's winner (anchored sweeps), for per-pass outputs and the statistics tables
