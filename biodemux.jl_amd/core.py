@@ -225,9 +225,14 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
         if _io not in ("auto", "native", "python"):
             raise ValueError("_io must be 'auto', 'native' or 'python'")
         use_native = _io == "native" or (_io == "auto" and nativeio.available())
+        if _timings is not None:
+            _timings["pre_s"] = (_dt.datetime.now() - start_time).total_seconds()  # everything before the first batch can be read
         if use_native:
+            t_call = _dt.datetime.now()
             nativeio.demux_native(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads,
                                   on_batch, _timings)
+            if _timings is not None:  # (beyond the pipeline's own wall clock: releasing its batch buffers)
+                _timings["native_call_s"] = (_dt.datetime.now() - t_call).total_seconds()
         else:
             _demux(fastq1, fastq2, config, output_directory, prefix1, prefix2, classifier, _batch_reads, on_batch)
         counts = np.asarray(classifier.counts)
@@ -239,6 +244,8 @@ def execute_demultiplexing(*args, _classifier_factory: Optional[Callable[[DemuxC
             _timings["close_s"] = (_dt.datetime.now() - t_close).total_seconds()
 
     duration = _dt.datetime.now() - start_time  # core.jl:484-485
+    if _timings is not None:
+        _timings["total_s"] = duration.total_seconds()
     if o["log"]:  # core.jl:487-491
         _log(f"Done: Finished in {canonical_duration(duration)}.")
     stats = DemuxStats.from_counts(counts, len(config.bc_seqs), len(config.bc_seqs2) if config.is_dual else 0)

@@ -55,6 +55,7 @@ struct BdxTuning {
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;
+    int no_staged_download = 0;  // BDX_NO_STAGED_DOWNLOAD: large result vectors go back with the runtime's own pageable copies
     int wave_maxres = 0;  // BDX_WAVE_MAXRES: resident waves per compute unit the wave kernel's geometry may plan for (default 16 = four per SIMD: the kernels need 114-128 VGPRs; tuning: the occupancy experiment of DESIGN §4)
     int cu_count = 0;     // BDX_CU_COUNT: pretend the device has this many compute units (tests of the grid sizing)
     int no_tier = 0;      // BDX_NO_TIER: no tiered budgets (every read filtered at the full budget)
@@ -108,6 +109,7 @@ struct bdx_ctx {
     hipStream_t copy_stream = nullptr;   // host entry point, large batches: chunk uploads beside the previous chunk's kernels
     hipEvent_t copy_events[8] = {};
     int64_t pipelined_calls = 0;
+    int64_t staged_downloads = 0;  // large result downloads that went through the page-locked staging buffer (download_items)
     hipStream_t stream = nullptr;
     // device tables
     DevBuf bc_bytes[2], bc_off[2], bc_nn[2];
@@ -127,6 +129,10 @@ struct bdx_ctx {
     void *h_stage = nullptr;  // page-locked staging for the verdict vectors of small batches
     size_t h_stage_bytes = 0;
     void *h_in = nullptr;     // page-locked staging for the bytes + offsets of small batches
+    void *h_back = nullptr;   // page-locked staging for the result vectors of large batches handed over in pageable memory (download_items)
+    size_t h_back_bytes = 0;
+    hipEvent_t back_events[10] = {};
+    bool back_events_made = false;
     size_t h_in_bytes = 0;
     int64_t window_uploads = 0;
     int64_t band_launches = 0;  // (pass, exact-kernel launch) pairs that ran with the diagonal-band DP enabled

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
-    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pair_launches", "bdx_pipelined_calls", "bdx_rejected_windows",
+    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pair_launches", "bdx_pipelined_calls", "bdx_staged_downloads", "bdx_rejected_windows",
     "bdx_debug_rejected_windows_total",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
@@ -221,6 +221,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_pair_launches.argtypes = [vp]
     L.bdx_pipelined_calls.restype = C.c_int64
     L.bdx_pipelined_calls.argtypes = [vp]
+    L.bdx_staged_downloads.restype = C.c_int64
+    L.bdx_staged_downloads.argtypes = [vp]
     L.bdx_rejected_windows.restype = C.c_int64
     L.bdx_rejected_windows.argtypes = [vp]
     L.bdx_debug_rejected_windows_total.restype = C.c_int64
@@ -478,6 +480,11 @@ class HipClassifier:
     def pipelined_calls(self) -> int:
         """classify() calls that uploaded their batch in chunks beside the previous chunk's kernels."""
         return int(self.lib.bdx_pipelined_calls(self.h))
+
+    @property
+    def staged_downloads(self) -> int:
+        """classify() calls whose result vectors came back through the page-locked staging buffer (large pageable outputs)."""
+        return int(self.lib.bdx_staged_downloads(self.h))
 
     @property
     def rejected_windows(self) -> int:

@@ -287,6 +287,12 @@ int64_t bdx_pair_launches(const bdx_ctx *ctx);
  * (large batches of configs with heavier kernels; env BDX_NO_PIPELINE switches it off).  Results are identical. */
 int64_t bdx_pipelined_calls(const bdx_ctx *ctx);
 
+/* How many bdx_classify_host calls brought their result vectors back through the context's page-locked staging buffer with
+ * several host threads copying them out (large batches whose output arrays are pageable; env BDX_NO_STAGED_DOWNLOAD switches
+ * it off — the runtime's own pageable copies then).  Results are identical; replaces nothing in the reference (its workers
+ * write into Julia arrays, core.jl:243-267) — this is the PCIe side of the drop-in boundary. */
+int64_t bdx_staged_downloads(const bdx_ctx *ctx);
+
 /* Hand-over windows the exact kernel refused because they do not end inside the read ("not a window": defence in
  * depth behind the filter kernels, classification.jl:238-445 then runs over the whole pass window).  A correct
  * producer / consumer pair never leaves one: the counter must read 0 (synchronises the stream); the test-suite runs

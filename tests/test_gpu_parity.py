@@ -1225,3 +1225,45 @@ def test_pipelined_host_upload_equals_the_single_upload(monkeypatch):
         k = 4000
         exp = H.orc.OracleClassifier(cfg, nthreads=16).classify(seq[:off[k]], off[:k + 1])
         fuzz.assert_same({kk: (v[:k] if v.shape[0] == 1_000_001 else v[:2 * k]) for kk, v in res[True][0].items()}, exp, str(kw))
+
+
+def test_large_result_downloads_all_forms(monkeypatch):
+    """Large batches bring their result vectors back through a page-locked staging buffer (several host threads copy them
+    out).  With and without it, output arrays that are fresh / reused / not page-aligned / page-locked, with and without the
+    per-pass outputs, single upload and chunked upload: identical results, the staged form really ran (or really did not), a
+    sample against the oracle."""
+    from biodemux_jl_amd import hipabi
+    bcs = synth.make_barcodes(96, 24)
+    n = 1_150_003
+    seq, off, _ = synth.make_reads(bcs, n, 150, seed=661)
+    for kw, want_pass in ((dict(max_error_rate=0.1), False), (dict(max_error_rate=0.2, trim_side=5), True)):
+        cfg = _c2_config(bcs, **kw)
+        ref = None
+        for env in ({}, {"BDX_NO_STAGED_DOWNLOAD": "1"}):
+            for k in ("BDX_NO_STAGED_DOWNLOAD",):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+                got = hc.classify(seq, off)  # fresh arrays
+                assert (hc.staged_downloads > 0) == ("BDX_NO_STAGED_DOWNLOAD" not in env), (kw, env, hc.staged_downloads)
+                if ref is None:
+                    ref = got
+                    k = 3000
+                    exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want_pass).classify(seq[:off[k]], off[:k + 1])
+                    fuzz.assert_same({kk: (v[:k] if v.shape[0] == n else v[:2 * k]) for kk, v in got.items()}, exp, str(kw))
+                for kk, v in got.items():
+                    assert np.array_equal(v, ref[kk], equal_nan=True) if v.dtype.kind == "f" else np.array_equal(v, ref[kk]), (kw, env, kk)
+                if not want_pass:
+                    # reused arrays holding garbage, arrays that start in the middle of a page, page-locked arrays
+                    reuse = {f: np.full(n, -77, dtype=np.int32) for f in ("bc1", "bc2", "keep_start", "keep_end")}
+                    odd = {f: np.full(n + 3, -77, dtype=np.int32)[3:] for f in reuse}
+                    pinned = {f: hipabi.pinned_empty(n, np.int32) for f in reuse}
+                    before = hc.staged_downloads
+                    for outs in (reuse, odd, pinned):
+                        g2 = hc.classify(seq, off, out=outs)
+                        for f in reuse:
+                            assert np.array_equal(g2[f], ref[f]), (kw, env, f)
+                    # page-locked destinations take the direct copies
+                    assert hc.staged_downloads - before == (2 if "BDX_NO_STAGED_DOWNLOAD" not in env else 0), (env, hc.staged_downloads - before)
+                assert hc.rejected_windows == 0

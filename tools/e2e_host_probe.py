@@ -64,6 +64,8 @@ def child():
             pass
 
     kw = {"_classifier_factory": Fake} if os.environ.get("FAKE") else {}
+    if os.environ.get("BATCH"):
+        kw["_batch_reads"] = int(os.environ["BATCH"])
     for rep in range(int(os.environ.get("REPS", "4"))):
         out = os.path.join(root, "out")
         shutil.rmtree(out, ignore_errors=True)
@@ -73,7 +75,7 @@ def child():
         dt = time.perf_counter() - t
         nb = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
         assert nb == n * 319, (nb, n * 319)
-        print(f"RUN {rep} {dt:.4f} {tm['index_s']:.4f} {tm['pack_s']:.4f} {tm['classify_s']:.4f} {tm['write_s']:.4f} {tm['wall_s']:.4f} {tm['threads']}", flush=True)
+        print(f"RUN {rep} {dt:.4f} {tm['index_s']:.4f} {tm['pack_s']:.4f} {tm['classify_s']:.4f} {tm['write_s']:.4f} {tm['wall_s']:.4f} {tm['threads']} {tm.get('pre_s', 0):.4f} {tm.get('close_s', 0):.4f} {tm.get('total_s', 0):.4f} {tm.get('native_call_s', 0):.4f}", flush=True)
         sys.stderr.write(f"[probe] end of run {rep}\n")
         sys.stderr.flush()
     shutil.rmtree(out, ignore_errors=True)
@@ -103,7 +105,7 @@ def main():
     for r, ph in zip(runs, phases):
         dt = float(r[2])
         print(f"{label:28s} run {r[1]}: {dt:.3f} s = {n / dt / 1e6:5.1f} M reads/s | index {float(r[3]):.3f} pack {float(r[4]):.3f} classify {float(r[5]):.3f} "
-              f"write {float(r[6]):.3f} (sizes {ph[0]:.3f} gather {ph[2]:.3f} files {ph[3]:.3f}) pipeline {float(r[7]):.3f} threads {r[8]}")
+              f"write {float(r[6]):.3f} (sizes {ph[0]:.3f} gather {ph[2]:.3f} files {ph[3]:.3f}) pipeline {float(r[7]):.3f} threads {r[8]} | before {float(r[9]):.3f} close {float(r[10]):.3f} inside-call {float(r[11]):.3f} native-call {float(r[12]):.3f}")
     if not os.environ.get("KEEP"):
         shutil.rmtree(root, ignore_errors=True)
 
