@@ -318,7 +318,8 @@ def run_e2e(n: int, dev_index: int, expect_matched=None):
             f.write("ID,Full_seq,Full_annotation\n" + "".join(f"bc{i + 1:03d},{b},{'B' * 24}\n" for i, b in enumerate(bcs)))
         write_s = time.time() - t0
         best = None
-        for rep in range(2):  # (first run: page cache / allocator warm-up)
+        all_runs = []
+        for rep in range(3):  # (first run: page cache / allocator warm-up, the batch buffers of the pipeline are faulted in; later runs reuse them — nativeio._BUFFER_POOL — as a long-running host would)
             out = os.path.join(root, f"out{rep}")
             tm = {}
             t1 = time.perf_counter()
@@ -330,6 +331,7 @@ def run_e2e(n: int, dev_index: int, expect_matched=None):
             if expect_matched is not None:
                 assert st.matched_reads == expect_matched, (st.matched_reads, expect_matched)
             shutil.rmtree(out)
+            all_runs.append(round(n / dt))
             if best is None or dt < best["seconds"]:
                 stages = {"reader (index + pack)": tm.get("index_s", 0.0) + tm.get("pack_s", 0.0), "classify (bdx_classify_host)": tm.get("classify_s", 0.0),
                           "writer": tm.get("write_s", 0.0)}
@@ -341,7 +343,8 @@ def run_e2e(n: int, dev_index: int, expect_matched=None):
                         "where": "tmpfs" if base else "tmp dir (no room on /dev/shm)", "generate_fastq_seconds": round(write_s, 1),
                         "note": "execute_demultiplexing(fastq, barcodes.csv, out_dir, max_error_rate=0.1) on the C2 shape: overlapped stages "
                                 "(reader thread | classify on the calling thread | writer thread, each with a pool of host threads for its batch); setup = barcode table + device context; "
-                                "output bytes = input bytes, file count and matched reads checked; best of two runs"}
+                                "output bytes = input bytes, file count and matched reads checked; best of three runs (the first faults the pipeline's batch buffers in, the others reuse them)"}
+        best["runs_reads_per_s"] = all_runs  # (every run, in order: the figure above is the best of them)
         return best
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -426,8 +429,10 @@ def main():
                 ev[1].record(stream)
             if allreduce_via.startswith("C-ABI"):
                 hc.allreduce_counts()   # enqueued on the same stream; the sum lands in the reduced vector
-            else:
+            elif world > 1:
                 total = bdist.allreduce_counts(d_counts)
+            else:
+                total = d_counts        # one rank: merge_stats over one worker is the identity (reporting.jl:1-9) — no collective, no copy
 
     for _ in range(args.warmup):
         step()

@@ -71,6 +71,9 @@ BdxTuning read_tuning() {
 #ifdef BDX_TUNING
     if (const char *e = getenv("BDX_DEBUG")) t.debug = atoi(e);
 #endif
+    // BDX_NO_WAVE_FALLBACK: known-score forms of the wave kernel list a read whose record tables overflow instead of sweeping
+    // it over every barcode themselves (results identical; bdx_last_list_reads shows the difference) — bit 30 of the kernels' dbg word
+    if (getenv("BDX_NO_WAVE_FALLBACK")) t.debug |= 1 << 30;
     return t;
 }
 
@@ -2405,7 +2408,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         }
         // scratch words (d_maxlen, 1 KiB): +64 tile queue, +128 hand-over count (+132.. tuning statistics),
         // +192 tier-0 list length, +256 tile queue of the second launch; one memset clears them all
-        char *scratch = (char *)ctx->d_maxlen.p;
+        // (the block's two halves alternate between calls: this call's last launch clears the other half for the next call,
+        // which then needs no memset of its own — 5 us of fill + a launch gap per call, 1 % of a 10 M-read C2 step)
+        const int spar = ctx->scratch_par & 1;
+        char *scratch = (char *)ctx->d_maxlen.p + 512 * spar;
+        uint32_t *zero_next = (uint32_t *)((char *)ctx->d_maxlen.p + 512 * (1 - spar) + 64);
         uint32_t *exc_list = nullptr;
         unsigned int *exc_count = (unsigned int *)(scratch + 128);
         if (!split) {
@@ -2424,8 +2431,9 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             for (DevBuf *b : bufs)
                 if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, ctx->stream));
         }
-        if (!ctx->scratch_zeroed) HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 448, ctx->stream));
+        if (!ctx->scratch_zeroed && !ctx->scratch_clean[spar]) HIP_TRY(ctx, hipMemsetAsync(scratch + 64, 0, 4 * BDX_SCRATCH_WORDS, ctx->stream));
         ctx->scratch_zeroed = false;
+        ctx->scratch_clean[spar] = false;  // (a call that fails half-way leaves it that way: the next one clears it itself)
         // restricted runs of passes that only report score (+ end) through the clean-class DP start m + kb columns before
         // the first end column (orc_selftest_clean_short_lookback); everything else keeps 2 (m + kb) + 1
         int short_lb[2] = {0, 0};
@@ -2664,11 +2672,14 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             HIP_TRY(ctx, bdx_launch_generic(band_cfg(ctx->F()), ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, w0,
                                             npass > 1 ? w1 : nullptr, n0, npass > 1 ? n1 : nullptr, listed ? t0.in_list : nullptr,
-                                            listed ? t0.in_count : nullptr, stp));
+                                            listed ? t0.in_count : nullptr, stp, nullptr, nullptr, zero_next));
         else
             HIP_TRY(ctx, bdx_launch_generic(ctx->dev, ctx->plan, d_seq_bytes, (const long long *)d_seq_off, n_reads, o,
                                             ctx->counts, c0, npass > 1 ? c1 : nullptr, ctx->stream, nullptr, nullptr, nullptr,
-                                            nullptr, exc_list, exc_count, stp));
+                                            nullptr, exc_list, exc_count, stp, nullptr, nullptr, zero_next));
+        // (the call's last launch is enqueued: the other half will hold zeros when the next call's kernels start)
+        ctx->scratch_clean[1 - spar] = true;
+        ctx->scratch_par = 1 - spar;
 #ifdef BDX_TUNING
         if (ctx->tune.debug & 128) {  // tuning statistics of the fused kernel (see bdx_bitpar.hip)
                 unsigned int st[4] = {0, 0, 0, 0}, tl = 0;
@@ -2751,7 +2762,7 @@ int32_t bdx_classify_host(bdx_ctx *ctx, const uint8_t *seq_bytes, const int64_t 
         void *h_in_dev = nullptr;  // the staging buffer as the device sees it
         HIP_TRY(ctx, hipHostGetDevicePointer(&h_in_dev, ctx->h_in, 0));
         const bool zero_scratch = ctx->d_maxlen.p != nullptr;  // (allocated at bdx_create when a filter is in use)
-        HIP_TRY(ctx, bdx_launch_copy(ctx->d_seq.p, h_in_dev, bytes, ctx->stream, zero_scratch ? (char *)ctx->d_maxlen.p + 64 : nullptr, 448));
+        HIP_TRY(ctx, bdx_launch_copy(ctx->d_seq.p, h_in_dev, bytes, ctx->stream, zero_scratch ? (char *)ctx->d_maxlen.p + 512 * (ctx->scratch_par & 1) + 64 : nullptr, 4 * BDX_SCRATCH_WORDS));
         ctx->scratch_zeroed = zero_scratch;
         const int rcs = run_and_download(ctx, (const uint8_t *)ctx->d_seq.p - base, (const int64_t *)((const char *)ctx->d_seq.p + o_off),
                                          n_reads, out, /*mapped_outputs=*/true);
@@ -2879,6 +2890,15 @@ int64_t bdx_pair_launches(const bdx_ctx *ctx) { return ctx ? ctx->pair_launches 
 
 int64_t bdx_pipelined_calls(const bdx_ctx *ctx) { return ctx ? ctx->pipelined_calls : 0; }
 int64_t bdx_staged_downloads(const bdx_ctx *ctx) { return ctx ? ctx->staged_downloads : 0; }
+int64_t bdx_last_list_reads(bdx_ctx *ctx) {
+    if (!ctx || !ctx->d_maxlen.p) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    unsigned int v = 0;
+    // (the scratch half of the LAST call: the halves alternate, the last launch of a call clears the other one)
+    const char *last = (const char *)ctx->d_maxlen.p + 512 * (1 - (ctx->scratch_par & 1)) + 192;
+    if (hipMemcpy(&v, last, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
 
 int64_t bdx_rejected_windows(bdx_ctx *ctx) {
     if (!ctx || !ctx->d_dbg.p) return 0;

@@ -55,6 +55,9 @@ struct GenericArgs {
     double tier_slo[2];
     uint32_t *tier_list;
     unsigned int *tier_count;
+    // the LAST launch of a classify call clears the scratch words (tile queues, list lengths) the NEXT call will use — the other
+    // half of the context's scratch block, which no kernel of this call touches (bdx_abi.cpp: ping-pong): no memset per call
+    uint32_t *zero_words;
 };
 
 // Tier settle rule for one pass evaluated over the barcodes tier 1 can see (every b with unit distance <= its
@@ -86,6 +89,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? (CLEAN ? BDX_CLEAN_WAVES : 2) : 1)
     const int tid = threadIdx.x;
     const int B0 = cfg.pass[0].n_barcodes;
     const int B1 = cfg.is_dual ? cfg.pass[1].n_barcodes : 0;
+    if (a.zero_words && blockIdx.x == 0)
+        for (int i = tid; i < BDX_SCRATCH_WORDS; i += BS) a.zero_words[i] = 0u;
 
     size_t o = 0;
     LDS int *DPbase = (LDS int *)(smem + o);
@@ -420,9 +425,10 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               hipStream_t stream, const uint32_t *d_wins0, const uint32_t *d_wins1,
                               const uint8_t *d_wcnt0, const uint8_t *d_wcnt1, const uint32_t *d_list,
                               const unsigned int *d_list_count, const BdxDevStats *stats, const BdxTierArgs *tier,
-                              const double *tier_slo) {
+                              const double *tier_slo, uint32_t *zero_words) {
     if (n_reads <= 0) return hipSuccess;
     GenericArgs a;
+    a.zero_words = zero_words;
     a.cfg = cfg;
     a.seq = d_seq;
     a.off = d_off;

@@ -273,7 +273,10 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
                               const uint32_t *d_wins1 = nullptr, const uint8_t *d_wcnt0 = nullptr,
                               const uint8_t *d_wcnt1 = nullptr, const uint32_t *d_list = nullptr,
                               const unsigned int *d_list_count = nullptr, const BdxDevStats *stats = nullptr,
-                              const BdxTierArgs *tier = nullptr, const double *tier_slo = nullptr);
+                              const BdxTierArgs *tier = nullptr, const double *tier_slo = nullptr, uint32_t *zero_words = nullptr);
+// scratch words of a classify call (tile queues, hand-over / tier list lengths): bytes [64, 512) of one half of the context's
+// 1 KiB scratch block; the halves alternate between calls and a call's last launch clears the other one (bdx_abi.cpp)
+#define BDX_SCRATCH_WORDS 112
 hipError_t bdx_generic_set_lds_limit(size_t bytes);
 // test switch BDX_POISON: checks (and sanitises) one hand-over between a producer and its consumer (bdx_device.hip)
 hipError_t bdx_launch_poison_check(uint32_t *list, const unsigned int *list_count, long long n_reads, const uint32_t *wins, uint8_t *wcnt,

@@ -1219,8 +1219,8 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                                                 new0 = t * RCAP + rs;
                                             else if (new1 < 0)
                                                 new1 = t * RCAP + rs;
-                                            else {  // a third record opened by one hit: not swept, the read goes to the list
-                                                flag[t] = 1;
+                                            else {  // a third record opened by one hit: not swept, the read is swept over every barcode below (flag 2)
+                                                if (flag[t] != 1) flag[t] = 2;  // (1: outside the known-score class — stays listed)
                                                 rid[t * RCAP + rs] = 0u;
                                                 rmk[t * RCAP + rs] = 0u;
                                             }
@@ -1228,7 +1228,7 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                                     }
                                     rs = (rs + 1) & (RCAP - 1);
                                 }
-                                if (!placed) flag[t] = 1;  // more than RCAP records in this read
+                                if (!placed && flag[t] != 1) flag[t] = 2;  // more than RCAP records in this read
                             }
                         } while (idx != 0u);
                     }
@@ -1243,8 +1243,8 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                         if (nw >= 0) {
                             if (kq < SQ) {
                                 recq[kq] = (uint32_t)nw;
-                            } else {  // more records than the tile's sweep list holds: this read goes to the list
-                                flag[nw / RCAP] = 1;
+                            } else {  // more records than the tile's sweep list holds: this read is swept over every barcode below
+                                if (flag[nw / RCAP] != 1) flag[nw / RCAP] = 2;
                                 rid[nw] = 0u;
                                 rmk[nw] = 0u;
                             }
@@ -1290,12 +1290,19 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
             sweep_lane(valid, t, b, lo, hi);
         }
         WAVE_SYNC();
-        if (SPLIT) {
+        if (SPLIT || !PAIRS) {
             // Reads whose tables overflowed (more records than a read or the tile holds, a hit queue that ran over: low
             // complexity): every barcode is swept over the whole read here, lane = barcode — the exact kernel then still
             // gets a true candidate mask.  (Handing such a read on with "every barcode, no windows" would make ONE lane
             // of the exact kernel run B whole-window DPs one after the other: two such reads in 2 M cost 11 ms.)
-            unsigned long long fm = tile_ok ? __builtin_amdgcn_ballot_w64(lane < nr && (flag[lane] != 0 || !hq_ok)) : 0ull;
+            // Known-score forms (round 4): the same for a read whose record tables overflowed (flag 2) — its survivors come out of
+            // the all-barcode sweeps and it is replayed like any other read (more than four survivors: still listed).  C2 lists ONE
+            // read in 10 M this way, and the general kernel's list launch behind the wave kernel takes 30 us for a one-read list
+            // against 5 us for an empty one.  (Reads outside the known-score class — flag 1 — and tiles whose hit queue ran over
+            // stay on the list.)
+            unsigned long long fm = !tile_ok ? 0ull
+                                    : SPLIT  ? __builtin_amdgcn_ballot_w64(lane < nr && (flag[lane] != 0 || !hq_ok))
+                                             : ((hq_ok && !(a.dbg & (1 << 30))) ? __builtin_amdgcn_ballot_w64(lane < nr && flag[lane] == 2) : 0ull);  // (bit 30: BDX_NO_WAVE_FALLBACK)
             while (fm) {
                 const int t = (int)__builtin_ctzll(fm);
                 fm &= fm - 1ull;
@@ -1303,7 +1310,8 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                     scnt[t] = 0;
                     wcl1[t] = 0;
                     flag[t] = 0;
-                    for (int w = 0; w < cwt; ++w) cand[t * cwt + w] = 0u;
+                    if (SPLIT)
+                        for (int w = 0; w < cwt; ++w) cand[t * cwt + w] = 0u;
                 }
                 WAVE_SYNC();
                 const int n = rlen(t);

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bdx_get_reduced_counts",
     # DemuxStats histograms (summary = true), collected on the device
     "bdx_stats_shape", "bdx_get_stats",
-    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pair_launches", "bdx_pipelined_calls", "bdx_staged_downloads", "bdx_rejected_windows",
+    "bdx_window_uploads", "bdx_band_launches", "bdx_wave_launches", "bdx_pair_launches", "bdx_pipelined_calls", "bdx_staged_downloads", "bdx_last_list_reads", "bdx_rejected_windows",
     "bdx_debug_rejected_windows_total",
 ]
 STATS_WHICH = {"pos": 0, "len": 1, "raw": 2}
@@ -223,6 +223,8 @@ def load_library(path: Optional[str] = None):
     L.bdx_pipelined_calls.argtypes = [vp]
     L.bdx_staged_downloads.restype = C.c_int64
     L.bdx_staged_downloads.argtypes = [vp]
+    L.bdx_last_list_reads.restype = C.c_int64
+    L.bdx_last_list_reads.argtypes = [vp]
     L.bdx_rejected_windows.restype = C.c_int64
     L.bdx_rejected_windows.argtypes = [vp]
     L.bdx_debug_rejected_windows_total.restype = C.c_int64
@@ -480,6 +482,11 @@ class HipClassifier:
     def pipelined_calls(self) -> int:
         """classify() calls that uploaded their batch in chunks beside the previous chunk's kernels."""
         return int(self.lib.bdx_pipelined_calls(self.h))
+
+    @property
+    def last_list_reads(self) -> int:
+        """Reads the first filter launch of the last classify call handed on through its device-side list."""
+        return int(self.lib.bdx_last_list_reads(self.h))
 
     @property
     def staged_downloads(self) -> int:

@@ -293,6 +293,13 @@ int64_t bdx_pipelined_calls(const bdx_ctx *ctx);
  * write into Julia arrays, core.jl:243-267) — this is the PCIe side of the drop-in boundary. */
 int64_t bdx_staged_downloads(const bdx_ctx *ctx);
 
+/* Reads the first filter launch of the LAST classify call (the wave kernel, or tier 1) handed on to the next kernel through
+ * its device-side list — the reads it could not answer itself (table overflows, reads outside its class, tier 1's open
+ * verdicts).  Synchronises the context's stream; a test-visibility counter (C2: one read in ten million since the wave kernel
+ * sweeps a read whose record tables overflow over every barcode itself, env BDX_NO_WAVE_FALLBACK switches that off).
+ * -1: the device could not be read. */
+int64_t bdx_last_list_reads(bdx_ctx *ctx);
+
 /* Hand-over windows the exact kernel refused because they do not end inside the read ("not a window": defence in
  * depth behind the filter kernels, classification.jl:238-445 then runs over the whole pass window).  A correct
  * producer / consumer pair never leaves one: the counter must read 0 (synchronises the stream); the test-suite runs

@@ -640,3 +640,60 @@ def test_window_mode_c5_shape_long_reads_mixed_barcode_lengths(monkeypatch):
     # ragged long reads (2..12 kbp), no hint
     seq, off, _ = synth.make_ragged_reads(bcs, 3000, 2000, 12000, seed=322, plant_hi=150, sub=0.03, ins=0.01, dele=0.01)
     _win_device_three_ways(_cfg(bcs, max_error_rate=0.2, ref_search_range=H.bdx.parse_dynamic_range("1:200")), seq, off, monkeypatch)
+
+
+def test_wave_sweeps_overflowed_reads_itself(monkeypatch):
+    """A read whose record tables overflow (low complexity: more seeded (barcode, diagonal) clusters than its table holds) is
+    swept over every barcode inside the wave kernel and replayed like any other read instead of going to the general kernel's
+    list (round 4: C2's list is one read in ten million, and a one-read list launch costs 30 us against 5 us for an empty one).
+    Both ways (BDX_NO_WAVE_FALLBACK): identical outputs and counters, equal to the oracle; the list really shrinks; reads
+    outside the known-score class (empty reads) and reads with more than four survivors stay listed."""
+    rng = np.random.Generator(np.random.PCG64(311))
+    bcs = ["ACGT" * 6, "AC" * 12, "AAAACCCCGGGGTTTTAAAACCCC", "TTTTTTTTAAAAAAAAGGGGGGGG"] + synth.make_barcodes(44, 24, seed=312)
+    reads = []
+    for i in range(9000):
+        body = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=150))
+        if i % 17 == 1:
+            reads.append("")  # (n = 0: outside the known-score class)
+        elif i % 3 == 0:
+            # a 40-base stretch of the first barcode's period inside a random read: its three 8-base pieces (one key) hit at
+            # nine positions on thirteen diagonals four apart — thirteen records for a table of eight, nine entries of the
+            # tile's hit queue (a fully periodic read would overflow the QUEUE and take its whole tile to the list)
+            at = int(rng.integers(0, 110))
+            reads.append(body[:at] + "ACGT" * 10 + body[at + 40:])
+        else:
+            reads.append(body)
+    seq, off = H.bdx.pack_reads(reads)
+    for kw in (dict(), dict(min_delta=0.05), dict(trim_side=5), dict(trim_side=3)):
+        cfg = _cfg(bcs, **kw)
+        oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=False)
+        exp = oc.classify(seq, off)
+        listed = {}
+        for fb in (True, False):
+            if fb:
+                monkeypatch.delenv("BDX_NO_WAVE_FALLBACK", raising=False)
+            else:
+                monkeypatch.setenv("BDX_NO_WAVE_FALLBACK", "1")
+            with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
+                monkeypatch.delenv("BDX_NO_WAVE_FALLBACK", raising=False)
+                for rep in range(2):  # (twice: the scratch halves alternate between calls)
+                    got = hc.classify(seq, off)
+                    fuzz.assert_same(got, exp, f"{kw} fallback {fb} [{hc.kernel_path}]")
+                    if rep == 0:
+                        assert np.array_equal(hc.counts, oc.counts), (kw, fb)
+                assert "wave" in hc.kernel_path and hc.wave_launches > 0, hc.kernel_path
+                listed[fb] = hc.last_list_reads
+                assert hc.rejected_windows == 0
+        n_empty = sum(1 for r in reads if r == "")
+        assert listed[False] > listed[True] + 1000, (kw, listed)      # the overflowing reads (a third of the batch) are answered in the kernel now
+        assert listed[True] >= n_empty, (kw, listed, n_empty)          # what is outside the class is still handed on
+
+
+def test_wave_c2_list_is_nearly_empty():
+    """The headline shape: the wave kernel hands on at most a handful of reads per million."""
+    bcs = synth.make_barcodes(96, 24)
+    seq, off, _ = synth.make_reads(bcs, 1_000_000, 150)
+    with H.bdx.HipClassifier(_cfg(bcs), want_pass=False) as hc:
+        hc.classify(seq, off)
+        assert "wave" in hc.kernel_path
+        assert 0 <= hc.last_list_reads <= 8, hc.last_list_reads
