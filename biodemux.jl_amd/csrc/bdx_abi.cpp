@@ -122,7 +122,57 @@ int plan_generic(bdx_ctx *ctx) {
         const bool band_len = len0 == 8 || len0 == 10 || len0 == 12 || len0 == 16 || len0 == 20 || len0 == 24 || len0 == 32;
         p.uniform_len = (free_ranges && same_len && band_len) ? len0 : 0;
     }
-    p.dp_rows = p.reg_rows ? 1 : d.max_m + 1;
+    // Barcodes beyond the register DP's 32 rows inside the clean class: the rolling diagonal band (bdx_core.h sg_band_roll) —
+    // H = two operation budgets at the configured rate + 9 end columns per chunk — instead of max_m + 1 LDS rows per lane
+    // (80-nt barcodes with trimming: 648 B per lane = ONE 128-lane workgroup per CU; 26 cells: two 256-lane workgroups).
+    p.band_roll = 0;
+    p.same_len = 0;
+    ctx->dev.band_hcap = 0;
+    // (only behind a filter: without hand-over windows — filter off, barcodes beyond the sweep's 128 rows — every candidate
+    // would be walked over its whole window in chunks, three times the full matrix, where sg_core's cut-off visits a few rows
+    // per column: 160-nt barcodes unfiltered 0.3 -> 0.03 M reads/s, measured; bdx_create plans again once the filter is known)
+    if (!p.reg_rows && d.max_m > 32 && !d.has_nindel && d.algorithm == BDX_ALG_SEMIGLOBAL && !d.force_lds_dp && !ctx->tune.no_clean &&
+        !ctx->band_roll_off && !getenv("BDX_NO_BAND_ROLL") && d.match >= 0 && d.mismatch >= 1 && d.indel >= 1) {
+        bool free_ranges = true, same_len = true;
+        int len0 = -1, kb_max = 0;
+        const int cmin = d.mismatch < d.indel ? d.mismatch : d.indel;
+        for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) {
+            const bdx_pass_t &ps = ctx->cfg.pass[k];
+            const auto whole = [](const bdx_range_t &r) { return !r.start_from_end && r.start_offset <= 1 && r.end_from_end && r.end_offset >= 0; };
+            free_ranges = free_ranges && ps.explicit_window == 0 && whole(ps.barcode_start_range) && whole(ps.barcode_end_range);
+            for (int b = 0; b < ps.n_barcodes; ++b) {
+                const int m = (int)(ps.bc_off[b + 1] - ps.bc_off[b]);
+                if (len0 < 0) len0 = m;
+                same_len = same_len && m == len0;
+                const int kb = (int)std::floor(d.max_error_rate * (double)m) / cmin;  // (ae as the device computes it, :254; the threshold only tightens)
+                kb_max = kb > kb_max ? kb : kb_max;
+            }
+        }
+        // H: at least two budgets + 9 end columns per chunk; up to four budgets + 9 (a clean occurrence has end columns within
+        // the budget on either side: one chunk) while two 256-lane workgroups still fit a CU (8 bytes per cell and lane)
+        int hcap = 2 * kb_max + 9;
+        {
+            size_t bc_bytes = 0;
+            int nb = 0;
+            for (int k = 0; k < (d.is_dual ? 2 : 1); ++k) {
+                bc_bytes += ctx->cfg.pass[k].bc_off[ctx->cfg.pass[k].n_barcodes];
+                nb += ctx->cfg.pass[k].n_barcodes;
+            }
+            // (what the workgroup keeps in LDS besides the cells — barcode bytes and tables, the counter histogram — as below)
+            const size_t other = (bc_bytes <= 32 * 1024 ? bc_bytes : 0) + (size_t)nb * 8 + (size_t)(d.n_counts <= 2048 ? d.n_counts : 2048) * 4 + 256;
+            const size_t room = other + 2048 < (size_t)78 * 1024 ? (size_t)78 * 1024 - other - 2048 : 0;
+            const int fit2 = (int)(room / (256 * (d.any_traceback ? 8 : 4))) - 1;  // cells per lane of a workgroup that shares the CU with another one
+            const int want = 4 * kb_max + 9;
+            const int roomy = want < fit2 ? want : fit2;
+            if (roomy > hcap) hcap = roomy;
+        }
+        if (free_ranges && hcap + 1 < d.max_m + 1 && d.max_error_rate >= 0.0 && d.max_error_rate <= 1.0) {
+            p.band_roll = 1;
+            p.same_len = same_len ? 1 : 0;
+            ctx->dev.band_hcap = hcap;
+        }
+    }
+    p.dp_rows = p.reg_rows ? 1 : (p.band_roll ? ctx->dev.band_hcap + 1 : d.max_m + 1);
     p.dp_rows_fused = d.max_m + 1;
     const size_t per_thread = (size_t)p.dp_rows * 4 * (d.any_traceback ? 2 : 1);
     const int B0 = d.pass[0].n_barcodes, B1 = d.is_dual ? d.pass[1].n_barcodes : 0;
@@ -141,7 +191,9 @@ int plan_generic(bdx_ctx *ctx) {
         // still leaves room for ~192 B per read; otherwise take what is left of the CU.
         const size_t share = 80 * 1024;  // two workgroups per CU (the exact kernels are compiled for two waves per SIMD)
         size_t budget = need < share ? share - need : 0;
-        if (budget < (size_t)t * 192) budget = LDS_MAX - need;
+        // (the rolling band is bound by the latency of its LDS chain: resident waves first — two workgroups per CU with whatever
+        // staging still fits, reads that do not fit come straight from L2)
+        if (budget < (size_t)t * 192 && !(p.band_roll && need <= share)) budget = LDS_MAX - need;
         size_t stage = budget > 64 * 1024 ? 64 * 1024 : budget;
         stage &= ~(size_t)15;
         if (stage < 1024 || p.bc_stage_bytes == 0) stage = 0;
@@ -1574,7 +1626,7 @@ int init_stats(bdx_ctx *ctx) {
             const bdx_range_t &r = c.pass[p].ref_search_range;
             sg_window = sg_window || r.start_from_end || r.start_offset > 1 || c.pass[p].explicit_window != 0;
         }
-    ctx->st_len_fixed = (ctx->plan.clean || c.algorithm != BDX_ALG_SEMIGLOBAL) && !sg_window;
+    ctx->st_len_fixed = (ctx->plan.clean || ctx->plan.band_roll || c.algorithm != BDX_ALG_SEMIGLOBAL) && !sg_window;
     ctx->st_len_rows = ctx->st_len_fixed ? 2 * ctx->dev.max_m + 2 : 0;
     for (int p = 0; p < npass; ++p)
         for (int w = (ctx->st_len_fixed ? 1 : 2); w < 3; ++w) {
@@ -2064,6 +2116,12 @@ int32_t bdx_create(const bdx_config_t *config, bdx_ctx **out) {
     if (rc != BDX_OK) return bail(rc);
     rc = build_bitpar_tables(ctx);
     if (rc != BDX_OK) return bail(rc);
+    if (ctx->plan.band_roll && !ctx->F().bplan.enabled) {  // no filter, no hand-over windows: the rolling band would walk whole windows
+        ctx->band_roll_off = true;
+        rc = plan_generic(ctx);
+        if (rc != BDX_OK) return bail(rc);
+        ctx->plan.n_cu = ctx->n_cu;
+    }
     rc = build_seed_tables(ctx, true);
     if (rc != BDX_OK) return bail(rc);
     rc = build_diag_tables(ctx);
@@ -2439,7 +2497,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         int short_lb[2] = {0, 0};
         for (int k = 0; k < npass; ++k) {
             const int ts = ctx->dev.pass[k].trim_side;
-            short_lb[k] = ctx->plan.clean && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !ctx->dev.need_traceback &&
+            short_lb[k] = (ctx->plan.clean || ctx->plan.band_roll) && ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && !ctx->dev.need_traceback &&
                           (ts == 0 || (ts == 5 && o.pass_start == nullptr));
         }
         for (BdxFilterSet &f : ctx->fs) {
@@ -2454,11 +2512,14 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             dv.dense_w = (&f == &ctx->fs[0]) && dense_w;
             for (int k = 0; k < npass; ++k) {
                 const int kb = f.bplan.kb_uniform[k];
-                const bool on = windows && ctx->plan.clean && ctx->plan.uniform_len > 0 && !ctx->tune.no_band &&
-                                ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && kb >= 0 && kb <= 4;
+                // (rolling band, barcodes beyond 32 rows: any uniform budget; the first end column is rebuilt from the hand-over row
+                // when every barcode has the same length — band_lb is made of max_m)
+                const bool on = ctx->plan.band_roll ? (windows && ctx->plan.same_len && kb >= 0)
+                                                    : (windows && ctx->plan.clean && ctx->plan.uniform_len > 0 && !ctx->tune.no_band &&
+                                                       ctx->dev.algorithm == BDX_ALG_SEMIGLOBAL && kb >= 0 && kb <= 4);
                 dv.band_m = ctx->plan.uniform_len;
                 dv.band_kb[k] = on ? kb : -1;
-                if (on) ctx->band_launches += 1;
+                if (on && !ctx->plan.band_roll) ctx->band_launches += 1;
                 dv.band_lb[k] = short_lb[k] ? ctx->dev.max_m + kb : 2 * (ctx->dev.max_m + kb) + 1;
             }
             return dv;

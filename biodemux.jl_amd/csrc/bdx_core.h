@@ -499,6 +499,95 @@ __device__ __attribute__((noinline)) AlignOut sg_core_band(const bdx_u32x4 qa, c
     return res;
 }
 
+// Rolling form of the diagonal band for barcodes of ANY length: the same cells, the same recurrence and
+// the same recording rule as sg_core_band — alignments of at most kbb operations that end in row m at a column of
+// [c_lo, c_hi] only touch the H = (c_hi - c_lo + 1) + 2 kbb diagonals  j - i  in  [c_lo - m - kbb, c_hi - m + kbb]  —
+// walked ROW BY ROW: slot h of V / O holds the cell of the previous row on diagonal d0 + h while row i is computed in
+// place (the substitution input is the slot's old value, the deletion input the next slot's old value, the insertion input
+// the previous slot's new one), so a lane needs H cells however long the barcode is — against the m + 1 rows per lane of
+// sg_core, which leave a 128-lane workgroup per CU for barcodes of 80 nt.  Cells outside the band are not read; row 0 is
+// 0 with origin j (:288, :308); a cell in the column in front of the pass window holds the reference's initial column
+// (indel * i, origin 1 - i, :278-283), cells further left are never read; columns beyond c_hi are not computed (nothing a
+// recording at or before c_hi depends on lies to its right).  The last row takes no horizontal move and is recorded in
+// column order (:142-153, early exit :420-430).  Several calls with consecutive column ranges fold to the whole range
+// (run_pass; enumerated for random chunkings by the oracle's orc_selftest_band_class).
+template <bool TB, bool STAGED>
+__device__ __forceinline__ AlignOut sg_band_roll(LDS int *V, LDS int *O, const int S, const Bytes<STAGED> q, const int m,
+                                                 const Bytes<STAGED> r, const int ae, const Costs c, const int trim_side,
+                                                 const int first, const int c_lo, const int c_hi, const int kbb) {
+    AlignOut res{BDX_INF32, -1, -1};
+    const int H = (c_hi - c_lo + 1) + 2 * kbb;
+    const int d0 = c_lo - m - kbb;  // diagonal (j - i) of slot 0
+    for (int i = 1; i <= m; ++i) {
+        const int qi = q[i - 1];
+        int h_lo = first - 1 - i - d0;  // j >= first - 1
+        h_lo = h_lo < 0 ? 0 : h_lo;
+        int h_hi = c_hi - i - d0;       // j <= c_hi
+        h_hi = h_hi > H - 1 ? H - 1 : h_hi;
+        if (h_lo > h_hi) continue;  // (this row's part of the band lies in front of the window)
+        int left = 0, left_o = 0;                                   // (i, j - 1): the previous slot of this row
+        int cur = V[h_lo * S], cur_o = TB ? O[h_lo * S] : 0;        // (i - 1, j - 1): this slot's old value
+#pragma unroll 4
+        for (int h = h_lo; h <= h_hi; ++h) {
+            const int j = i + d0 + h;
+            int nxt = 0, nxt_o = 0;                                  // (i - 1, j): the next slot's old value
+            if (h + 1 <= H - 1) {
+                nxt = V[(h + 1) * S];
+                if (TB) nxt_o = O[(h + 1) * S];
+            }
+            int nv, no = 0;
+            if (j == first - 1) {  // the reference's initial column
+                nv = c.indel * i;
+                if (TB) no = 1 - i;
+            } else {
+                const int rj = r[j - 1];
+                const int diag = i == 1 ? 0 : cur;
+                int o = i == 1 ? j : cur_o;
+                int b2 = diag + (qi == rj ? c.match : c.mismatch);  // :185
+                if (i == 1 || h + 1 <= H - 1) {  // the deletion input is row 0 or lies in the band
+                    const int del = (i == 1 ? 0 : nxt) + c.indel;  // :184
+                    if (TB) o = b2 < del ? o : (i == 1 ? j : nxt_o);  // :310-316
+                    b2 = b2 < del ? b2 : del;
+                }
+                if (i == m) {  // the last row: no horizontal move; nothing is stored
+                    if (j >= c_lo && b2 <= ae) {  // :417 (the end range does not bind)
+                        if (b2 == 0 && (!TB || trim_side == 5)) return AlignOut{0, TB ? o : -1, j};  // :420-430
+                        if (TB) {  // :142-153
+                            if (b2 < res.raw || (b2 == res.raw && trim_side == 3 && o > res.start)) {
+                                res.raw = b2;
+                                res.start = o;
+                                res.end = j;
+                            }
+                        } else if (b2 < res.raw) {
+                            res.raw = b2;
+                            res.end = j;
+                        }
+                    }
+                    cur = nxt;
+                    cur_o = nxt_o;
+                    continue;
+                }
+                if (h > h_lo) {  // (i, j - 1) lies in the band and not in front of the initial column
+                    const int ins = left + c.indel;  // :183
+                    if (TB) o = ins < b2 ? left_o : o;  // :317-320
+                    b2 = ins < b2 ? ins : b2;
+                }
+                nv = b2;
+                no = o;
+            }
+            if (i != m) {
+                V[h * S] = nv;
+                if (TB) O[h * S] = no;
+            }
+            left = nv;
+            left_o = no;
+            cur = nxt;
+            cur_o = nxt_o;
+        }
+    }
+    return res;
+}
+
 // the read's bytes of the band's columns j0 .. j0 + M + H - 2, as words whose byte k is column j0 + k (bytes in front
 // of the read are never used: clamped addresses)
 template <int NS, bool STAGED>
@@ -1038,6 +1127,43 @@ __device__ __forceinline__ PassOut run_pass(const BdxDevCfg &cfg, const BdxDevPa
                 a = !need_tb ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                     : end_only ? sg_core_clean<false, (REGM > 0 ? REGM : 4), STAGED, true, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi)
                                : sg_core_clean<true, (REGM > 0 ? REGM : 4), STAGED, false, UM>(q, m, r, n, ae, c, trim_side, jf, jl, cjlo, cjhi);
+            } else if (REGM == 0 && CLEAN) {
+                // Barcodes beyond the register DP's 32 rows inside the clean class: the rolling diagonal band (sg_band_roll) over
+                // the end columns the filter handed over — or, without a hand-over (filter off, more entries than a row holds),
+                // over the whole pass window — in chunks of as many end columns as the lane's H cells allow; the chunks are
+                // folded in column order with the recording rule (:142-153) and the early exit on a zero (:420-430).  The budget
+                // of the band is what a recorded alignment can spend at the CURRENT threshold: ae / min(mismatch, indel)
+                // operations (the threshold only tightens, so the planned H — two budgets at the initial rate + 9 — always
+                // leaves room for at least nine end columns per chunk).
+                const int pidx = (&P == &cfg.pass[1]) ? 1 : 0;
+                const int cmin = c.mismatch < c.indel ? c.mismatch : c.indel;
+                const int kbb = ae / cmin;
+                int e_lo = jf, e_hi = jl;
+                if (cjhi < 0x40000000) {
+                    // (uniform budgets: the first end column itself; else the restricted run's first column — a superset)
+                    const int lo_e = cfg.band_kb[pidx] >= 0 ? cjlo + cfg.band_lb[pidx] : cjlo;
+                    e_lo = lo_e > e_lo ? lo_e : e_lo;
+                    e_hi = cjhi < e_hi ? cjhi : e_hi;
+                }
+                a = AlignOut{BDX_INF32, -1, -1};
+                const int wc = cfg.band_hcap - 2 * kbb;
+                if (m > 0 && n > 0 && wc >= 1) {
+                    const bool end_only = need_tb && trim_side == 5 && !cfg.need_traceback && cfg.end_only_ok;
+                    const bool tbf = need_tb && !end_only;
+                    for (int clo = e_lo; clo <= e_hi; clo += wc) {
+                        const int chi = clo + wc - 1 < e_hi ? clo + wc - 1 : e_hi;
+                        const AlignOut x = tbf ? sg_band_roll<true, STAGED>(DP, OG, S, q, m, r, ae, c, trim_side, jf, clo, chi, kbb)
+                                               : sg_band_roll<false, STAGED>(DP, OG, S, q, m, r, ae, c, trim_side, jf, clo, chi, kbb);
+                        if (x.raw >= BDX_INF32) continue;
+                        if (x.raw == 0 && (!tbf || trim_side == 5)) {  // the walk ends at the first zero
+                            a = x;
+                            break;
+                        }
+                        if (tbf ? (x.raw < a.raw || (x.raw == a.raw && trim_side == 3 && x.start > a.start)) : x.raw < a.raw) a = x;
+                    }
+                    if (!need_tb) a.end = -1;
+                    if (end_only) a.start = -1;
+                }
             } else if (REGM > 0) {
                 // With trim_side == 5 and nobody asking for the start position, the alignment's END is all that is
                 // observable (keep_start = end + 1, :914): the origin half of the DP is dropped.  Same values, same

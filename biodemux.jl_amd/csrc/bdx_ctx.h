@@ -124,6 +124,7 @@ struct bdx_ctx {
     int tier_cap_fixed = -1; // >= 0: the pairs tier — tier 1's budgets are capped at this many operations for every barcode and its
                              // filter is the same-diagonal pairs mode over the whole batch (configs whose min_delta the seed tier cannot prove)
     int pairs_tier = 0;
+    bool band_roll_off = false;      // bdx_create: the config has no filter (no hand-over windows) — the exact kernel keeps its by-construction LDS form
     int scratch_par = 0;             // which half of the scratch block the next classify call uses
     bool scratch_clean[2] = {false, false};  // that half is known to hold zeros (cleared by the previous call's last launch)
     bool scratch_zeroed = false;  // the small-batch copy kernel has already cleared the filter kernels' scratch words

@@ -410,6 +410,9 @@ hipError_t bdx_generic_set_lds_limit(size_t bytes) {
     if ((e = generic_attr<256, 0>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<128, 0>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<64, 0>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<256, 0, true>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<128, 0, true>(bytes)) != hipSuccess) return e;
+    if ((e = generic_attr<64, 0, true>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<256, 24>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<256, 32>(bytes)) != hipSuccess) return e;
     if ((e = generic_attr<256, 24, true, true>(bytes)) != hipSuccess) return e;
@@ -476,6 +479,20 @@ hipError_t bdx_launch_generic(const BdxDevCfg &cfg, const BdxGenericPlan &plan, 
         hipLaunchKernelGGL((bdx_generic_kernel<256, 24>), grid, block, plan.lds_bytes, stream, a);
     } else if (plan.reg_rows == 32 && plan.threads == 256) {
         hipLaunchKernelGGL((bdx_generic_kernel<256, 32>), grid, block, plan.lds_bytes, stream, a);
+    } else if (plan.band_roll) {  // barcodes beyond 32 rows in the clean class: the rolling diagonal band (sg_band_roll)
+        switch (plan.threads) {
+            case 256:
+                hipLaunchKernelGGL((bdx_generic_kernel<256, 0, true>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            case 128:
+                hipLaunchKernelGGL((bdx_generic_kernel<128, 0, true>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            case 64:
+                hipLaunchKernelGGL((bdx_generic_kernel<64, 0, true>), grid, block, plan.lds_bytes, stream, a);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
     } else {
         switch (plan.threads) {
             case 256:

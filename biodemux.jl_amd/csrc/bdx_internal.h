@@ -64,6 +64,7 @@ struct BdxDevCfg {
     int band_lb[2];
     int dense_w;       // per launch: the column windows are a dense table wins[pass][read][barcode] (lo + 1024 | hi << 16), wcnt = 254
     int band_m;        // the common barcode length the band bodies run with (8, 10, 12, 16, 20, 24 or 32)
+    int band_hcap;     // rolling band (sg_band_roll, barcodes beyond 32 rows in the clean class): diagonals a lane's LDS cells hold; 0: off
     unsigned int *dbg_rejected;  // device counter: hand-over windows the exact kernel refused as "not a window" (must stay 0)
     BdxDevPass pass[2];
 };
@@ -99,6 +100,8 @@ struct BdxGenericPlan {
     int clean;           // register DP in its clean-class form (sg_core_clean): in-domain costs, start / end ranges "1:end"
     int uniform_m;       //   ... and every barcode has exactly reg_rows rows
     int uniform_len;     //   ... every barcode of the config has this length and band bodies exist for it (else 0)
+    int band_roll;       // barcodes beyond 32 rows inside the clean class: the exact DP is the rolling diagonal band (sg_band_roll), dp_rows = its H + 1
+    int same_len;        // every barcode of the config has the same length (the filter's first end column can be rebuilt from a hand-over row)
     int dp_rows;         // generic kernel: max_m + 1, or 1 in register mode
     int dp_rows_fused;   // fused kernel's in-kernel exact stage always keeps LDS columns: max_m + 1
     int stage_bytes;     // LDS bytes reserved for staged read bytes (0 = read from HBM/L2 directly)

@@ -1398,6 +1398,95 @@ static orc_align_t band_dp(const uint8_t *q0, int64_t m, const uint8_t *r0, int6
     return finalize_result(output_mode, result, norm);
 }
 
+/* ---- model of the HIP "rolling band" DP (csrc/bdx_core.h sg_band_roll), test-only -----------------------------------
+ * The same band as band_dp — the diagonals  j - i  in  [c_lo - m - kb, c_hi - m + kb]  of the alignments that end in row m
+ * at a column of [c_lo, c_hi] — walked ROW BY ROW in place over H = (c_hi - c_lo + 1) + 2 kb cells per array (slot h = diagonal
+ * d0 + h): what a barcode of ANY length needs per lane.  The kernel's operations in the kernel's order; the slots start out
+ * holding junk (whatever the previous candidate left there) to show that no cell is read before it is written. */
+static orc_align_t band_dp_roll(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n, double max_error, int64_t match,
+                                int64_t mismatch, int64_t indel, int32_t output_mode, int32_t trim_side, int64_t first,
+                                int64_t last, int64_t norm, int64_t c_lo, int64_t c_hi, int64_t kb, uint64_t junk) {
+    const int tb = output_mode == ORC_OUT_TRACEBACK;
+    res_t result = init_result();
+    if (m == 0 || n == 0) return finalize_result(output_mode, result, norm);
+    const int64_t ae = (int64_t)floor(max_error * (double)norm);
+    if (first < 1) first = 1;
+    if (last > n) last = n;
+    if (c_lo < first) c_lo = first;
+    if (c_hi > last) c_hi = last;
+    if (c_lo > c_hi) return finalize_result(output_mode, result, norm);
+    const int64_t H = (c_hi - c_lo + 1) + 2 * kb, d0 = c_lo - m - kb;
+    int64_t V[600], O[600];
+    if (H > 600) return finalize_result(output_mode, result, norm);
+    for (int64_t h = 0; h < H; h++) {
+        junk = junk * 6364136223846793005ULL + 1442695040888963407ULL;
+        V[h] = (int64_t)((junk >> 33) % 7) - 3; /* small values: a stale cell that WAS read would win a comparison */
+        O[h] = (int64_t)((junk >> 40) % 400) - 100;
+    }
+    for (int64_t i = 1; i <= m; i++) {
+        const int64_t qi = q0[i - 1];
+        int64_t h_lo = first - 1 - i - d0, h_hi = c_hi - i - d0;
+        if (h_lo < 0) h_lo = 0;
+        if (h_hi > H - 1) h_hi = H - 1;
+        if (h_lo > h_hi) continue;
+        int64_t left = 0, left_o = 0, cur = V[h_lo], cur_o = O[h_lo];
+        for (int64_t h = h_lo; h <= h_hi; h++) {
+            const int64_t j = i + d0 + h;
+            int64_t nxt = 0, nxt_o = 0;
+            if (h + 1 <= H - 1) {
+                nxt = V[h + 1];
+                nxt_o = O[h + 1];
+            }
+            int64_t nv, no = 0;
+            if (j == first - 1) { /* the reference's initial column (:278-283) */
+                nv = indel * i;
+                no = 1 - i;
+            } else {
+                const int64_t diag = i == 1 ? 0 : cur;
+                int64_t o = i == 1 ? j : cur_o;
+                int64_t b2 = diag + (qi == r0[j - 1] ? match : mismatch);
+                if (i == 1 || h + 1 <= H - 1) {
+                    const int64_t del = (i == 1 ? 0 : nxt) + indel;
+                    o = b2 < del ? o : (i == 1 ? j : nxt_o);
+                    b2 = b2 < del ? b2 : del;
+                }
+                if (i == m) {
+                    if (j >= c_lo && b2 <= ae) {
+                        if (b2 == 0 && (!tb || trim_side == 5)) {
+                            result.score = 0;
+                            if (tb) {
+                                result.start = o;
+                                result.end = j;
+                            }
+                            return finalize_result(output_mode, result, norm);
+                        }
+                        result = tb ? update_result_traceback(trim_side, result, b2, j, o) : update_result_scoreonly(result, b2);
+                    }
+                    cur = nxt;
+                    cur_o = nxt_o;
+                    continue;
+                }
+                if (h > h_lo) {
+                    const int64_t ins = left + indel;
+                    o = ins < b2 ? left_o : o;
+                    b2 = ins < b2 ? ins : b2;
+                }
+                nv = b2;
+                no = o;
+            }
+            if (i != m) {
+                V[h] = nv;
+                O[h] = no;
+            }
+            left = nv;
+            left_o = no;
+            cur = nxt;
+            cur_o = nxt_o;
+        }
+    }
+    return finalize_result(output_mode, result, norm);
+}
+
 int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad /* 8 ints or NULL; no mismatch: [1..3] = cases compared exactly, of those with traceback, of those with the band crossing the first column */) {
     int64_t n_exact = 0, n_tb = 0, n_edge = 0, n_chunked = 0;
     static const char AL[6] = "ACGTN";
@@ -1476,6 +1565,34 @@ int64_t orc_selftest_band_class(uint64_t seed, int64_t iters, int64_t *first_bad
         int wrong;
         if (full.raw <= ops_bound) wrong = got.raw != full.raw || (mode && (got.end != full.end || got.start != full.start));
         else wrong = got.raw <= ops_bound; /* beyond the budget: anything, but never a value inside it */
+        {
+            /* the rolling form of the same band (sg_band_roll): whole range, and folded over chunks of end columns */
+            orc_align_t gr = band_dp_roll(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, e_lo, e_hi, kb, st_next(&s));
+            if ((st_next(&s) % 2) == 0) {
+                const int64_t cw = 1 + (int64_t)(st_next(&s) % (uint64_t)(e_hi - e_lo + 1));
+                const int tb = mode == ORC_OUT_TRACEBACK;
+                orc_align_t acc = {INFINITY, INF_INT, -1, -1};
+                int have = 0;
+                for (int64_t c_lo = e_lo; c_lo <= e_hi; c_lo += cw) {
+                    const int64_t c_hi = c_lo + cw - 1 < e_hi ? c_lo + cw - 1 : e_hi;
+                    orc_align_t part = band_dp_roll(q, m, r, n, used, match, mismatch, indel, mode, trim, first, last, m, c_lo, c_hi, kb, st_next(&s));
+                    if (part.raw >= INF_INT) continue;
+                    if (part.raw == 0 && (!tb || trim == 5)) {
+                        acc = part;
+                        have = 1;
+                        break;
+                    }
+                    if (!have || part.raw < acc.raw || (part.raw == acc.raw && tb && trim == 3 && part.start > acc.start)) {
+                        acc = part;
+                        have = 1;
+                    }
+                }
+                if (have) gr = acc;
+                else gr.raw = INF_INT, gr.start = -1, gr.end = -1;
+            }
+            if (full.raw <= ops_bound) wrong = wrong || gr.raw != full.raw || (mode && (gr.end != full.end || gr.start != full.start));
+            else wrong = wrong || gr.raw <= ops_bound;
+        }
         n_exact += full.raw <= ops_bound;
         n_tb += full.raw <= ops_bound && mode;
         n_edge += full.raw <= ops_bound && e_hi + kb - (m + H - 2) < first; /* the band crosses the window's first column */

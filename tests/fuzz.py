@@ -191,29 +191,31 @@ def random_case_tiers(seed: int, n_reads: int = 1500):
     return cfg, seq, off
 
 
-def random_case_band(seed: int, n_reads: int = 1500):
+def random_case_band(seed: int, n_reads: int = 1500, m_choices=None, read_lens=None, mixed: bool = False):
     """The diagonal-band DP's domain (exact stage, clean class, every barcode of the config with the same 8, 10, 12, 16,
     20, 24 or 32 bases):
     traceback through trimming or summary, or weighted costs; budgets 0..4 and beyond (fallback), tiers, column
     windows that start inside the read, barcodes hanging over either end of the read, concatemers, low-complexity
     barcodes (wide end-column windows: the 17-diagonal body or the all-rows fallback), dual."""
     rng = np.random.Generator(np.random.PCG64(seed ^ 0xBA9D))
-    m = int([24, 24, 24, 32, 32, 8, 10, 12, 16, 20][int(rng.integers(0, 10))])
-    B = int(rng.integers(8, 140))
+    mc = m_choices or [24, 24, 24, 32, 32, 8, 10, 12, 16, 20]
+    m = int(mc[int(rng.integers(0, len(mc)))])
+    m_lo = max(33, m - int(rng.integers(1, 30))) if (mixed and m > 34 and rng.random() < 0.4) else m  # (long barcodes: sometimes mixed lengths)
+    B = int(rng.integers(8, 140 if m_choices is None else 60))
     lowc = rng.random() < 0.15
     if lowc:
-        bcs = ["".join("AC"[int(x)] for x in rng.integers(0, 2, size=m)) for _ in range(B)]
+        bcs = ["".join("AC"[int(x)] for x in rng.integers(0, 2, size=int(rng.integers(m_lo, m + 1)))) for _ in range(B)]
         bcs = list(dict.fromkeys(bcs))
     else:
-        bcs = _rand_barcodes(rng, B, m, m, False)
+        bcs = _rand_barcodes(rng, B, m_lo, m, False)
     dual = rng.random() < 0.3
-    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 48)), m, m, False) if dual else []
+    bcs2 = _rand_barcodes(rng, int(rng.integers(8, 48)), m_lo, m, False) if dual else []
     unit = rng.random() < 0.6
     trim = [None, 3, 3, 5, 5][int(rng.integers(0, 5))]
     summary = bool(rng.random() < (0.6 if trim is None and unit else 0.15))
     rngs = ["1:end"] * 5 + ["5:end-3", "1:120", "20:end", "end-90:end"]
     kw = dict(
-        bc_seqs=bcs, bc_lengths_no_N=[m] * len(bcs), ids=[f"a{i}" for i in range(len(bcs))],
+        bc_seqs=bcs, bc_lengths_no_N=[len(b) for b in bcs], ids=[f"a{i}" for i in range(len(bcs))],
         max_error_rate=float([0.05, 0.1, 0.1, 0.13, 0.17, 0.2, 0.2, 0.25][int(rng.integers(0, 8))]),
         min_delta=float([0.0, 0.0, 0.05, 0.1][int(rng.integers(0, 4))]),
         match=0, mismatch=1 if unit else int(rng.integers(1, 4)), indel=1 if unit else int(rng.integers(1, 4)),
@@ -221,10 +223,11 @@ def random_case_band(seed: int, n_reads: int = 1500):
         trim_side=trim, summary=summary,
     )
     if dual:
-        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[m] * len(bcs2), ids2=[f"b{i}" for i in range(len(bcs2))],
+        kw.update(is_dual=True, bc_seqs2=bcs2, bc_lengths_no_N2=[len(b) for b in bcs2], ids2=[f"b{i}" for i in range(len(bcs2))],
                   trim_side2=[None, 3, 5][int(rng.integers(0, 3))])
     cfg = H.bdx.DemuxConfig(**kw)
-    max_len = int([60, 100, 150, 150, 200][int(rng.integers(0, 5))])
+    rl = read_lens or [60, 100, 150, 150, 200]
+    max_len = int(rl[int(rng.integers(0, len(rl)))])
     second = (bcs2, max_len // 2, None) if dual else None
     repeat = dict(frac=0.3) if rng.random() < 0.3 else None
     err = float([0.0, 0.02, 0.04, 0.07][int(rng.integers(0, 4))])
@@ -237,12 +240,20 @@ def random_case_band(seed: int, n_reads: int = 1500):
         n = int(off[i + 1] - off[i])
         b = np.frombuffer(bcs[int(rng.integers(0, len(bcs)))].encode(), dtype=np.uint8)
         cut = int(rng.integers(1, 5))
-        if n >= m:
+        mb = len(b)
+        if n >= mb:
             if i % 2:
-                seq[off[i]: off[i] + m - cut] = b[cut:]
+                seq[off[i]: off[i] + mb - cut] = b[cut:]
             else:
-                seq[off[i + 1] - (m - cut): off[i + 1]] = b[:m - cut]
+                seq[off[i + 1] - (mb - cut): off[i + 1]] = b[:mb - cut]
     return cfg, seq, off
+
+
+def random_case_band_long(seed: int, n_reads: int = 600):
+    """The rolling diagonal band's domain (exact stage, clean class, barcodes of 33 .. 128 bases, one length or mixed):
+    the generator above with long barcodes and longer reads."""
+    return random_case_band(seed ^ 0x10C6, n_reads=n_reads, m_choices=[33, 40, 48, 64, 64, 80, 80, 100, 128],
+                            read_lens=[120, 200, 300, 300, 400], mixed=True)
 
 
 def permuted_batch(seq: np.ndarray, off: np.ndarray, seed: int):

@@ -1267,3 +1267,26 @@ def test_large_result_downloads_all_forms(monkeypatch):
                     # page-locked destinations take the direct copies
                     assert hc.staged_downloads - before == (2 if "BDX_NO_STAGED_DOWNLOAD" not in env else 0), (env, hc.staged_downloads - before)
                 assert hc.rejected_windows == 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_band_roll_vs_oracle(seed, monkeypatch):
+    """Barcodes of 33 .. 128 bases inside the clean class (trimming, summary, weighted costs): the exact stage is the rolling
+    diagonal band (sg_band_roll) over the filter's end columns — or, filter off, over the whole window in chunks.  Against the
+    oracle with and without it (BDX_NO_BAND_ROLL: the by-construction LDS form), filter auto and off; column windows that start
+    inside the read, barcodes over the read's ends, concatemers, low-complexity barcodes, mixed lengths, dual."""
+    cfg, seq, off = fuzz.random_case_band_long(7100 + seed)
+    oc = H.orc.OracleClassifier(cfg, nthreads=16)
+    exp = oc.classify(seq, off)
+    for roll in (True, False):
+        if roll:
+            monkeypatch.delenv("BDX_NO_BAND_ROLL", raising=False)
+        else:
+            monkeypatch.setenv("BDX_NO_BAND_ROLL", "1")
+        for flt in ("auto", "off"):
+            with H.bdx.HipClassifier(cfg, want_pass=True, filter=flt) as hc:
+                got = hc.classify(seq, off)
+                fuzz.assert_same(got, exp, f"seed {seed} roll {roll} filter {flt} [{hc.kernel_path}]")
+                assert np.array_equal(hc.counts, oc.counts), (seed, roll, flt)
+                assert hc.rejected_windows == 0
+    monkeypatch.delenv("BDX_NO_BAND_ROLL", raising=False)

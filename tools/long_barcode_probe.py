@@ -10,11 +10,11 @@ import bdx_oracle as orc
 from biodemux_jl_amd import synth
 dev = torch.device("cuda:0"); torch.cuda.is_available()
 n = int(os.environ.get("N", "500000"))
-for m, kw in ((24, {}), (24, {}), (48, {}), (64, {}), (80, {}), (128, {}), (80, dict(trim_side=3)), (160, {})):
+for m, kw in ((24, {}), (24, {}), (48, {}), (64, {}), (80, {}), (128, {}), (48, dict(trim_side=5)), (64, dict(trim_side=3)), (80, dict(trim_side=3)), (128, dict(trim_side=3)), (80, dict(trim_side=5, max_error_rate=0.2)), (160, {})):
     nn = n if m <= 128 else 20000
     bcs = synth.make_barcodes(48, 24, seed=7, lengths=[m] * 48, min_hamming=10)
     seq, off, _ = synth.make_reads(bcs, nn, 300, seed=8)
-    cfg = bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[m] * 48, ids=[str(i) for i in range(48)], max_error_rate=0.1, **kw)
+    cfg = bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[m] * 48, ids=[str(i) for i in range(48)], **{**dict(max_error_rate=0.1), **kw})
     d_seq = torch.from_numpy(seq).to(dev); d_off = torch.from_numpy(off).to(dev)
     outs = {k: torch.empty(nn, dtype=torch.int32, device=dev) for k in ("bc1", "keep_start", "keep_end")}
     with bdx.HipClassifier(cfg) as hc:
