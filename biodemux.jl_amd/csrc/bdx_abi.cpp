@@ -160,7 +160,7 @@ int plan_generic(bdx_ctx *ctx) {
             }
             // (what the workgroup keeps in LDS besides the cells — barcode bytes and tables, the counter histogram — as below)
             const size_t other = (bc_bytes <= 32 * 1024 ? bc_bytes : 0) + (size_t)nb * 8 + (size_t)(d.n_counts <= 2048 ? d.n_counts : 2048) * 4 + 256;
-            const size_t room = other + 2048 < (size_t)78 * 1024 ? (size_t)78 * 1024 - other - 2048 : 0;
+            const size_t room = other + 2048 < (size_t)76 * 1024 ? (size_t)76 * 1024 - other - 2048 : 0;
             const int fit2 = (int)(room / (256 * (d.any_traceback ? 8 : 4))) - 1;  // cells per lane of a workgroup that shares the CU with another one
             const int want = 4 * kb_max + 9;
             const int roomy = want < fit2 ? want : fit2;
@@ -189,7 +189,9 @@ int plan_generic(bdx_ctx *ctx) {
         p.threads = t;
         // Read staging: aim for two resident workgroups per CU (<= 80 KiB each) when that
         // still leaves room for ~192 B per read; otherwise take what is left of the CU.
-        const size_t share = 80 * 1024;  // two workgroups per CU (the exact kernels are compiled for two waves per SIMD)
+        // two workgroups per CU (the exact kernels are compiled for two waves per SIMD); the rolling band keeps clear of the last
+        // granules (measured on the fused kernel: three workgroups of 54 128 B do not share a CU, three of 51 872 B do)
+        const size_t share = p.band_roll ? 77 * 1024 : 80 * 1024;
         size_t budget = need < share ? share - need : 0;
         // (the rolling band is bound by the latency of its LDS chain: resident waves first — two workgroups per CU with whatever
         // staging still fits, reads that do not fit come straight from L2)

@@ -502,88 +502,106 @@ __device__ __attribute__((noinline)) AlignOut sg_core_band(const bdx_u32x4 qa, c
 // Rolling form of the diagonal band for barcodes of ANY length: the same cells, the same recurrence and
 // the same recording rule as sg_core_band — alignments of at most kbb operations that end in row m at a column of
 // [c_lo, c_hi] only touch the H = (c_hi - c_lo + 1) + 2 kbb diagonals  j - i  in  [c_lo - m - kbb, c_hi - m + kbb]  —
-// walked ROW BY ROW: slot h of V / O holds the cell of the previous row on diagonal d0 + h while row i is computed in
-// place (the substitution input is the slot's old value, the deletion input the next slot's old value, the insertion input
-// the previous slot's new one), so a lane needs H cells however long the barcode is — against the m + 1 rows per lane of
-// sg_core, which leave a 128-lane workgroup per CU for barcodes of 80 nt.  Cells outside the band are not read; row 0 is
-// 0 with origin j (:288, :308); a cell in the column in front of the pass window holds the reference's initial column
-// (indel * i, origin 1 - i, :278-283), cells further left are never read; columns beyond c_hi are not computed (nothing a
-// recording at or before c_hi depends on lies to its right).  The last row takes no horizontal move and is recorded in
-// column order (:142-153, early exit :420-430).  Several calls with consecutive column ranges fold to the whole range
-// (run_pass; enumerated for random chunkings by the oracle's orc_selftest_band_class).
+// walked column by column like the reference (:287) over a ROLLING window of rows: at column j the band holds the H rows
+// j - dtop .. j - d0, row i lives in slot i mod H of V / O (the row that enters the band at a column takes the slot of the
+// row that left it), so a lane needs H cells however long the barcode is — against the m + 1 rows per lane of sg_core,
+// which leave a 128-lane workgroup per CU for barcodes of 80 nt.  One read byte per column (fetched a column ahead), the
+// barcode's bytes from the staged table.  Cells outside the band are not read; row 0 is 0 with origin j (:288, :308); when
+// the walk starts at the first column of the pass window the rows the band held one column earlier take the reference's
+// initial column (indel * i, origin 1 - i, :278-283); columns beyond c_hi are not computed (nothing a recording at or before
+// c_hi depends on lies to its right).  The last row takes no horizontal move and is recorded in column order (:142-153,
+// early exit :420-430).  Several calls with consecutive column ranges fold to the whole range (run_pass; enumerated for
+// random chunkings by the oracle's orc_selftest_band_class, model band_dp_roll).
+// (First version, measured: the same band ROW by row — one read byte per CELL, fetched from L2 when the workgroup's reads do
+// not fit its staging area: 4.4 ms instead of the exact kernel's 29 ms for 500 k reads x 48 barcodes of 80 nt, but ~450
+// cycles per cell.  Also measured: value and origin of a cell as ONE 64-bit LDS word — no gain, the LDS instruction count is not
+// what bounds the walk.)
 template <bool TB, bool STAGED>
 __device__ __forceinline__ AlignOut sg_band_roll(LDS int *V, LDS int *O, const int S, const Bytes<STAGED> q, const int m,
                                                  const Bytes<STAGED> r, const int ae, const Costs c, const int trim_side,
                                                  const int first, const int c_lo, const int c_hi, const int kbb) {
     AlignOut res{BDX_INF32, -1, -1};
     const int H = (c_hi - c_lo + 1) + 2 * kbb;
-    const int d0 = c_lo - m - kbb;  // diagonal (j - i) of slot 0
-    for (int i = 1; i <= m; ++i) {
-        const int qi = q[i - 1];
-        int h_lo = first - 1 - i - d0;  // j >= first - 1
-        h_lo = h_lo < 0 ? 0 : h_lo;
-        int h_hi = c_hi - i - d0;       // j <= c_hi
-        h_hi = h_hi > H - 1 ? H - 1 : h_hi;
-        if (h_lo > h_hi) continue;  // (this row's part of the band lies in front of the window)
-        int left = 0, left_o = 0;                                   // (i, j - 1): the previous slot of this row
-        int cur = V[h_lo * S], cur_o = TB ? O[h_lo * S] : 0;        // (i - 1, j - 1): this slot's old value
-#pragma unroll 4
-        for (int h = h_lo; h <= h_hi; ++h) {
-            const int j = i + d0 + h;
-            int nxt = 0, nxt_o = 0;                                  // (i - 1, j): the next slot's old value
-            if (h + 1 <= H - 1) {
-                nxt = V[(h + 1) * S];
-                if (TB) nxt_o = O[(h + 1) * S];
+    const int d0 = c_lo - m - kbb, dtop = d0 + H - 1;  // lowest / highest diagonal (j - i) of the band
+    int j = d0 + 1 > first ? d0 + 1 : first;           // the first column at which the band holds a row >= 1 inside the window
+    if (j > c_hi) return res;
+    if (j == first) {  // the reference's initial column on the rows the band held one column earlier
+        int ia = first - 1 - dtop, ib = first - 1 - d0;
+        ia = ia < 1 ? 1 : ia;
+        ib = ib > m ? m : ib;
+        if (ia <= ib) {
+            int s = ia % H;
+            for (int i = ia; i <= ib; ++i) {
+                V[s * S] = c.indel * i;
+                if (TB) O[s * S] = 1 - i;
+                s = s + 1 == H ? 0 : s + 1;
             }
-            int nv, no = 0;
-            if (j == first - 1) {  // the reference's initial column
-                nv = c.indel * i;
-                if (TB) no = 1 - i;
-            } else {
-                const int rj = r[j - 1];
-                const int diag = i == 1 ? 0 : cur;
-                int o = i == 1 ? j : cur_o;
-                int b2 = diag + (qi == rj ? c.match : c.mismatch);  // :185
-                if (i == 1 || h + 1 <= H - 1) {  // the deletion input is row 0 or lies in the band
-                    const int del = (i == 1 ? 0 : nxt) + c.indel;  // :184
-                    if (TB) o = b2 < del ? o : (i == 1 ? j : nxt_o);  // :310-316
-                    b2 = b2 < del ? b2 : del;
-                }
-                if (i == m) {  // the last row: no horizontal move; nothing is stored
-                    if (j >= c_lo && b2 <= ae) {  // :417 (the end range does not bind)
-                        if (b2 == 0 && (!TB || trim_side == 5)) return AlignOut{0, TB ? o : -1, j};  // :420-430
-                        if (TB) {  // :142-153
-                            if (b2 < res.raw || (b2 == res.raw && trim_side == 3 && o > res.start)) {
-                                res.raw = b2;
-                                res.start = o;
-                                res.end = j;
-                            }
-                        } else if (b2 < res.raw) {
-                            res.raw = b2;
-                            res.end = j;
-                        }
-                    }
-                    cur = nxt;
-                    cur_o = nxt_o;
-                    continue;
-                }
-                if (h > h_lo) {  // (i, j - 1) lies in the band and not in front of the initial column
-                    const int ins = left + c.indel;  // :183
-                    if (TB) o = ins < b2 ? left_o : o;  // :317-320
-                    b2 = ins < b2 ? ins : b2;
-                }
-                nv = b2;
-                no = o;
-            }
-            if (i != m) {
-                V[h * S] = nv;
-                if (TB) O[h * S] = no;
-            }
-            left = nv;
-            left_o = no;
-            cur = nxt;
-            cur_o = nxt_o;
         }
+    }
+    int lo = j - dtop;
+    lo = lo < 1 ? 1 : lo;
+    int s_lo = lo % H;  // slot of row lo (kept up to date as lo moves down the barcode)
+    int rj = r[j - 1];
+    for (; j <= c_hi; ++j) {
+        const int rj_next = j < c_hi ? r[j] : 0;
+        const int rb = j - d0;  // the row that enters the band at this column (its left neighbour lies outside)
+        const int hi = rb > m ? m : rb;
+        int prev = 0, prev_o = j, diag = 0, diag_o = j;  // row 0: value 0, origin j (:288, :308)
+        if (lo > 1) {  // (lo - 1, j - 1): the band's top diagonal — its slot is overwritten by the entering row at the END of this column
+            const int sd = s_lo == 0 ? H - 1 : s_lo - 1;
+            diag = V[sd * S];
+            if (TB) diag_o = O[sd * S];
+        }
+        int s = s_lo;
+        int vm = BDX_INF32, om = -1;
+        for (int i = lo; i <= hi; ++i) {
+            const int old = V[s * S];
+            int old_o = 0;
+            if (TB) old_o = O[s * S];
+            const int sub = diag + (q[i - 1] == rj ? c.match : c.mismatch);  // :185
+            int b2 = sub, o = diag_o;
+            if (i > lo || lo == 1) {  // the deletion input lies in the band (or is row 0)
+                const int del = prev + c.indel;  // :184
+                if (TB) o = sub < del ? diag_o : prev_o;  // :310-316
+                b2 = sub < del ? sub : del;
+            }
+            if (i == m) {  // the last row: no horizontal move; its stored value is never read
+                vm = b2;
+                om = o;
+            } else {
+                int nv = b2;
+                if (i != rb) {  // (i, j - 1) lies in the band
+                    const int ins = old + c.indel;  // :183
+                    if (TB) o = ins < b2 ? old_o : o;  // :317-320
+                    nv = ins < b2 ? ins : b2;
+                }
+                V[s * S] = nv;
+                if (TB) O[s * S] = o;
+                prev = nv;
+                prev_o = o;
+            }
+            diag = old;
+            diag_o = old_o;
+            s = s + 1 == H ? 0 : s + 1;
+        }
+        if (hi == m && j >= c_lo && vm <= ae) {  // :417 (the end range does not bind)
+            if (vm == 0 && (!TB || trim_side == 5)) return AlignOut{0, TB ? om : -1, j};  // :420-430
+            if (TB) {  // :142-153
+                if (vm < res.raw || (vm == res.raw && trim_side == 3 && om > res.start)) {
+                    res.raw = vm;
+                    res.start = om;
+                    res.end = j;
+                }
+            } else if (vm < res.raw) {
+                res.raw = vm;
+                res.end = j;
+            }
+        }
+        if (j + 1 - dtop > 1) {  // the top row leaves the band
+            lo += 1;
+            s_lo = s_lo + 1 == H ? 0 : s_lo + 1;
+        }
+        rj = rj_next;
     }
     return res;
 }

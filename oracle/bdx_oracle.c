@@ -1400,9 +1400,11 @@ static orc_align_t band_dp(const uint8_t *q0, int64_t m, const uint8_t *r0, int6
 
 /* ---- model of the HIP "rolling band" DP (csrc/bdx_core.h sg_band_roll), test-only -----------------------------------
  * The same band as band_dp — the diagonals  j - i  in  [c_lo - m - kb, c_hi - m + kb]  of the alignments that end in row m
- * at a column of [c_lo, c_hi] — walked ROW BY ROW in place over H = (c_hi - c_lo + 1) + 2 kb cells per array (slot h = diagonal
- * d0 + h): what a barcode of ANY length needs per lane.  The kernel's operations in the kernel's order; the slots start out
- * holding junk (whatever the previous candidate left there) to show that no cell is read before it is written. */
+ * at a column of [c_lo, c_hi] — walked column by column over a ROLLING window of rows: at column j the band holds the H =
+ * (c_hi - c_lo + 1) + 2 kb rows  j - dtop .. j - d0,  row i lives in slot i mod H (the row that enters the band takes the
+ * slot of the row that left it): what a barcode of ANY length needs per lane.  The kernel's operations in the kernel's order;
+ * the slots start out holding junk (whatever the previous candidate left there) to show that no cell is read before it is
+ * written. */
 static orc_align_t band_dp_roll(const uint8_t *q0, int64_t m, const uint8_t *r0, int64_t n, double max_error, int64_t match,
                                 int64_t mismatch, int64_t indel, int32_t output_mode, int32_t trim_side, int64_t first,
                                 int64_t last, int64_t norm, int64_t c_lo, int64_t c_hi, int64_t kb, uint64_t junk) {
@@ -1415,7 +1417,7 @@ static orc_align_t band_dp_roll(const uint8_t *q0, int64_t m, const uint8_t *r0,
     if (c_lo < first) c_lo = first;
     if (c_hi > last) c_hi = last;
     if (c_lo > c_hi) return finalize_result(output_mode, result, norm);
-    const int64_t H = (c_hi - c_lo + 1) + 2 * kb, d0 = c_lo - m - kb;
+    const int64_t H = (c_hi - c_lo + 1) + 2 * kb, d0 = c_lo - m - kb, dtop = d0 + H - 1;
     int64_t V[600], O[600];
     if (H > 600) return finalize_result(output_mode, result, norm);
     for (int64_t h = 0; h < H; h++) {
@@ -1423,66 +1425,67 @@ static orc_align_t band_dp_roll(const uint8_t *q0, int64_t m, const uint8_t *r0,
         V[h] = (int64_t)((junk >> 33) % 7) - 3; /* small values: a stale cell that WAS read would win a comparison */
         O[h] = (int64_t)((junk >> 40) % 400) - 100;
     }
-    for (int64_t i = 1; i <= m; i++) {
-        const int64_t qi = q0[i - 1];
-        int64_t h_lo = first - 1 - i - d0, h_hi = c_hi - i - d0;
-        if (h_lo < 0) h_lo = 0;
-        if (h_hi > H - 1) h_hi = H - 1;
-        if (h_lo > h_hi) continue;
-        int64_t left = 0, left_o = 0, cur = V[h_lo], cur_o = O[h_lo];
-        for (int64_t h = h_lo; h <= h_hi; h++) {
-            const int64_t j = i + d0 + h;
-            int64_t nxt = 0, nxt_o = 0;
-            if (h + 1 <= H - 1) {
-                nxt = V[h + 1];
-                nxt_o = O[h + 1];
-            }
-            int64_t nv, no = 0;
-            if (j == first - 1) { /* the reference's initial column (:278-283) */
-                nv = indel * i;
-                no = 1 - i;
-            } else {
-                const int64_t diag = i == 1 ? 0 : cur;
-                int64_t o = i == 1 ? j : cur_o;
-                int64_t b2 = diag + (qi == r0[j - 1] ? match : mismatch);
-                if (i == 1 || h + 1 <= H - 1) {
-                    const int64_t del = (i == 1 ? 0 : nxt) + indel;
-                    o = b2 < del ? o : (i == 1 ? j : nxt_o);
-                    b2 = b2 < del ? b2 : del;
-                }
-                if (i == m) {
-                    if (j >= c_lo && b2 <= ae) {
-                        if (b2 == 0 && (!tb || trim_side == 5)) {
-                            result.score = 0;
-                            if (tb) {
-                                result.start = o;
-                                result.end = j;
-                            }
-                            return finalize_result(output_mode, result, norm);
-                        }
-                        result = tb ? update_result_traceback(trim_side, result, b2, j, o) : update_result_scoreonly(result, b2);
-                    }
-                    cur = nxt;
-                    cur_o = nxt_o;
-                    continue;
-                }
-                if (h > h_lo) {
-                    const int64_t ins = left + indel;
-                    o = ins < b2 ? left_o : o;
-                    b2 = ins < b2 ? ins : b2;
-                }
-                nv = b2;
-                no = o;
-            }
-            if (i != m) {
-                V[h] = nv;
-                O[h] = no;
-            }
-            left = nv;
-            left_o = no;
-            cur = nxt;
-            cur_o = nxt_o;
+    int64_t j = d0 + 1 > first ? d0 + 1 : first;
+    if (j > c_hi) return finalize_result(output_mode, result, norm);
+    if (j == first) { /* the reference's initial column (:278-283) on the rows the band held one column earlier */
+        int64_t ia = first - 1 - dtop, ib = first - 1 - d0;
+        if (ia < 1) ia = 1;
+        if (ib > m) ib = m;
+        for (int64_t i = ia; i <= ib; i++) {
+            V[i % H] = indel * i;
+            O[i % H] = 1 - i;
         }
+    }
+    int64_t lo = j - dtop;
+    if (lo < 1) lo = 1;
+    for (; j <= c_hi; j++) {
+        const int64_t rj = r0[j - 1];
+        const int64_t rb = j - d0, hi = rb > m ? m : rb;
+        int64_t prev = 0, prev_o = j, diag = 0, diag_o = j; /* row 0: value 0, origin j (:288, :308) */
+        if (lo > 1) {
+            diag = V[(lo - 1) % H];
+            diag_o = O[(lo - 1) % H];
+        }
+        int64_t vm = INF_INT, om = -1;
+        for (int64_t i = lo; i <= hi; i++) {
+            const int64_t old = V[i % H], old_o = O[i % H];
+            const int64_t sub = diag + (q0[i - 1] == rj ? match : mismatch);
+            int64_t b2 = sub, o = diag_o;
+            if (i > lo || lo == 1) {
+                const int64_t del = prev + indel;
+                o = sub < del ? diag_o : prev_o;
+                b2 = sub < del ? sub : del;
+            }
+            if (i == m) {
+                vm = b2;
+                om = o;
+            } else {
+                int64_t nv = b2;
+                if (i != rb) {
+                    const int64_t ins = old + indel;
+                    o = ins < b2 ? old_o : o;
+                    nv = ins < b2 ? ins : b2;
+                }
+                V[i % H] = nv;
+                O[i % H] = o;
+                prev = nv;
+                prev_o = o;
+            }
+            diag = old;
+            diag_o = old_o;
+        }
+        if (hi == m && j >= c_lo && vm <= ae) {
+            if (vm == 0 && (!tb || trim_side == 5)) { /* :420-430 */
+                result.score = 0;
+                if (tb) {
+                    result.start = om;
+                    result.end = j;
+                }
+                return finalize_result(output_mode, result, norm);
+            }
+            result = tb ? update_result_traceback(trim_side, result, vm, j, om) : update_result_scoreonly(result, vm);
+        }
+        if (j + 1 - dtop > 1) lo += 1;
     }
     return finalize_result(output_mode, result, norm);
 }

@@ -197,6 +197,25 @@ for seed in range(lo7, hi7):
 print(f"round-4 seeds {lo7}..{hi7 - 1}: paths {paths7}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
 
 
+# barcodes of 33 .. 128 bases inside the clean class: the rolling diagonal band of the exact kernel (sg_band_roll, round 4)
+lo8, hi8 = int(os.environ.get("SEED8_LO", "86000")), int(os.environ.get("SEED8_HI", "86200"))
+paths8 = {}
+t0 = time.time()
+for seed in range(lo8, hi8):
+    cfg, seq, off = fuzz.random_case_band_long(seed)
+    for want in (True, False):
+        exp = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want).classify(seq, off)
+        try:
+            with H.bdx.HipClassifier(cfg, want_pass=want) as hc:
+                got = hc.classify(seq, off)
+                paths8[hc.kernel_path] = paths8.get(hc.kernel_path, 0) + 1
+                fuzz.assert_same(got, exp, f"long-barcode seed {seed} want_pass {want} [{hc.kernel_path}]")
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", e, flush=True)
+print(f"long-barcode seeds {lo8}..{hi8 - 1}: paths {paths8}, {time.time() - t0:.0f} s; mismatches so far {bad}", flush=True)
+
+
 def stress(name, bcs, seq, off, **kw):
     global bad
     cfg = H.bdx.DemuxConfig(bc_seqs=bcs, bc_lengths_no_N=[sum(c != "N" for c in b) for b in bcs],

@@ -15,6 +15,12 @@ if which == "c4":
     cfg = C(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
             bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.2, trim_side=5, trim_side2=3)
     outs = ("bc1", "bc2", "keep_start", "keep_end")
+elif which.startswith("long"):  # CFG=long80: 48 barcodes of 80 nt, 300-base reads, trim_side = 3 (the rolling band's probe shape)
+    m = int(which[4:])
+    bcs = synth.make_barcodes(48, 24, seed=7, lengths=[m] * 48, min_hamming=10)
+    seq, off, _ = synth.make_reads(bcs, n, 300, seed=8)
+    cfg = C(bc_seqs=bcs, bc_lengths_no_N=[m] * 48, ids=[str(i) for i in range(48)], max_error_rate=0.1, trim_side=3)
+    outs = ("bc1", "keep_start", "keep_end")
 else:
     bcs = synth.make_barcodes(96, 24)
     seq, off, _ = synth.make_reads(bcs, n, 150)
