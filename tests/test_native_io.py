@@ -256,3 +256,29 @@ def test_pipeline_errors_propagate_instead_of_hanging(tmp_path, where):
     assert "err" in result, result
     if where == "classify":
         assert "batch 2" in str(result["err"])
+
+
+def test_batch_buffers_are_reused_across_runs(tmp_path):
+    """The pipeline's batch buffers (line tables, packed chunk, verdict vectors) are kept in a process-wide pool between runs:
+    consecutive runs with other inputs, batch sizes, trim settings and read lengths must not see each other's contents
+    (byte-exact against the Python reader / writer every time); `release_buffers()` empties the pool."""
+    from biodemux_jl_amd import nativeio
+    nativeio.release_buffers()
+    bcs = synth.make_barcodes(6, 12, seed=15, min_hamming=4)
+    bc = tmp_path / "bc.csv"
+    bc.write_text("ID,Full_seq,Full_annotation\n" + "".join(f"b{i},{b},{'B' * len(b)}\n" for i, b in enumerate(bcs)))
+    runs = [(900, 20, 90, dict(max_error_rate=0.2, trim_side=5, _batch_reads=128), False),
+            (300, 0, 40, dict(max_error_rate=0.1, _batch_reads=64), True),      # fewer, shorter reads, CRLF: stale tails of every buffer
+            (1500, 60, 150, dict(max_error_rate=0.2, trim_side=3, _batch_reads=500), False),
+            (10, 5, 20, dict(max_error_rate=0.2, _batch_reads=4), False)]
+    for k, (n, lo, hi, kw, crlf) in enumerate(runs):
+        seq, off, _ = synth.make_ragged_reads(bcs, n, lo, hi, seed=20 + k)
+        seqs = [seq[off[i]:off[i + 1]].tobytes() for i in range(n)]
+        fq = str(tmp_path / f"reads{k}.fastq")
+        _fastq(fq, seqs, crlf=crlf)
+        run_py(fq, str(bc), str(tmp_path / f"py{k}"), **kw)
+        run_nat(fq, str(bc), str(tmp_path / f"nat{k}"), **kw)
+        _same_tree(str(tmp_path / f"py{k}"), str(tmp_path / f"nat{k}"))
+        assert 1 <= len(nativeio._BUFFER_POOL) <= nativeio._BUFFER_POOL_MAX
+    nativeio.release_buffers()
+    assert nativeio._BUFFER_POOL == []
