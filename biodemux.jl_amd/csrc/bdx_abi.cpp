@@ -1717,9 +1717,16 @@ static int download_items(bdx_ctx *ctx, const BackItem *items, int n_items) {
     int T = (int)std::thread::hardware_concurrency();
     T = T < 1 ? 1 : (T > 8 ? 8 : T);
     std::atomic<int> failed{0};
+    std::atomic<int> next_slice[10];
+    for (auto &x : next_slice) x.store(0);
     const int dev = ctx->device;
-    auto work = [&](const int t) {
-        if (t > 0 && hipSetDevice(dev) != hipSuccess) failed.store(1);
+    // (every vector is cut into T slices claimed by whoever is there: with fewer helper threads than planned — the host is out
+    // of threads — the caller simply copies more of them itself)
+    auto work = [&](const bool helper) {
+        if (helper && hipSetDevice(dev) != hipSuccess) {
+            failed.store(1);
+            return;
+        }
         for (int k = 0; k < n_items; ++k) {
             if (!(items[k].h && items[k].d && items[k].bytes)) continue;
             if (hipEventSynchronize(ctx->back_events[k]) != hipSuccess) {
@@ -1727,17 +1734,22 @@ static int download_items(bdx_ctx *ctx, const BackItem *items, int n_items) {
                 return;
             }
             const size_t per = ((items[k].bytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
-            const size_t a = per * (size_t)t, b = a + per < items[k].bytes ? a + per : items[k].bytes;
-            if (a < b) memcpy((char *)items[k].h + a, (const char *)ctx->h_back + offs[k] + a, b - a);
+            for (;;) {
+                const int sl = next_slice[k].fetch_add(1);
+                if (sl >= T) break;
+                const size_t a = per * (size_t)sl, b = a + per < items[k].bytes ? a + per : items[k].bytes;
+                if (a < b) memcpy((char *)items[k].h + a, (const char *)ctx->h_back + offs[k] + a, b - a);
+            }
         }
     };
-    try {
+    {
         std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
+        try {
+            for (int t = 1; t < T; ++t) th.emplace_back(work, true);
+        } catch (...) {  // (no more threads to be had: the ones that started and the caller share the slices)
+        }
+        work(false);
         for (auto &x : th) x.join();
-    } catch (...) {
-        return fail(ctx, BDX_E_DEVICE, "out of host resources (threads of the result download)");
     }
     if (failed.load()) return fail(ctx, BDX_E_DEVICE, "device-to-host copy of the results failed");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
