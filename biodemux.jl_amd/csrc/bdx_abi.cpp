@@ -56,6 +56,7 @@ BdxTuning read_tuning() {
     if (const char *e = getenv("BDX_WAVE_WAVES")) t.wave_waves = atoi(e);
     if (const char *e = getenv("BDX_WAVE_MAXRES")) t.wave_maxres = atoi(e);
     t.no_staged_download = getenv("BDX_NO_STAGED_DOWNLOAD") != nullptr;
+    t.no_carry = getenv("BDX_NO_CARRY") != nullptr;
     if (const char *e = getenv("BDX_CU_COUNT")) t.cu_count = atoi(e);
     t.no_clean = getenv("BDX_NO_CLEAN") != nullptr;
     t.no_band = getenv("BDX_NO_BAND") != nullptr;
@@ -2319,6 +2320,7 @@ void bdx_destroy(bdx_ctx *ctx) {
     }
     ctx->d_wlist.release();
     ctx->d_tier.release();
+    ctx->d_carry.release();
     ctx->d_maxlen.release();
     ctx->d_exc.release();
     ctx->d_seq.release();
@@ -2499,7 +2501,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             // (bdx_poison_check_kernel) then looks at exactly the elements the consumer is going to read — an element that
             // still holds the fill was never written: counted (bdx_rejected_windows) and made harmless
             DevBuf *bufs[] = {&ctx->d_cand[0], &ctx->d_cand[1], &ctx->d_wins[0], &ctx->d_wins[1], &ctx->d_wcnt[0], &ctx->d_wcnt[1],
-                              &ctx->d_exc, &ctx->d_tier, &ctx->d_wlist};
+                              &ctx->d_exc, &ctx->d_tier, &ctx->d_wlist, &ctx->d_carry};
             for (DevBuf *b : bufs)
                 if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0xA5, b->cap, ctx->stream));
         }
@@ -2540,11 +2542,11 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         };
         // test switch BDX_POISON: between a producer and its consumer, every element the consumer will read must have
         // been written (bdx_poison_check_kernel); `with_windows`: also the window hand-over of both passes for these reads
-        const auto poison_check = [&](uint32_t *list, const unsigned int *count, bool check_list, bool with_windows) -> hipError_t {
+        const auto poison_check = [&](uint32_t *list, const unsigned int *count, bool check_list, bool with_windows, bool packed = false) -> hipError_t {
             if (!ctx->tune.poison) return hipSuccess;
             unsigned int *dbg = (unsigned int *)ctx->d_dbg.p;
             if (!with_windows || !windows)
-                return list ? bdx_launch_poison_check(list, count, n_reads, nullptr, nullptr, nullptr, 0, 0, check_list ? 1 : 0, dbg, ctx->stream) : hipSuccess;
+                return list ? bdx_launch_poison_check(list, count, n_reads, nullptr, nullptr, nullptr, 0, 0, (check_list ? 1 : 0) | (packed ? 2 : 0), dbg, ctx->stream) : hipSuccess;
             for (int k = 0; k < npass; ++k) {
                 hipError_t e = bdx_launch_poison_check(list, count, n_reads, k ? w1 : w0, k ? n1 : n0, k ? c1 : c0, ctx->dev.pass[k].cand_words,
                                                        ctx->dev.pass[k].n_barcodes, (check_list && k == 0) ? 1 : 0, dbg, ctx->stream);
@@ -2624,6 +2626,23 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_list = (const uint32_t *)ctx->d_wlist.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
+        // Carried passes: tier 1 of a dual known-class config lists a read when ONE of its passes is open; the pass it settled goes
+        // along (two state bits on the list entry + the pass's winning survivor in d_carry[read]) and the pairs mode only looks for
+        // the other pass's barcodes — about half of its sweeps for C4.  Only when the pairs mode in its known form is what reads
+        // tier 1's list (nothing else understands the state bits), reads fit 30 bits and min_delta = 0 (a lone carried winner
+        // then IS the pass's result).
+        bool carry_on = false;
+        for (BdxFilterSet &f : ctx->fs) f.wplan_k.d_carry = f.wplan_a.d_carry = f.pplan_k.d_carry = f.pplan_a.d_carry = nullptr;
+        if (tiered && wave1k && ctx->dev.is_dual && ctx->dev.min_delta == 0.0 && !ctx->tune.no_carry && n_reads < (1LL << 30) && o.pass_start == nullptr &&
+            o.pass_end == nullptr && o.pass_raw == nullptr && o.pass_bc == nullptr && o.pass_score == nullptr && o.pass_delta == nullptr) {
+            BdxWavePlan &pp = aln_ok ? ctx->fs[0].pplan_a : ctx->fs[0].pplan_k;
+            if (size_pairs(ctx, pp, tier_len) && pp.groups <= 1 && pp.pairs_kb <= 4 && !pp.split) {
+                HIP_TRY(ctx, ctx->d_carry.ensure((size_t)n_reads * 4 + 64));
+                carry_on = true;
+                wk1.d_carry = (uint32_t *)ctx->d_carry.p;
+                pp.d_carry = (uint32_t *)ctx->d_carry.p;
+            }
+        }
         if (tiered) {
             HIP_TRY(ctx, ctx->d_tier.ensure((size_t)n_reads * 4 + 64));
             BdxTierArgs t1{1, (uint32_t *)ctx->d_tier.p, (unsigned int *)(scratch + 192), nullptr, nullptr};
@@ -2674,7 +2693,7 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
             t0.in_list = (const uint32_t *)ctx->d_tier.p;
             t0.in_count = (const unsigned int *)(scratch + 192);
         }
-        if (tiered || wave0 || wave0k) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false));
+        if (tiered || wave0 || wave0k) HIP_TRY(ctx, poison_check((uint32_t *)t0.in_list, t0.in_count, true, false, carry_on));
         // Pairs mode of the wave kernel between tier 1 and the general kernel: the listed reads are gathered into slots and
         // filtered at the full budgets by the two-intact-pieces lemma.  Known-score configs: it answers them (what it cannot
         // answer goes on to the general kernel in list mode); split configs: it is tier 0's filter (masks + windows of the

@@ -55,6 +55,7 @@ struct BdxTuning {
     int no_wave = 0;      // BDX_NO_WAVE: never the wave-autonomous kernel (bdx_wave.hip): the general fused kernel answers every read
     int wave_rw = 0;      // BDX_WAVE_RW / BDX_WAVE_WAVES: forced tile size / waves per workgroup of the wave kernel (tuning)
     int wave_waves = 0;
+    int no_carry = 0;     // BDX_NO_CARRY: tier 1 of a dual config hands a listed read on without the pass it settled (the pairs mode evaluates both passes again)
     int no_staged_download = 0;  // BDX_NO_STAGED_DOWNLOAD: large result vectors go back with the runtime's own pageable copies
     int wave_maxres = 0;  // BDX_WAVE_MAXRES: resident waves per compute unit the wave kernel's geometry may plan for (default 16 = four per SIMD: the kernels need 114-128 VGPRs; tuning: the occupancy experiment of DESIGN §4)
     int cu_count = 0;     // BDX_CU_COUNT: pretend the device has this many compute units (tests of the grid sizing)
@@ -96,6 +97,7 @@ struct bdx_ctx {
     BdxTuning tune{};
     DevBuf d_maxlen;
     DevBuf d_tier;      // tiered budgets: reads handed from tier 1 to tier 0
+    DevBuf d_carry;     // dual tiered known-class configs: the winning survivor of the pass tier 1 settled, per listed read (BdxWavePlan::d_carry)
     int user_len_hint = 0;  // 0 = measure every device batch
     int filter_used = BDX_FILTER_OFF;
     int device = 0;

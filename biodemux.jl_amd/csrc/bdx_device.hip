@@ -338,7 +338,10 @@ __global__ void bdx_poison_check_kernel(uint32_t *list, const unsigned int *list
         long long rid = i;
         if (list) {
             uint32_t e = list[i];
-            if (check_list && (e == 0xA5A5A5A5u || (long long)e >= n_reads)) {
+            // (check_list bit 1: the entries carry two state bits above a 30-bit read number — carried passes, bdx_wave.hip)
+            const bool unwritten = e == 0xA5A5A5A5u;
+            if ((check_list & 2) && !unwritten) e &= 0x3FFFFFFFu;
+            if ((check_list & 1) && (unwritten || (long long)e >= n_reads)) {
                 atomicAdd(dbg + 1, 1u);
                 list[i] = 0u;
                 e = 0u;

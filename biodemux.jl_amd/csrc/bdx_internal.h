@@ -174,6 +174,8 @@ struct BdxSeedPlan {
 // Tables are built next to the seed tables of a filter set (bdx_abi.cpp, build_wave_tables); the geometry per batch.
 struct BdxWavePlan {
     int enabled;           // config-level eligibility of this filter set
+    uint32_t *d_carry = nullptr;  // per launch (dual tiered known-class configs, min_delta = 0): tier 1 leaves the winning survivor of the ONE pass it settled
+                                  // for a read it lists here (indexed by read; two state bits ride on the list entry) and the pairs mode takes it over
     int q;                 // seed length (6..8)
     int n_ent;             // seed table entries (one per (key, barcode, piece start))
     int n_barcodes;        // of all passes together (the barcodes of pass 1 are numbered behind those of pass 0)

@@ -69,6 +69,7 @@ struct WaveArgs {
     double tier_slo;
     double tier_slo1;        // ... of pass 1 (dual configs)
     int dual;                // two passes (known-score form: the survivors of pass 1 sit in the candidate-word area)
+    uint32_t *carry_ent;     // dual tiered configs with min_delta = 0 (else null): see BdxWavePlan::d_carry
     uint32_t *list;          // reads this kernel does not answer ...
     unsigned int *list_count;  // ... and how many
     // split mode (trimming / summary / weighted costs: the exact kernel gives every verdict; this kernel only filters):
@@ -338,6 +339,12 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
     const bool ranged = GEN && a.ranged != 0, dual = GEN && a.dual != 0;
     static_assert(!WINM || (!PAIRS && !SPLIT && KEND == 0 && GEN), "window mode: the non-split single-seed kernel");
     constexpr bool SCAT = PAIRS || WINM;  // scattered tiles: every read of a tile is fetched on its own (by list index) into a slot of the images
+    // Carried passes (dual tiered known-class configs with min_delta = 0): tier 1 lists a read when ONE of its passes is open; the pass
+    // it did settle travels with the read — two state bits on the list entry (1: pass 0 settled and matched, 2: pass 1 settled
+    // on its own) and the pass's winning survivor entry in carry_ent[read] — and the pairs mode drops that pass's barcodes from
+    // its flags and replays the carried survivor instead: about half of its sweeps for C4.
+    constexpr bool CARRY = PAIRS && !SPLIT && !MG && KB <= 4;
+    const uint32_t idmask = (CARRY && a.carry_ent != nullptr) ? 0x3FFFFFFFu : 0xFFFFFFFFu;
     const long long n_reads = (SCAT && a.n_dev) ? (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*a.n_dev) : a.n_reads;
 
     // ---- LDS carve-up: shared tables, then one work area per wave ----
@@ -371,10 +378,10 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
     constexpr int O_TN = O_GID + (SCAT ? RW * 4 : 0);        // int[RW]: window mode: the reads' true lengths
     // scattered tiles: slot geometry of this tile and the next (double-buffered: written when a tile's bytes are requested, one
     // tile ahead) — u32x4 {aligned address lo, hi, vectors to fetch | head << 8, length (-1: handed on)}, read number, true length
-    constexpr int O_SG4 = O_TN + (WINM ? RW * 4 : 0);        // u32x4[2][RW]
+    constexpr int O_SG4 = O_TN + ((WINM || PAIRS) ? RW * 4 : 0);  // u32x4[2][RW]   (pairs mode: tn = which pass of the read tier 1 settled, stn = that pass's winning survivor)
     constexpr int O_SGID = O_SG4 + (SCAT ? 2 * RW * 16 : 0); // u32[2][RW]
     constexpr int O_STN = O_SGID + (SCAT ? 2 * RW * 4 : 0);  // int[2][RW] (window mode)
-    constexpr int O_IMG2 = O_STN + (WINM ? 2 * RW * 4 : 0) + (SCAT ? 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (scattered tiles: four guard words in front)
+    constexpr int O_IMG2 = O_STN + ((WINM || PAIRS) ? 2 * RW * 4 : 0) + (SCAT ? 16 : 0);  // u32[nvec_cap + 2]: 2-bit image (scattered tiles: four guard words in front)
     const int nvec_cap = a.span_cap >> 4;
     LDS int *fb = (LDS int *)(wbase + O_FB);
     LDS uint32_t *rid = (LDS uint32_t *)(wbase + O_RID);
@@ -462,7 +469,7 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
         const long long r0 = (long long)t * RW;
         ScatOff so{0, -1};
         if (SCAT && t < ntiles && r0 + lane < n_reads && lane < RW) {
-            const ll2a o = *(const ll2a __attribute__((address_space(1))) *)(a.off + id);
+            const ll2a o = *(const ll2a __attribute__((address_space(1))) *)(a.off + (CARRY ? (id & idmask) : id));
             so.o0 = o[0];
             const long long l = o[1] - o[0];
             so.len = (l >= 0 && l < (1LL << 30)) ? (int)l : -1;
@@ -544,6 +551,7 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
             sg4[par * RW + lane] = u32x4{(uint32_t)sg.abase, (uint32_t)((unsigned long long)sg.abase >> 32), (uint32_t)sg.nv | ((uint32_t)sg.head << 8), (uint32_t)sg.len};
             sgid[par * RW + lane] = id;
             if (WINM) stn[par * RW + lane] = so.len;
+            if (CARRY) stn[par * RW + lane] = (a.carry_ent != nullptr && (id >> 30) != 0u) ? (int)a.carry_ent[id & idmask] : 0;
         }
         WAVE_SYNC();
     };
@@ -619,13 +627,24 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                 const int slen = (int)e[3];
                 fb[lane] = lane * a.slot + (int)(e[2] >> 8);  // the read's first base within the tile's flat images
                 rl[lane] = lane < nr ? slen : 0;              // (-1: longer than its slot — handed on)
-                gid[lane] = sgid[par * RW + lane];
+                gid[lane] = sgid[par * RW + lane] & idmask;
+                if (CARRY) tn[lane] = a.carry_ent != nullptr ? (int)(sgid[par * RW + lane] >> 30) : 0;
                 if (WINM) {
                     tn[lane] = stn[par * RW + lane];
                     if (lane < nr && slen < 0) flag[lane] = 1;  // (not in the known-score class, or a window longer than planned: listed)
                 }
             }
             wcl1[lane] = 0;  // (split mode: window entries of pass 1; known-score dual configs: survivors of pass 1)
+            if (CARRY && lane < nr) {  // a pass tier 1 settled: its winning survivor is the pass's only entry (its barcodes are dropped from the flags below)
+                const int st = tn[lane];
+                if (st == 1) {
+                    slots[lane * 4] = (uint32_t)stn[par * RW + lane];
+                    scnt[lane] = 1;
+                } else if (st == 2) {
+                    cand[lane * 4] = (uint32_t)stn[par * RW + lane];
+                    wcl1[lane] = 1;
+                }
+            }
             if (SPLIT)
                 for (int w = 0; w < cwt; ++w) cand[lane * cwt + w] = 0u;
         }
@@ -1039,6 +1058,17 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                         keys();
                         diagonals(0u);
                     }
+                    if constexpr (CARRY) {
+                        const int st = on ? tn[t] : 0;
+                        if (st) {  // (the run of flagged diagonals may stay wider than the kept barcodes need: a superset)
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                const int blo = 32 * w;
+                                const uint32_t p0 = a.B0 >= blo + 32 ? 0xFFFFFFFFu : (a.B0 <= blo ? 0u : ((1u << (a.B0 - blo)) - 1u));  // barcodes of pass 0 in this word
+                                Fl[w] &= st == 1 ? ~p0 : p0;
+                            }
+                        }
+                    }
                     append(0);
                 } else {
                     // more than 128 barcodes: groups of 128, each with its own piece tables (the keys' addresses are shared)
@@ -1357,6 +1387,7 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
         Verdict vd{0, 0, -1, -1};
         PassOut p1{0, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()}, p2{2, 0, -1, -1, -1, __builtin_inf(), __builtin_inf()};
         bool done = false;
+        uint32_t cst = 0u, centry = 0u;  // tier 1 of a dual config: which pass of a listed read is settled (1 / 2) and its winning survivor
         if (active && tile_ok && hq_ok && !BDX_DBG(1)) {
             const int n = WINM ? tn[lane] : rlen(lane);  // (window mode: the keep range is the whole READ, :907-908)
             const int cnt = scnt[lane], cnt1 = dual ? wcl1[lane] : 0;
@@ -1385,6 +1416,7 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                     vd.bc1 = 0;
                     settled_all = false;  // (nothing within the capped budgets: tier 0 decides)
                 }
+                const bool s1_settled = settled_all;  // pass 0 settled and matched
                 vd.bc2 = 0;
                 if (dual && vd.bc1 > 0) {
                     int bc2v = 0;
@@ -1403,6 +1435,21 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
                     if (bc2v == 0) vd.bc2 = 0;
                 }
                 if (a.tier) done = settled_all;
+                if (!PAIRS && a.tier && dual && a.carry_ent != nullptr && !settled_all) {
+                    // one pass settled, the other open: the settled one travels with the read (see CARRY above)
+                    if (s1_settled) {
+                        cst = 1u;
+                        centry = slots[lane * 4];
+                    } else if (cnt1 == 1) {  // pass 1 on its own (the reducers of a pass do not look at the other pass)
+                        const uint32_t e = cand[lane * 4];
+                        const int bb = KEND ? (int)(e >> 22) : (int)(e >> 8), d = KEND ? (int)((e >> 16) & 63u) : (int)(e & 255u), g = a.B0 + bb;
+                        const int dmax = (int)((meta[g] >> 16) & 255u);
+                        if (dmax != 255 && d <= dmax && ((settle[g] >> (d + sbit)) & 1u) != 0u) {
+                            cst = 2u;
+                            centry = e;
+                        }
+                    }
+                }
                 vd.keep_start = vd.bc1 > 0 ? 1 : -1;  // :907-908 / :879-883 (ScoreOnly: the whole read, n >= 1)
                 vd.keep_end = vd.bc1 > 0 ? n : -1;
                 if (KEND && vd.bc1 > 0) {
@@ -1598,7 +1645,8 @@ __global__ BDX_WAVE_BOUNDS void bdx_wave_kernel(const WaveArgs a) {
             if (mk) {
                 const int n_new = (int)__builtin_popcountll(mk);
                 if (lcnt + n_new > 64) flush_list();
-                if (hand) lbuf[lcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint32_t)ridx;
+                if (hand) lbuf[lcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = (uint32_t)ridx | (cst << 30);
+                if (hand && cst != 0u) a.carry_ent[ridx] = centry;
                 lcnt += n_new;
             }
         }
@@ -1707,6 +1755,7 @@ void fill_args(WaveArgs &a, const BdxDevCfg &cfg, const BdxWavePlan &wp, int his
     a.sq_cap = wp.sq_cap;
     a.list = list;
     a.list_count = list_count;
+    a.carry_ent = wp.d_carry;
     a.dbg = dbg;
     a.B0 = wp.b0;
     for (int k = 0; k < 2; ++k) {
@@ -1857,7 +1906,7 @@ size_t bdx_wave_area_bytes(int rw, int span_cap, bool pairs, int hq_cap, int sq_
     const size_t nvec = (size_t)span_cap >> 4;
     const size_t recs = pairs ? 0 : 2 * (size_t)rw * 8 * 4;  // record tables
     const size_t fixed = (size_t)(((rw + 1) * 4 + 15) / 16 * 16) + recs + (size_t)rw * 16 + 3 * (size_t)rw * 4 + 256 +
-                         ((pairs || winm) ? 2 * (size_t)rw * 4 + 16 + 2 * (size_t)rw * 20 : 0) + (winm ? (size_t)rw * 4 + 2 * (size_t)rw * 4 : 0);
+                         ((pairs || winm) ? 2 * (size_t)rw * 4 + 16 + 2 * (size_t)rw * 20 : 0) + ((winm || pairs) ? (size_t)rw * 4 + 2 * (size_t)rw * 4 : 0);
     const size_t o = fixed + ((nvec + 2 + 3) & ~(size_t)3) * 4 + ((2 * nvec + 6 + 3) & ~(size_t)3) * 4 + ((size_t)hq_cap + (pairs ? 0 : (size_t)sq_cap) + (size_t)rw * (size_t)cand_words) * 4;
     return (o + 31) & ~(size_t)31;
 }

@@ -248,3 +248,35 @@ def test_fuzz_known_trim_vs_oracle(seed):
     with H.bdx.HipClassifier(cfg, want_pass=False) as hc:
         fuzz.assert_same(hc.classify(seq, off), exp, f"seed {seed} [{hc.kernel_path}]")
         assert np.array_equal(hc.counts, oc.counts), f"seed {seed}: counters"
+
+
+@pytest.mark.parametrize("t1,t2", [(5, 3), (3, 5), (5, None), (None, 3), (None, None)])
+def test_dual_carried_pass_vs_oracle(t1, t2, monkeypatch):
+    """Tier 1 of a dual config lists a read when ONE of its passes is open; the pass it settled travels with the read (two state
+    bits on the list entry, the pass's winning survivor beside it) and the pairs mode only looks for the other pass's barcodes.
+    C4's shape and a shape whose second barcode is often missing or damaged, every mix of trim sides incl. none: with and without
+    the carry (BDX_NO_CARRY) the outputs and counters equal the oracle's; per-pass outputs switch the carry off by themselves."""
+    b1 = synth.make_barcodes(24, 24, seed=801)
+    b2 = synth.make_barcodes(16, 24, seed=802)
+    kw = dict(bc_seqs=b1, bc_lengths_no_N=[24] * 24, ids=[f"x{i}" for i in range(24)], is_dual=True, bc_seqs2=b2,
+              bc_lengths_no_N2=[24] * 16, ids2=[f"y{i}" for i in range(16)], max_error_rate=0.2, trim_side=t1, trim_side2=t2)
+    cfg = H.bdx.DemuxConfig(**kw)
+    for seed, sub in ((803, 0.02), (804, 0.07)):  # (at 7 % substitutions many passes need the full budget: both kinds of carried pass occur)
+        seq, off, _ = synth.make_reads(b1, 30000, 150, seed=seed, sub=sub, ins=sub / 4, dele=sub / 4, plant_lo=0, plant_hi=40, second=(b2, 100, 126))
+        for want_pass in (False, True):
+            oc = H.orc.OracleClassifier(cfg, nthreads=16, want_pass=want_pass)
+            exp = oc.classify(seq, off)
+            for carry in (True, False):
+                if carry:
+                    monkeypatch.delenv("BDX_NO_CARRY", raising=False)
+                else:
+                    monkeypatch.setenv("BDX_NO_CARRY", "1")
+                with H.bdx.HipClassifier(cfg, want_pass=want_pass) as hc:
+                    monkeypatch.delenv("BDX_NO_CARRY", raising=False)
+                    for rep in range(2):
+                        got = hc.classify(seq, off)
+                        fuzz.assert_same(got, exp, f"trims {t1}/{t2} sub {sub} want_pass {want_pass} carry {carry} [{hc.kernel_path}]")
+                        if rep == 0:
+                            assert np.array_equal(hc.counts, oc.counts), (t1, t2, sub, want_pass, carry)
+                    assert hc.rejected_windows == 0
+                    assert hc.kernel_path.startswith("tier1:wave"), hc.kernel_path
