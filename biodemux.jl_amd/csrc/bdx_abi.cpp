@@ -2632,14 +2632,18 @@ int32_t bdx_classify_device(bdx_ctx *ctx, const uint8_t *d_seq_bytes, const int6
         // tier 1's list (nothing else understands the state bits), reads fit 30 bits and min_delta = 0 (a lone carried winner
         // then IS the pass's result).
         bool carry_on = false;
-        for (BdxFilterSet &f : ctx->fs) f.wplan_k.d_carry = f.wplan_a.d_carry = f.pplan_k.d_carry = f.pplan_a.d_carry = nullptr;
-        if (tiered && wave1k && ctx->dev.is_dual && ctx->dev.min_delta == 0.0 && !ctx->tune.no_carry && n_reads < (1LL << 30) && o.pass_start == nullptr &&
+        for (BdxFilterSet &f : ctx->fs)
+            f.wplan.d_carry = f.pplan.d_carry = f.wplan_k.d_carry = f.wplan_a.d_carry = f.pplan_k.d_carry = f.pplan_a.d_carry = nullptr;
+        // (the known-trim / known-alignment forms — wave1k — and the plain known-score form of a dual config without trimming — wave1)
+        const bool carry_tier = tiered && (wave1k || (wave1 && !split && !ctx->fs[1].wplan.winm));
+        if (carry_tier && ctx->dev.is_dual && ctx->dev.min_delta == 0.0 && !ctx->tune.no_carry && n_reads < (1LL << 30) && o.pass_start == nullptr &&
             o.pass_end == nullptr && o.pass_raw == nullptr && o.pass_bc == nullptr && o.pass_score == nullptr && o.pass_delta == nullptr) {
-            BdxWavePlan &pp = aln_ok ? ctx->fs[0].pplan_a : ctx->fs[0].pplan_k;
+            BdxWavePlan &pp = wave1k ? (aln_ok ? ctx->fs[0].pplan_a : ctx->fs[0].pplan_k) : ctx->fs[0].pplan;
+            BdxWavePlan &t1p = wave1k ? wk1 : ctx->fs[1].wplan;
             if (size_pairs(ctx, pp, tier_len) && pp.groups <= 1 && pp.pairs_kb <= 4 && !pp.split) {
                 HIP_TRY(ctx, ctx->d_carry.ensure((size_t)n_reads * 4 + 64));
                 carry_on = true;
-                wk1.d_carry = (uint32_t *)ctx->d_carry.p;
+                t1p.d_carry = (uint32_t *)ctx->d_carry.p;
                 pp.d_carry = (uint32_t *)ctx->d_carry.p;
             }
         }
