@@ -458,7 +458,11 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
         const int64_t hi = std::min(size, scanned_to + std::min<int64_t>(region, (int64_t)std::max(1, nthreads) * 0xFFFF0000LL));
         const int T = std::max(1, std::min<int>(nthreads, (int)std::min<int64_t>((hi - scanned_to) >> 20, 1 << 20) + 1));
         const int64_t span = (hi - scanned_to + T - 1) / T;
-        std::vector<std::unique_ptr<uint32_t[]>> pos((size_t)T);
+        // (the slices' newline vectors are kept by the calling thread across calls — the pipeline's reader thread indexes every
+        // batch: a fresh 28 MB of them per 2^19-read batch would be page-faulted in again each time)
+        static thread_local std::vector<std::vector<uint32_t>> pos_keep;
+        if (pos_keep.size() < (size_t)T) pos_keep.resize((size_t)T);
+        std::vector<std::vector<uint32_t>> &pos = pos_keep;
         std::vector<int64_t> cnt((size_t)T, 0);
         {
                         parallel_for(T, [&](const int t) {
@@ -468,7 +472,9 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
                     // generous is tried first and the slice is rescanned with the exact count if it does not hold)
                     int64_t cap = (b - a) / 24 + 64;
                     for (;;) {
-                        std::unique_ptr<uint32_t[]> v(new uint32_t[(size_t)cap]);
+                        std::vector<uint32_t> &v = pos[(size_t)t];
+                        if ((int64_t)v.size() < cap) v.resize((size_t)cap);
+                        cap = (int64_t)v.size();
                         const uint8_t *p = d + a, *e = d + b;
                         int64_t n = 0;
                         bool fits = true;
@@ -481,7 +487,6 @@ static int64_t index_range(const uint8_t *d, const int64_t size, const bool fina
                             p = q + 1;
                         }
                         if (fits) {
-                            pos[(size_t)t] = std::move(v);
                             cnt[(size_t)t] = n;
                             break;
                         }
