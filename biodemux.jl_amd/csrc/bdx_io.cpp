@@ -738,13 +738,18 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
     for (int c = 0; c < n_classes; ++c)
         if (csize[(size_t)c] > 0) todo.push_back(c);
     struct Dest {
-        uint8_t *base = nullptr;              // gather buffer (heap), or
-        std::unique_ptr<uint8_t[]> heap;
-        std::unique_ptr<struct iovec[]> iov;  // the records as iovecs into the input
+        uint8_t *base = nullptr;      // gather buffer, or
+        struct iovec *iov = nullptr;  // the records as iovecs into the input
         bool gz = false;
         int fail = 0;
     };
     std::vector<Dest> dest((size_t)n_classes);
+    // (gather buffers and iovec arrays are kept by the calling thread — the pipeline's writer thread — across batches: 7 MB of
+    // iovecs and the 21 MB buffer of the unmatched reads per 2^19-read batch would be allocated and page-faulted in again)
+    static thread_local std::vector<std::vector<uint8_t>> heap_keep;
+    static thread_local std::vector<std::vector<struct iovec>> iov_keep;
+    if (heap_keep.size() < (size_t)n_classes) heap_keep.resize((size_t)n_classes);
+    if (iov_keep.size() < (size_t)n_classes) iov_keep.resize((size_t)n_classes);
     static const int64_t IOV_LIMIT = getenv("BDX_IO_IOV_LIMIT") ? atoll(getenv("BDX_IO_IOV_LIMIT")) : (int64_t)8 << 20;  // classes with more bytes than this in a batch are gathered
     for (int c : todo) {
         Dest &ds = dest[(size_t)c];
@@ -752,10 +757,13 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
         std::transform(low.begin(), low.end(), low.begin(), ::tolower);
         ds.gz = force_gzip || (low.size() >= 3 && low.compare(low.size() - 3, 3, ".gz") == 0);
         if (!ds.gz && cplain[(size_t)c] && csize[(size_t)c] <= IOV_LIMIT) {
-            ds.iov.reset(new struct iovec[(size_t)crecs[(size_t)c]]);
+            std::vector<struct iovec> &v = iov_keep[(size_t)c];
+            if (v.size() < (size_t)crecs[(size_t)c]) v.resize((size_t)crecs[(size_t)c]);
+            ds.iov = v.data();
         } else {
-            ds.heap.reset(new uint8_t[(size_t)csize[(size_t)c]]);
-            ds.base = ds.heap.get();
+            std::vector<uint8_t> &v = heap_keep[(size_t)c];
+            if (v.size() < (size_t)csize[(size_t)c]) v.resize((size_t)csize[(size_t)c]);
+            ds.base = v.data();
         }
     }
     const bool any_fail = false;
@@ -907,7 +915,7 @@ static int32_t demux_write_impl(const bdx_fq_file *src, const int64_t *line_off,
                         continue;
                     }
                     if (ds.iov) {
-                        struct iovec *v = ds.iov.get();
+                        struct iovec *v = ds.iov;
                         int64_t left = crecs[(size_t)c];
                         while (left > 0 && !ds.fail) {
                             const int n = (int)std::min<int64_t>(left, 1024);  // IOV_MAX
